@@ -1,0 +1,237 @@
+"""oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes bindings for the CPU restatement of the reference's registration path
+(oracle/*_oracle.c -> oracle/liboracle.so) and, when present, for the
+reference's own vendored nanoflann compiled into oracle/_ref.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; nothing under simpleslam_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "liboracle.so")
+_REF = os.path.join(_DIR, "_ref", "libref_nanoflann.so")
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB) or any(
+        os.path.getmtime(os.path.join(_DIR, f)) > os.path.getmtime(_LIB)
+        for f in os.listdir(_DIR) if f.endswith("_oracle.c")
+    ):
+        subprocess.check_call(["make", "-C", _DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(_REF) or force:
+        subprocess.check_call(["make", "-C", _DIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+class LoamParams(C.Structure):
+    _fields_ = [
+        ("plane_pts", C.c_int), ("knn_max_sq", C.c_double), ("plane_thresh", C.c_double),
+        ("point_thresh", C.c_double), ("pos_conv", C.c_double), ("rot_conv", C.c_double),
+        ("iters", C.c_int), ("early_exit", C.c_int), ("threads", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.oracle_kd_build.restype = C.c_void_p
+        L.oracle_kd_build.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        L.oracle_kd_free.argtypes = [C.c_void_p]
+        L.oracle_kd_knn.restype = C.c_int
+        L.oracle_kd_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_knn_brute.restype = C.c_int
+        L.oracle_knn_brute.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_colpiv_qr_solve_5x3.restype = C.c_int
+        L.oracle_colpiv_qr_solve_5x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_plane_fit5.restype = C.c_int
+        L.oracle_plane_fit5.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        L.oracle_ldlt6_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_t2se3.argtypes = [C.c_void_p]
+        L.oracle_pose_update.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_loam_default_params.argtypes = [C.POINTER(LoamParams)]
+        L.oracle_loam_linearize.restype = C.c_long
+        L.oracle_loam_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                            C.POINTER(LoamParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        L.oracle_loam_scan2map.restype = C.c_int
+        L.oracle_loam_scan2map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                           C.POINTER(LoamParams), C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] >= 3
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def loam_params(**kw):
+    p = LoamParams()
+    lib().oracle_loam_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class KdTree:
+    """Exact k-NN index over float xyz rows (own restatement)."""
+
+    def __init__(self, pts):
+        self.pts = _f32(pts)
+        self.h = lib().oracle_kd_build(_p(self.pts), self.pts.shape[0], self.pts.shape[1])
+
+    def knn(self, queries, k=5):
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+        idx = np.full((q.shape[0], k), -1, np.int32)
+        d2 = np.full((q.shape[0], k), np.inf, np.float64)
+        L = lib()
+        for i in range(q.shape[0]):
+            L.oracle_kd_knn(self.h, _p(q[i]), k, _p(idx[i]), _p(d2[i]))
+        return idx, d2
+
+    def __del__(self):
+        try:
+            lib().oracle_kd_free(self.h)
+        except Exception:
+            pass
+
+
+def knn_brute(pts, queries, k=5):
+    pts = _f32(pts)
+    q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+    idx = np.full((q.shape[0], k), -1, np.int32)
+    d2 = np.full((q.shape[0], k), np.inf, np.float64)
+    L = lib()
+    for i in range(q.shape[0]):
+        L.oracle_knn_brute(_p(pts), pts.shape[0], pts.shape[1], _p(q[i]), k, _p(idx[i]), _p(d2[i]))
+    return idx, d2
+
+
+def colpiv_qr_solve_5x3(A, b):
+    A = np.ascontiguousarray(A, np.float64).reshape(5, 3)
+    b = np.ascontiguousarray(b, np.float64).reshape(5)
+    x = np.zeros(3)
+    r = lib().oracle_colpiv_qr_solve_5x3(_p(A), _p(b), _p(x))
+    return x, r
+
+
+def plane_fit5(A, thresh=float(np.float32(0.2))):
+    A = np.ascontiguousarray(A, np.float64).reshape(5, 3)
+    x = np.zeros(3)
+    ok = lib().oracle_plane_fit5(_p(A), _p(x), thresh)
+    return x, bool(ok)
+
+
+def ldlt6_solve(M, rhs):
+    M = np.ascontiguousarray(M, np.float64).reshape(6, 6)
+    rhs = np.ascontiguousarray(rhs, np.float64).reshape(6)
+    x = np.zeros(6)
+    lib().oracle_ldlt6_solve(_p(M), _p(rhs), _p(x))
+    return x
+
+
+def se3_exp(k):
+    """4x4 (numpy row/col indexable) of exp([rho; omega])."""
+    k = np.ascontiguousarray(k, np.float64).reshape(6)
+    T = np.zeros(16)
+    lib().oracle_se3_exp(_p(k), _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def t2se3(T):
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16).copy()
+    lib().oracle_t2se3(_p(Tc))
+    return Tc.reshape(4, 4).T.copy()
+
+
+def loam_linearize(tree, src, pose, params=None, per_point=False):
+    """One linearisation. pose: 4x4. Returns dict(JtJ 6x6, JtE 6, n[, status, rows, nn])."""
+    src = _f32(src)
+    params = params or loam_params()
+    pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16)
+    JtJ = np.zeros(36)
+    JtE = np.zeros(6)
+    n_src = src.shape[0]
+    status = np.zeros(n_src, np.int8) if per_point else None
+    rows = np.zeros((n_src, 7)) if per_point else None
+    nn = np.zeros((n_src, 5), np.int32) if per_point else None
+    n = lib().oracle_loam_linearize(tree.h, _p(src), n_src, src.shape[1], _p(pc), C.byref(params), _p(JtJ), _p(JtE),
+                                    _p(status), _p(rows), _p(nn))
+    out = dict(JtJ=JtJ.reshape(6, 6), JtE=JtE, n=int(n))
+    if per_point:
+        out.update(status=status, rows=rows, nn=nn)
+    return out
+
+
+def loam_scan2map(src, dst, pose, params=None, trace=False):
+    """Full LOAM scan2Map. Returns (pose 4x4, converged, info)."""
+    src = _f32(src)
+    dst = _f32(dst)
+    assert src.shape[1] == dst.shape[1], "src/dst must share a row stride"
+    params = params or loam_params()
+    pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16).copy()
+    tr = np.zeros((params.iters, 43)) if trace else None
+    tx = np.zeros((params.iters, 6)) if trace else None
+    nrun = C.c_int(0)
+    conv = lib().oracle_loam_scan2map(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc),
+                                      C.byref(params), _p(tr), _p(tx), C.byref(nrun))
+    info = dict(iters_run=nrun.value)
+    if trace:
+        info.update(JtJ=tr[:, :36].reshape(-1, 6, 6), JtE=tr[:, 36:42], n=tr[:, 42].astype(np.int64), x=tx)
+    return pc.reshape(4, 4).T.copy(), bool(conv), info
+
+
+# ---------------------------------------------------------------------------
+# The reference's own nanoflann (oracle/_ref), when it was built
+# ---------------------------------------------------------------------------
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(_REF)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        if not ref_available():
+            build()
+        R = C.CDLL(_REF)
+        R.ref_kd_build.restype = C.c_void_p
+        R.ref_kd_build.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        R.ref_kd_free.argtypes = [C.c_void_p]
+        R.ref_kd_knn_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        _ref = R
+    return _ref
+
+
+def ref_knn(pts, queries_f32, k=5):
+    """k-NN through the reference's vendored nanoflann (f64 distance on f32 coords)."""
+    pts = _f32(pts)
+    q = _f32(queries_f32)
+    R = ref_lib()
+    h = R.ref_kd_build(_p(pts), pts.shape[0], pts.shape[1])
+    idx = np.zeros((q.shape[0], k), np.int64)
+    d2 = np.zeros((q.shape[0], k), np.float64)
+    R.ref_kd_knn_batch(h, _p(q), q.shape[0], q.shape[1], k, _p(idx), _p(d2))
+    R.ref_kd_free(h)
+    return idx, d2

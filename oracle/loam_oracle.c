@@ -1,0 +1,595 @@
+/*
+ * oracle/loam_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C99 + OpenMP) of the reference's LOAM scan-to-map
+ * registration, used only as the parity checker in tests/, in
+ * __graft_entry__.smoke() and as bench.py's cpu_baseline leg.  The shipped
+ * library (simpleslam_amd/csrc) never includes, links or calls this file.
+ *
+ * Follows (all paths relative to the reference tree):
+ *   PCR/src/LoamRegister.cpp:29-45    plane LS solve + validity gate
+ *   PCR/src/LoamRegister.cpp:47-72    5-NN gather + squared-distance gate
+ *   PCR/src/LoamRegister.cpp:99-223   Gauss-Newton driver
+ *   PCR/include/PCR/LoamRegister.hpp:30-40,70-77   constants, _J_e_wrt_x, _dist
+ *   common/geometry/manifolds.hpp:33-68   SE(3) exp, J_SE3
+ *   common/geometry/matrix.hpp:13-18      skew
+ *   common/geometry/trans.hpp:54-65       T2SE3 / rot2q
+ *   third_parties/nanoflann/.../pcl_adaptor.hpp:47-58 + nanoflann.hpp:201-234,
+ *   510-540  exact k-NN, f64 squared distance accumulated x,y,z in that order
+ *
+ * PARITY STATUS: "parity unpinned" for everything downstream of the k-NN
+ * stage.  The reference ships no golden vectors and its LOAM
+ * path cannot be compiled here (needs Eigen/PCL/spdlog, all absent), so the
+ * Eigen routines it calls (ColPivHouseholderQR::solve, LDLT::solve,
+ * Quaternion(R).normalized().toRotationMatrix()) are restated from their
+ * published algorithms and cross-checked against numpy/scipy in tests/.
+ * The k-NN stage IS pinned: tests compare it with the reference's own vendored
+ * nanoflann.hpp compiled into oracle/_ref (see oracle/Makefile).
+ *
+ * Deliberate, documented deviations from the reference (none changes a result
+ * beyond rounding):
+ *   - equal-distance ties in the k-NN are broken by lower original index
+ *     (nanoflann: by tree traversal order);
+ *   - accepted rows are summed in scan-point order (the reference pushes rows
+ *     under `omp critical` in a nondeterministic order, LoamRegister.cpp:153).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* k-d tree over float3 points (exact k-NN, f64 distances)             */
+/* ------------------------------------------------------------------ */
+
+#define KD_LEAF 10 /* nanoflann.hpp:697 leaf_max_size */
+
+typedef struct {
+    int32_t left, right; /* children, -1 for leaf */
+    int32_t lo, hi;      /* leaf: range in perm[] */
+    int32_t dim;
+    double split_lo, split_hi; /* max of left side, min of right side along dim */
+} kd_node;
+
+typedef struct {
+    const float *pts; /* n x stride floats, xyz first */
+    size_t stride;    /* in floats */
+    int32_t n;
+    int32_t *perm;
+    kd_node *nodes;
+    int32_t n_nodes, cap_nodes;
+} kd_tree;
+
+static inline double kd_coord(const kd_tree *t, int32_t i, int d)
+{
+    return (double)t->pts[(size_t)i * t->stride + d];
+}
+
+static int32_t kd_new_node(kd_tree *t)
+{
+    if (t->n_nodes == t->cap_nodes) {
+        t->cap_nodes = t->cap_nodes ? t->cap_nodes * 2 : 1024;
+        t->nodes = (kd_node *)realloc(t->nodes, sizeof(kd_node) * (size_t)t->cap_nodes);
+    }
+    return t->n_nodes++;
+}
+
+/* quickselect on perm[lo,hi) by coordinate dim so that perm[mid] is in place */
+static void kd_select(kd_tree *t, int32_t lo, int32_t hi, int32_t mid, int dim)
+{
+    while (hi - lo > 1) {
+        /* median of three pivot */
+        int32_t a = lo, b = lo + (hi - lo) / 2, c = hi - 1;
+        double va = kd_coord(t, t->perm[a], dim), vb = kd_coord(t, t->perm[b], dim),
+               vc = kd_coord(t, t->perm[c], dim);
+        int32_t p = (va < vb) ? ((vb < vc) ? b : (va < vc ? c : a)) : ((va < vc) ? a : (vb < vc ? c : b));
+        double pv = kd_coord(t, t->perm[p], dim);
+        int32_t tmp = t->perm[p]; t->perm[p] = t->perm[hi - 1]; t->perm[hi - 1] = tmp;
+        int32_t s = lo;
+        for (int32_t i = lo; i < hi - 1; ++i) {
+            if (kd_coord(t, t->perm[i], dim) < pv) {
+                tmp = t->perm[i]; t->perm[i] = t->perm[s]; t->perm[s] = tmp; ++s;
+            }
+        }
+        tmp = t->perm[s]; t->perm[s] = t->perm[hi - 1]; t->perm[hi - 1] = tmp;
+        if (s == mid) return;
+        if (mid < s) hi = s; else lo = s + 1;
+    }
+}
+
+static int32_t kd_build_rec(kd_tree *t, int32_t lo, int32_t hi)
+{
+    int32_t id = kd_new_node(t);
+    if (hi - lo <= KD_LEAF) {
+        kd_node nd; nd.left = nd.right = -1; nd.lo = lo; nd.hi = hi; nd.dim = 0;
+        nd.split_lo = nd.split_hi = 0.0;
+        t->nodes[id] = nd;
+        return id;
+    }
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int32_t i = lo; i < hi; ++i)
+        for (int d = 0; d < 3; ++d) {
+            double v = kd_coord(t, t->perm[i], d);
+            if (v < mn[d]) mn[d] = v;
+            if (v > mx[d]) mx[d] = v;
+        }
+    int dim = 0;
+    if (mx[1] - mn[1] > mx[dim] - mn[dim]) dim = 1;
+    if (mx[2] - mn[2] > mx[dim] - mn[dim]) dim = 2;
+    int32_t mid = lo + (hi - lo) / 2;
+    if (mx[dim] > mn[dim]) kd_select(t, lo, hi, mid, dim);
+    double slo = -DBL_MAX, shi = DBL_MAX;
+    for (int32_t i = lo; i < mid; ++i) { double v = kd_coord(t, t->perm[i], dim); if (v > slo) slo = v; }
+    for (int32_t i = mid; i < hi; ++i) { double v = kd_coord(t, t->perm[i], dim); if (v < shi) shi = v; }
+    int32_t l = kd_build_rec(t, lo, mid);
+    int32_t r = kd_build_rec(t, mid, hi);
+    kd_node nd; nd.left = l; nd.right = r; nd.lo = lo; nd.hi = hi; nd.dim = dim;
+    nd.split_lo = slo; nd.split_hi = shi;
+    t->nodes[id] = nd;
+    return id;
+}
+
+kd_tree *oracle_kd_build(const float *pts, size_t n, size_t stride_floats)
+{
+    kd_tree *t = (kd_tree *)calloc(1, sizeof(kd_tree));
+    t->pts = pts; t->stride = stride_floats; t->n = (int32_t)n;
+    t->perm = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    for (int32_t i = 0; i < (int32_t)n; ++i) t->perm[i] = i;
+    if (n) kd_build_rec(t, 0, (int32_t)n);
+    return t;
+}
+
+void oracle_kd_free(kd_tree *t)
+{
+    if (!t) return;
+    free(t->perm); free(t->nodes); free(t);
+}
+
+typedef struct {
+    int k, count;
+    double d[32];
+    int32_t idx[32];
+} knn_set;
+
+/* ordered by (d, idx) lexicographic: the documented tie-break */
+static inline int knn_less(double d, int32_t i, double d2, int32_t i2)
+{
+    return d < d2 || (d == d2 && i < i2);
+}
+
+static inline void knn_add(knn_set *s, double d, int32_t idx)
+{
+    if (s->count == s->k && !knn_less(d, idx, s->d[s->k - 1], s->idx[s->k - 1])) return;
+    int i = (s->count < s->k) ? s->count++ : s->k - 1;
+    while (i > 0 && knn_less(d, idx, s->d[i - 1], s->idx[i - 1])) {
+        s->d[i] = s->d[i - 1]; s->idx[i] = s->idx[i - 1]; --i;
+    }
+    s->d[i] = d; s->idx[i] = idx;
+}
+
+/* f64 squared distance accumulated x, y, z in that order with no FMA
+ * (nanoflann.hpp:523-535, L2_Simple_Adaptor::evalMetric). */
+static inline double sqdist(const double q[3], const kd_tree *t, int32_t i)
+{
+    double r = 0.0;
+    for (int d = 0; d < 3; ++d) {
+        double diff = q[d] - kd_coord(t, i, d);
+        r += diff * diff;
+    }
+    return r;
+}
+
+static void kd_search_rec(const kd_tree *t, int32_t id, const double q[3], knn_set *s)
+{
+    const kd_node *nd = &t->nodes[id];
+    if (nd->left < 0) {
+        for (int32_t i = nd->lo; i < nd->hi; ++i) knn_add(s, sqdist(q, t, t->perm[i]), t->perm[i]);
+        return;
+    }
+    double v = q[nd->dim];
+    /* gap to each side along the split dimension */
+    double gl = v - nd->split_lo; gl = gl > 0 ? gl : 0; /* distance to left side  */
+    double gr = nd->split_hi - v; gr = gr > 0 ? gr : 0; /* distance to right side */
+    int32_t first = (gl <= gr) ? nd->left : nd->right;
+    int32_t second = (gl <= gr) ? nd->right : nd->left;
+    double gsecond = (gl <= gr) ? gr : gl;
+    kd_search_rec(t, first, q, s);
+    /* <= keeps equal-distance candidates reachable for the index tie-break */
+    if (s->count < s->k || gsecond * gsecond <= s->d[s->k - 1]) kd_search_rec(t, second, q, s);
+}
+
+/* exact k-NN; returns number found (min(k, n)); outputs sorted ascending */
+int oracle_kd_knn(const kd_tree *t, const double q[3], int k, int32_t *idx_out, double *d_out)
+{
+    knn_set s; s.k = k > 32 ? 32 : k; s.count = 0;
+    if (t->n > 0) kd_search_rec(t, 0, q, &s);
+    for (int i = 0; i < s.count; ++i) { idx_out[i] = s.idx[i]; d_out[i] = s.d[i]; }
+    return s.count;
+}
+
+/* brute-force exact k-NN (independent of the tree; for small fixtures) */
+int oracle_knn_brute(const float *pts, size_t n, size_t stride_floats, const double q[3], int k,
+                     int32_t *idx_out, double *d_out)
+{
+    kd_tree t; memset(&t, 0, sizeof t); t.pts = pts; t.stride = stride_floats; t.n = (int32_t)n;
+    knn_set s; s.k = k > 32 ? 32 : k; s.count = 0;
+    for (int32_t i = 0; i < (int32_t)n; ++i) knn_add(&s, sqdist(q, &t, i), i);
+    for (int i = 0; i < s.count; ++i) { idx_out[i] = s.idx[i]; d_out[i] = s.d[i]; }
+    return s.count;
+}
+
+/* ------------------------------------------------------------------ */
+/* Plane fit: A(5x3) x = -1 by column-pivoted Householder QR           */
+/* ------------------------------------------------------------------ */
+/*
+ * Restates Eigen::ColPivHouseholderQR<Matrix<double,5,3>>::compute + solve
+ * (called at LoamRegister.cpp:34) from the published algorithm (LAPACK
+ * dgeqp3-style norm down-dating, Eigen 3.3/3.4 rank rule: a pivot column whose
+ * remaining squared norm falls below (eps*maxnorm)^2 * (rows-k)/rows ends the
+ * factorisation; solve() zeroes the unknowns of the dropped columns).
+ * A is row-major 5x3.  Returns the number of nonzero pivots.
+ */
+int oracle_colpiv_qr_solve_5x3(const double A_in[15], const double b_in[5], double x[3])
+{
+    enum { R = 5, C = 3 };
+    double a[R][C], c[R];
+    for (int i = 0; i < R; ++i) { for (int j = 0; j < C; ++j) a[i][j] = A_in[i * C + j]; c[i] = b_in[i]; }
+    int perm[C] = {0, 1, 2};
+    double tau[C] = {0, 0, 0};
+    double norm_upd[C], norm_dir[C];
+    double maxn = 0;
+    for (int j = 0; j < C; ++j) {
+        double s = 0; for (int i = 0; i < R; ++i) s += a[i][j] * a[i][j];
+        norm_dir[j] = norm_upd[j] = sqrt(s);
+        if (norm_upd[j] > maxn) maxn = norm_upd[j];
+    }
+    const double eps = DBL_EPSILON;
+    const double thr_helper = (maxn * eps) * (maxn * eps) / (double)R;
+    const double downdate_thr = sqrt(eps);
+    int nonzero = C;
+    for (int k = 0; k < C; ++k) {
+        int big = k; double bign = norm_upd[k];
+        for (int j = k + 1; j < C; ++j) if (norm_upd[j] > bign) { bign = norm_upd[j]; big = j; }
+        double big_sq = bign * bign;
+        if (nonzero == C && big_sq < thr_helper * (double)(R - k)) nonzero = k;
+        if (big != k) {
+            for (int i = 0; i < R; ++i) { double t = a[i][k]; a[i][k] = a[i][big]; a[i][big] = t; }
+            double t = norm_upd[k]; norm_upd[k] = norm_upd[big]; norm_upd[big] = t;
+            t = norm_dir[k]; norm_dir[k] = norm_dir[big]; norm_dir[big] = t;
+            int ti = perm[k]; perm[k] = perm[big]; perm[big] = ti;
+        }
+        /* Householder reflector for a[k..R-1][k] */
+        double tail_sq = 0; for (int i = k + 1; i < R; ++i) tail_sq += a[i][k] * a[i][k];
+        double c0 = a[k][k], beta;
+        if (tail_sq <= DBL_MIN) {
+            tau[k] = 0; beta = c0;
+            for (int i = k + 1; i < R; ++i) a[i][k] = 0;
+        } else {
+            beta = sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0) beta = -beta;
+            for (int i = k + 1; i < R; ++i) a[i][k] /= (c0 - beta);
+            tau[k] = (beta - c0) / beta;
+        }
+        a[k][k] = beta;
+        /* apply H = I - tau v v^T (v = [1; essential]) to remaining columns */
+        for (int j = k + 1; j < C; ++j) {
+            double tmp = 0; for (int i = k + 1; i < R; ++i) tmp += a[i][k] * a[i][j];
+            tmp += a[k][j];
+            a[k][j] -= tau[k] * tmp;
+            for (int i = k + 1; i < R; ++i) a[i][j] -= tau[k] * a[i][k] * tmp;
+        }
+        /* norm down-dating */
+        for (int j = k + 1; j < C; ++j) {
+            if (norm_upd[j] != 0) {
+                double temp = fabs(a[k][j]) / norm_upd[j];
+                temp = (1.0 + temp) * (1.0 - temp);
+                if (temp < 0) temp = 0;
+                double r = norm_upd[j] / norm_dir[j];
+                double temp2 = temp * r * r;
+                if (temp2 <= downdate_thr) {
+                    double s = 0; for (int i = k + 1; i < R; ++i) s += a[i][j] * a[i][j];
+                    norm_dir[j] = sqrt(s); norm_upd[j] = norm_dir[j];
+                } else {
+                    norm_upd[j] *= sqrt(temp);
+                }
+            }
+        }
+    }
+    /* c = Q^T b using the first `nonzero` reflectors */
+    for (int k = 0; k < nonzero; ++k) {
+        double tmp = 0; for (int i = k + 1; i < R; ++i) tmp += a[i][k] * c[i];
+        tmp += c[k];
+        c[k] -= tau[k] * tmp;
+        for (int i = k + 1; i < R; ++i) c[i] -= tau[k] * a[i][k] * tmp;
+    }
+    /* back-substitute the leading nonzero x nonzero upper triangle */
+    double y[C] = {0, 0, 0};
+    for (int i = nonzero - 1; i >= 0; --i) {
+        double s = c[i];
+        for (int j = i + 1; j < nonzero; ++j) s -= a[i][j] * y[j];
+        y[i] = s / a[i][i];
+    }
+    for (int i = 0; i < C; ++i) x[perm[i]] = (i < nonzero) ? y[i] : 0.0;
+    return nonzero;
+}
+
+/* LoamRegister.cpp:29-45: solve A x = -1, then every |x.a_i + 1| must be
+ * <= 0.2*|x|.  Returns 1 when the plane is valid. */
+int oracle_plane_fit5(const double A[15], double x[3], double plane_thresh)
+{
+    const double b[5] = {-1, -1, -1, -1, -1};
+    oracle_colpiv_qr_solve_5x3(A, b, x);
+    double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    for (int i = 0; i < 5; ++i) {
+        double dot = x[0] * A[i * 3 + 0] + x[1] * A[i * 3 + 1] + x[2] * A[i * 3 + 2];
+        if (fabs(dot + 1.0) > plane_thresh * xn) return 0;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* 6x6 LDLT solve (Eigen::LDLT: diagonal pivoting, lower)              */
+/* ------------------------------------------------------------------ */
+/* Restates Eigen::LDLT<Matrix6d>::compute + solve (LoamRegister.cpp:198):
+ * at step k the largest |diagonal| of the trailing block is brought to (k,k)
+ * by a symmetric swap; D entries with |d| <= DBL_MIN give 0 in the solve.
+ * M is row-major symmetric 6x6 (only the lower triangle is read). */
+void oracle_ldlt6_solve(const double M_in[36], const double rhs[6], double x[6])
+{
+    enum { N = 6 };
+    double m[N][N];
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = (j <= i) ? M_in[i * N + j] : M_in[j * N + i];
+    int tr[N];
+    for (int k = 0; k < N; ++k) {
+        int p = k; double big = fabs(m[k][k]);
+        for (int i = k + 1; i < N; ++i) if (fabs(m[i][i]) > big) { big = fabs(m[i][i]); p = i; }
+        tr[k] = p;
+        if (p != k) {
+            /* symmetric swap of rows/cols k and p acting on the lower triangle */
+            for (int j = 0; j < k; ++j) { double t = m[k][j]; m[k][j] = m[p][j]; m[p][j] = t; }
+            for (int i = p + 1; i < N; ++i) { double t = m[i][k]; m[i][k] = m[i][p]; m[i][p] = t; }
+            for (int i = k + 1; i < p; ++i) { double t = m[i][k]; m[i][k] = m[p][i]; m[p][i] = t; }
+            double t = m[k][k]; m[k][k] = m[p][p]; m[p][p] = t;
+        }
+        /* A21 -= A20 * (D0 .* A10^T);  a11 -= A10 * (D0 .* A10^T) */
+        if (k > 0) {
+            double temp[N];
+            for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+            double s = 0; for (int j = 0; j < k; ++j) s += m[k][j] * temp[j];
+            m[k][k] -= s;
+            for (int i = k + 1; i < N; ++i) {
+                double s2 = 0; for (int j = 0; j < k; ++j) s2 += m[i][j] * temp[j];
+                m[i][k] -= s2;
+            }
+        }
+        double piv = m[k][k];
+        if (fabs(piv) > 0.0) for (int i = k + 1; i < N; ++i) m[i][k] /= piv;
+    }
+    double y[N];
+    for (int i = 0; i < N; ++i) y[i] = rhs[i];
+    for (int k = 0; k < N; ++k) if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) y[i] -= m[i][j] * y[j];
+    for (int i = 0; i < N; ++i) y[i] = (fabs(m[i][i]) > DBL_MIN) ? y[i] / m[i][i] : 0.0;
+    for (int i = N - 1; i >= 0; --i) for (int j = i + 1; j < N; ++j) y[i] -= m[j][i] * y[j];
+    for (int k = N - 1; k >= 0; --k) if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+/* ------------------------------------------------------------------ */
+/* SE(3) exp, T2SE3                                                    */
+/* ------------------------------------------------------------------ */
+/* manifolds.hpp:33-60.  k = [rho; omega]; T is column-major 4x4. */
+void oracle_se3_exp(const double k[6], double T[16])
+{
+    const double *p = k, *w = k + 3;
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    double t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (t < 1e-6) { T[12] = p[0]; T[13] = p[1]; T[14] = p[2]; return; }
+    double a[3] = {w[0] / t, w[1] / t, w[2] / t};
+    double ct = cos(t), st = sin(t);
+    /* a_hat (matrix.hpp:13-18), row-major */
+    double ah[3][3] = {{0, -a[2], a[1]}, {a[2], 0, -a[0]}, {-a[1], a[0], 0}};
+    double Rm[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double I = (i == j) ? 1.0 : 0.0, aa = a[i] * a[j];
+            Rm[i][j] = ct * I + (1.0 - ct) * aa + st * ah[i][j];
+            V[i][j] = st / t * I + (1.0 - st / t) * aa + ((1 - ct) / t) * ah[i][j];
+        }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[j * 4 + i] = Rm[i][j];
+        T[12 + i] = V[i][0] * p[0] + V[i][1] * p[1] + V[i][2] * p[2];
+    }
+}
+
+/* trans.hpp:54-65: R <- Quaternion(R).normalized().toRotationMatrix()
+ * (Eigen's matrix->quaternion branch on the trace).  T column-major 4x4. */
+void oracle_t2se3(double T[16])
+{
+#define M(i, j) T[(j) * 4 + (i)]
+    double q[4]; /* x y z w */
+    double t = M(0, 0) + M(1, 1) + M(2, 2);
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (M(2, 1) - M(1, 2)) * t; q[1] = (M(0, 2) - M(2, 0)) * t; q[2] = (M(1, 0) - M(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (M(k, j) - M(j, k)) * t;
+        q[j] = (M(j, i) + M(i, j)) * t;
+        q[k] = (M(k, i) + M(i, k)) * t;
+    }
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+           tyz = tz * y, tzz = tz * z;
+    M(0, 0) = 1 - (tyy + tzz); M(0, 1) = txy - twz; M(0, 2) = txz + twy;
+    M(1, 0) = txy + twz; M(1, 1) = 1 - (txx + tzz); M(1, 2) = tyz - twx;
+    M(2, 0) = txz - twy; M(2, 1) = tyz + twx; M(2, 2) = 1 - (txx + tyy);
+#undef M
+}
+
+/* ------------------------------------------------------------------ */
+/* One linearisation (the hot loop, LoamRegister.cpp:122-164)           */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    int plane_pts;       /* 5 (fixed; kept for documentation) */
+    double knn_max_sq;   /* 1.0  LoamRegister.hpp:31 */
+    double plane_thresh; /* 0.2  LoamRegister.hpp:32 */
+    double point_thresh; /* 0.1  LoamRegister.hpp:33 */
+    double pos_conv;     /* 5e-3 LoamRegister.hpp:37 */
+    double rot_conv;     /* 5e-3 LoamRegister.hpp:38 */
+    int iters;           /* 8    LoamRegister.hpp:40 */
+    int early_exit;      /* 1 = reference behaviour (LoamRegister.cpp:202-206) */
+    int threads;         /* OpenMP team size (`cores`, PointCloudRegister.hpp:31) */
+} oracle_loam_params;
+
+void oracle_loam_default_params(oracle_loam_params *p)
+{
+    p->plane_pts = 5; p->knn_max_sq = (double)1.0f; p->plane_thresh = (double)0.2f; p->point_thresh = (double)0.1f;
+    p->pos_conv = (double)5e-3f; p->rot_conv = (double)5e-3f; p->iters = 8; p->early_exit = 1; p->threads = 1;
+}
+
+/* Per-point evaluation.  status: 0 accepted, 1 k-NN gate, 2 plane gate,
+ * 3 weight gate.  row[0..5] = s*[n ; p x n], row[6] = s*dist. */
+static int loam_point(const kd_tree *t, const float *sp, const double pose[16], const oracle_loam_params *prm,
+                      double row[7], int32_t nn_idx[5])
+{
+    /* LoamRegister.cpp:126-130: f64 transform, then cast to f32 */
+    double ox = (double)sp[0], oy = (double)sp[1], oz = (double)sp[2];
+    float pm[3];
+    for (int i = 0; i < 3; ++i) {
+        double v = pose[0 * 4 + i] * ox + pose[1 * 4 + i] * oy + pose[2 * 4 + i] * oz + pose[3 * 4 + i] * 1.0;
+        pm[i] = (float)v;
+    }
+    double q[3] = {(double)pm[0], (double)pm[1], (double)pm[2]};
+    double nd[5];
+    int found = oracle_kd_knn(t, q, 5, nn_idx, nd);
+    if (found < 5 || !(nd[4] < prm->knn_max_sq)) return 1; /* LoamRegister.cpp:59 */
+    double A[15];
+    for (int j = 0; j < 5; ++j)
+        for (int d = 0; d < 3; ++d) A[j * 3 + d] = kd_coord(t, nn_idx[j], d);
+    double x[3];
+    if (!oracle_plane_fit5(A, x, prm->plane_thresh)) return 2;
+    double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    double dist = (q[0] * x[0] + q[1] * x[1] + q[2] * x[2] + 1.0) / xn; /* LoamRegister.hpp:75-77 */
+    /* LoamRegister.cpp:147-148: the squared range is float arithmetic; the two
+     * roots are taken in float (sqrt(float) overload) -- see DESIGN.md */
+    float r2 = sp[0] * sp[0] + sp[1] * sp[1] + sp[2] * sp[2];
+    float rr = sqrtf(sqrtf(r2));
+    double s = 1 - 0.9 * fabs(dist) / (double)rr;
+    if (!(s > prm->point_thresh)) return 3;
+    double n[3] = {x[0] / xn, x[1] / xn, x[2] / xn}; /* _J_e_wrt_x */
+    /* s * n^T [I | -p^]  = s * [n ; p x n]  (manifolds.hpp:63-68, matrix.hpp:13-18) */
+    double sn[3] = {s * n[0], s * n[1], s * n[2]};
+    row[0] = sn[0]; row[1] = sn[1]; row[2] = sn[2];
+    row[3] = sn[1] * (-q[2]) + sn[2] * q[1];
+    row[4] = sn[0] * q[2] + sn[2] * (-q[0]);
+    row[5] = sn[0] * (-q[1]) + sn[1] * q[0];
+    row[6] = s * dist;
+    return 0;
+}
+
+/*
+ * One linearisation over all scan points.  src: n_src x stride floats.
+ * JtJ (36, row-major), JtE (6).  Optional per-point outputs (may be NULL):
+ * status[n_src], rows[n_src*7], nn[n_src*5].  Returns the accepted count.
+ * Rows are summed in scan order per thread chunk, chunks in thread order.
+ */
+long oracle_loam_linearize(const kd_tree *t, const float *src, size_t n_src, size_t stride_floats,
+                           const double pose[16], const oracle_loam_params *prm, double JtJ[36], double JtE[6],
+                           int8_t *status, double *rows, int32_t *nn)
+{
+    int nth = prm->threads > 0 ? prm->threads : 1;
+    double *acc = (double *)calloc((size_t)nth * 43, sizeof(double));
+    long *cnt = (long *)calloc((size_t)nth, sizeof(long));
+#pragma omp parallel num_threads(nth)
+    {
+#ifdef _OPENMP
+        int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int tid = 0, nt = 1;
+#endif
+        size_t lo = n_src * (size_t)tid / (size_t)nt, hi = n_src * (size_t)(tid + 1) / (size_t)nt;
+        double *a = acc + (size_t)tid * 43;
+        for (size_t i = lo; i < hi; ++i) {
+            double row[7]; int32_t idx[5] = {-1, -1, -1, -1, -1};
+            int st = loam_point(t, src + i * stride_floats, pose, prm, row, idx);
+            if (status) status[i] = (int8_t)st;
+            if (nn) memcpy(nn + i * 5, idx, sizeof idx);
+            if (rows) { if (st == 0) memcpy(rows + i * 7, row, sizeof row); else memset(rows + i * 7, 0, sizeof row); }
+            if (st != 0) continue;
+            for (int r = 0; r < 6; ++r) {
+                for (int c = 0; c < 6; ++c) a[r * 6 + c] += row[r] * row[c];
+                a[36 + r] += row[r] * row[6];
+            }
+            cnt[tid]++;
+        }
+    }
+    long n = 0;
+    memset(JtJ, 0, 36 * sizeof(double)); memset(JtE, 0, 6 * sizeof(double));
+    for (int th = 0; th < nth; ++th) {
+        for (int i = 0; i < 36; ++i) JtJ[i] += acc[(size_t)th * 43 + i];
+        for (int i = 0; i < 6; ++i) JtE[i] += acc[(size_t)th * 43 + 36 + i];
+        n += cnt[th];
+    }
+    free(acc); free(cnt);
+    return n;
+}
+
+/* pose <- exp(x) * pose, both column-major 4x4 (LoamRegister.cpp:213-216) */
+void oracle_pose_update(const double x[6], double pose[16])
+{
+    double E[16], out[16];
+    oracle_se3_exp(x, E);
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += E[k * 4 + r] * pose[c * 4 + k];
+            out[c * 4 + r] = s;
+        }
+    memcpy(pose, out, sizeof out);
+}
+
+/*
+ * Full scan2Map (LoamRegister.cpp:99-223).  pose in/out column-major 4x4.
+ * trace (optional, iters*43 doubles): per iteration JtJ(36) JtE(6) n;
+ * trace_x (optional, iters*6): the solved increment.  Returns converged.
+ * n_iters_run (optional) receives the number of linearisations performed.
+ */
+int oracle_loam_scan2map(const float *src, size_t n_src, const float *dst, size_t n_dst, size_t stride_floats,
+                         double pose[16], const oracle_loam_params *prm, double *trace, double *trace_x,
+                         int *n_iters_run)
+{
+    int converged = 0, run = 0;
+    kd_tree *t = oracle_kd_build(dst, n_dst, stride_floats); /* LoamRegister.cpp:110: rebuilt every call */
+    for (int it = 0; it < prm->iters; ++it) {
+        double JtJ[36], JtE[6], x[6], rhs[6];
+        long n = oracle_loam_linearize(t, src, n_src, stride_floats, pose, prm, JtJ, JtE, NULL, NULL, NULL);
+        ++run;
+        if (trace) { memcpy(trace + it * 43, JtJ, sizeof JtJ); memcpy(trace + it * 43 + 36, JtE, sizeof JtE); trace[it * 43 + 42] = (double)n; }
+        if (n < 6) break; /* LoamRegister.cpp:173-176 */
+        for (int i = 0; i < 6; ++i) rhs[i] = -JtE[i];
+        oracle_ldlt6_solve(JtJ, rhs, x);
+        if (trace_x) memcpy(trace_x + it * 6, x, sizeof x);
+        double np = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        double nr = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+        if (prm->early_exit && np <= prm->pos_conv && nr <= prm->rot_conv) { converged = 1; break; } /* :202-206 */
+        oracle_pose_update(x, pose);
+    }
+    oracle_t2se3(pose); /* LoamRegister.cpp:220 */
+    oracle_kd_free(t);
+    if (n_iters_run) *n_iters_run = run;
+    return converged;
+}
