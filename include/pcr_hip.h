@@ -1,0 +1,152 @@
+/*
+ * pcr_hip.h -- C ABI of the MI355X-native scan-to-map registration library
+ * (libpcr_hip.so).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * It is the drop-in boundary for the reference's registration plugin
+ *   PCR::PointCloudRegister::scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res)
+ *   (reference PCR/include/PCR/PointCloudRegister.hpp:12-38)
+ * and its three implementations selected by the config key frontend.pcr
+ *   "loam"  -> PCR::LoamRegister   (PCR/src/LoamRegister.cpp:99-223)
+ *   "ndt"   -> PCR::NdtRegister    (PCR/src/NdtRegister.cpp:21-31)
+ *   "vgicp" -> PCR::VgicpRegister  (PCR/src/VgicpRegister.cpp:30-45)
+ *   (factory: frontend/src/LidarOdometry.cpp:44-54).
+ * INTEGRATION.md shows the reference-side adapter class that binds these entry
+ * points; simpleslam_amd/host/PCR mirrors the reference classes without PCL/Eigen.
+ *
+ * Conventions
+ *   - A point is `stride_bytes` bytes whose first 12 are float x,y,z.
+ *     stride 32 = pcl::PointXYZI (reference common/types/basic.hpp:16), 16 = float4.
+ *   - A pose is 16 doubles, column-major 4x4 (Eigen::Isometry3d::matrix().data(),
+ *     reference common/types/basic.hpp:19); in = initial guess, out = refined.
+ *   - Every call returns 0 on success, nonzero on error; pcr_last_error() then
+ *     describes it.  Nothing throws across this boundary.  A handle serves one
+ *     caller at a time; distinct handles are independent (own stream and buffers).
+ */
+#ifndef PCR_HIP_H
+#define PCR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcr_handle pcr_handle;
+
+/* Defaults (pcr_default_params) are the reference's constants; see SURVEY.md App. A. */
+typedef struct pcr_params {
+    uint32_t struct_size;      /* sizeof(pcr_params), set by pcr_default_params */
+    int32_t device;            /* HIP device ordinal; -1 = current device */
+
+    /* LOAM -- PCR/include/PCR/LoamRegister.hpp:30-40 */
+    int32_t loam_iters;        /* 8   iteration cap (LoamRegister.hpp:40) */
+    int32_t loam_early_exit;   /* 1   stop when the step is small (LoamRegister.cpp:202-206) */
+    double loam_knn_max_sq;    /* 1.0 gate on the SQUARED 5th-neighbour distance (LoamRegister.cpp:59) */
+    double loam_plane_thresh;  /* 0.2 plane validity, times |x| (LoamRegister.cpp:39) */
+    double loam_point_thresh;  /* 0.1 weight gate (LoamRegister.cpp:151) */
+    double loam_pos_conv;      /* 5e-3 (LoamRegister.hpp:37) */
+    double loam_rot_conv;      /* 5e-3 (LoamRegister.hpp:38) */
+
+    /* NDT -- PCR/src/NdtRegister.cpp:12-13, third_parties/pclomp/src/ndt_omp_impl.hpp:50-51,71-72 */
+    double ndt_resolution;     /* 1.0 */
+    double ndt_step_size;      /* 0.1 */
+    double ndt_outlier_ratio;  /* 0.55 */
+    double ndt_trans_eps;      /* 0.1 */
+    int32_t ndt_max_iters;     /* 35 */
+    int32_t ndt_min_points;    /* 6 points per voxel (pclomp/voxel_grid_covariance_omp.h:210) */
+
+    /* VGICP -- PCR/src/VgicpRegister.cpp:13, third_parties/pclomp/src/fast_vgicp_impl.hpp:22-24,
+     * fast_gicp_impl.hpp:16-20, lsq_registration_impl.hpp:11-18 */
+    double vgicp_resolution;   /* 1.0 */
+    int32_t vgicp_k_corr;      /* 20 neighbours for the covariances */
+    int32_t vgicp_max_iters;   /* 64 */
+    int32_t vgicp_lm_inner;    /* 10 */
+    double vgicp_rot_eps;      /* 2e-3 */
+    double vgicp_trans_eps;    /* 5e-4 */
+    double vgicp_lm_init_scale;/* 1e-9 */
+
+    int32_t record_trace;      /* 1: keep per-iteration normal equations for pcr_get_trace */
+    int32_t reserved[7];
+} pcr_params;
+
+/* Per-call device timings, from HIP events on the handle's stream. */
+typedef struct pcr_stats {
+    double total_ms;        /* whole call on the device timeline */
+    double index_ms;        /* target index build (0 when the cached index was used) */
+    double solve_ms;        /* all optimisation launches */
+    double kernel_ms;       /* sum over the dominant kernel's launches (only with pcr_set_profile(h,2)) */
+    int32_t kernel_launches;/* launches summed in kernel_ms */
+    int32_t iterations;     /* linearisations performed */
+    int64_t n_src, n_dst;
+} pcr_stats;
+
+void pcr_default_params(pcr_params* p);
+
+/* method = "loam" | "ndt" | "vgicp" (frontend.pcr).  NULL on failure; pcr_last_error(NULL)
+ * then holds the reason (unknown method: the reference factory throws,
+ * LidarOdometry.cpp:50-54).  p == NULL uses the defaults. */
+pcr_handle* pcr_create(const char* method, const pcr_params* p);
+void pcr_destroy(pcr_handle* h);
+const char* pcr_last_error(const pcr_handle* h);
+
+/* scan2Map with HOST buffers (what PCR::PointCloudRegister::scan2Map hands over:
+ * src->points.data(), dst->points.data()).  The target index is rebuilt on every
+ * call, as the reference does (LoamRegister.cpp:110).  *converged = isConverge. */
+int pcr_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst,
+                 size_t stride_bytes, double pose_inout[16], int* converged);
+
+/* Same with DEVICE-resident buffers (HBM pointers valid on the handle's device). */
+int pcr_scan2map_device(pcr_handle* h, const void* d_src, size_t n_src, const void* d_dst, size_t n_dst,
+                        size_t stride_bytes, double pose_inout[16], int* converged);
+
+/* Static-map localisation (reference test/loc.cpp: one PCD map, many scans): build
+ * the target index once, then align scans against it.  on_device != 0 marks the
+ * buffers as HBM pointers.  The library copies what it keeps. */
+int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_bytes, int on_device);
+int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
+              double pose_inout[16], int* converged);
+/* Drop the cached target (the reference caches by pointer identity and goes stale,
+ * SURVEY.md F10; this library never keys on the pointer). */
+int pcr_invalidate_target(pcr_handle* h);
+
+/* PointCloudRegister::getFitnessScore (PointCloudRegister.hpp:34; VgicpRegister.cpp:42-45):
+ * mean squared 1-NN distance of the last aligned source.  Negative when unavailable. */
+double pcr_fitness(pcr_handle* h);
+
+/* ---- introspection used by tests and bench.py ---- */
+
+/* One LOAM linearisation at `pose` against the current target (pcr_set_target):
+ * JtJ (36, row-major), JtE (6), accepted count.  Optional per-point outputs (host,
+ * may be NULL): status[n] (0 accepted, 1 k-NN gate, 2 plane gate, 3 weight gate),
+ * rows[n*7] (s*[n ; p x n], s*d), nn[n*5] (original target indices, ascending distance). */
+int pcr_loam_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
+                       const double pose[16], double JtJ[36], double JtE[6], int64_t* n_accepted,
+                       int8_t* status, double* rows, int32_t* nn);
+
+/* Per-iteration trace of the last LOAM call (params.record_trace = 1):
+ * for it < *n_iters: JtJ[it*36..], JtE[it*6..], n[it], x[it*6..]. Arrays sized for loam_iters. */
+int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int64_t* n, double* x);
+
+int pcr_get_stats(pcr_handle* h, pcr_stats* out);
+/* 0: no timing events; 1: phase events (default); 2: also an event pair around every
+ * launch of the dominant kernel (adds host work; for roofline measurement only). */
+int pcr_set_profile(pcr_handle* h, int level);
+/* Use an existing HIP stream (hipStream_t) instead of the handle's own. */
+int pcr_set_stream(pcr_handle* h, void* hip_stream);
+
+/* ---- multi-GPU (one process per GPU; map tiles + 1-cell halo per rank) ---- */
+
+/* Restrict the handle to queries whose transformed position lies in [lo, hi) (metres,
+ * map frame): each scan point is then processed by exactly one rank.  lo > hi clears it. */
+int pcr_set_query_tile(pcr_handle* h, const double lo[3], const double hi[3]);
+/* RCCL communicator for the per-linearisation all-reduce of the normal equations
+ * (28 doubles).  unique_id = 128 bytes from pcr_comm_unique_id on rank 0, shared by the
+ * caller (e.g. torch.distributed broadcast).  librccl is dlopen'ed here, never before. */
+int pcr_comm_unique_id(void* out128);
+int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_HIP_H */

@@ -22,7 +22,7 @@ def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
     if force or not os.path.exists(_LIB) or any(
         os.path.getmtime(os.path.join(_DIR, f)) > os.path.getmtime(_LIB)
-        for f in os.listdir(_DIR) if f.endswith("_oracle.c")
+        for f in os.listdir(_DIR) if f.endswith("_oracle.c") or f == "Makefile"
     ):
         subprocess.check_call(["make", "-C", _DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     if not os.path.exists(_REF) or force:

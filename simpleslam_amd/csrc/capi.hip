@@ -1,0 +1,491 @@
+// capi.hip -- the C ABI of libpcr_hip.so (include/pcr_hip.h): handle management,
+// host<->HBM staging and the launch sequence of each registration method.
+// Host C++ only talks to the kernels through the launchers in pcr_internal.h.
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "pcr_internal.h"
+
+using namespace pcr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Method { kLoam = 0, kNdt = 1, kVgicp = 2 };
+
+// --- RCCL, loaded lazily (multi-GPU sharded mode only) ---------------------------
+struct NcclId { char internal[128]; };
+typedef int (*nccl_get_id_fn)(NcclId*);
+typedef int (*nccl_init_rank_fn)(void**, int, NcclId, int);
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_destroy_fn)(void*);
+struct Rccl {
+    void* lib = nullptr;
+    nccl_get_id_fn get_id = nullptr;
+    nccl_init_rank_fn init_rank = nullptr;
+    nccl_allreduce_fn allreduce = nullptr;
+    nccl_destroy_fn destroy = nullptr;
+    bool load(std::string* err) {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { if (err) *err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
+        get_id = (nccl_get_id_fn)dlsym(lib, "ncclGetUniqueId");
+        init_rank = (nccl_init_rank_fn)dlsym(lib, "ncclCommInitRank");
+        allreduce = (nccl_allreduce_fn)dlsym(lib, "ncclAllReduce");
+        destroy = (nccl_destroy_fn)dlsym(lib, "ncclCommDestroy");
+        if (!get_id || !init_rank || !allreduce || !destroy) { if (err) *err = "librccl lacks ncclGetUniqueId/CommInitRank/AllReduce"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+}  // namespace
+
+struct pcr_handle {
+    Method method = kLoam;
+    pcr_params prm;
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int profile = 1;
+
+    // target
+    GridIndex grid;
+    DeviceBuf tgt_stage;         // host targets are staged here
+    const float* tgt_ptr = nullptr;   // device pointer the index was built from (for rebuild on overflow)
+    size_t tgt_n = 0, tgt_stride = 0;
+    bool have_target = false;
+    // source
+    DeviceBuf src_stage;
+
+    // LOAM work memory
+    DeviceBuf loam_state, loam_partials, loam_trace, loam_reduced, dbg_status, dbg_rows, dbg_nn;
+    LoamResult* result_host = nullptr;   // host-mapped, written by the finalize kernel
+    LoamResult* result_dev = nullptr;
+    std::vector<LoamTrace> trace_host;
+    int trace_iters = 0;
+
+    // multi-GPU
+    int use_tile = 0;
+    double tile_lo[3] = {0, 0, 0}, tile_hi[3] = {0, 0, 0};
+    void* comm = nullptr;
+    int nranks = 1;
+
+    // timing
+    hipEvent_t ev_start = nullptr, ev_index = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_kernel;
+    pcr_stats stats;
+    double fitness = -1.0;
+};
+
+namespace {
+
+#define H_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(_e); return 1; } } while (0)
+
+int fail(pcr_handle* h, const std::string& msg) { h->err = msg; return 1; }
+
+double grid_cell_for(double max_sq) {
+    // smallest power of two >= the gate radius, so that x / cell is exact in f64
+    double r = sqrt(max_sq > 0 ? max_sq : 1.0), c = 1.0;
+    while (c < r) c *= 2.0;
+    while (c * 0.5 >= r) c *= 0.5;
+    return c;
+}
+
+int ensure_loam_buffers(pcr_handle* h) {
+    H_TRY(h->loam_state.reserve(2 * sizeof(LoamState)));
+    H_TRY(h->loam_partials.reserve((size_t)2 * kMaxPartials * kAccum * sizeof(double)));
+    H_TRY(h->loam_reduced.reserve(kAccum * sizeof(double)));
+    const int iters = std::max(1, h->prm.loam_iters);
+    if (h->prm.record_trace) H_TRY(h->loam_trace.reserve((size_t)iters * sizeof(LoamTrace)));
+    if (!h->result_host) {
+        H_TRY(hipHostMalloc((void**)&h->result_host, sizeof(LoamResult), hipHostMallocMapped));
+        H_TRY(hipHostGetDevicePointer((void**)&h->result_dev, h->result_host, 0));
+    }
+    return 0;
+}
+
+void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16]) {
+    memset(a, 0, sizeof(*a));
+    a->src = d_src; a->n_src = (uint32_t)n_src; a->src_stride = (uint32_t)stride_floats;
+    a->grid = h->grid.view();
+    a->c.knn_max_sq = h->prm.loam_knn_max_sq; a->c.plane_thresh = h->prm.loam_plane_thresh;
+    a->c.point_thresh = h->prm.loam_point_thresh; a->c.pos_conv = h->prm.loam_pos_conv; a->c.rot_conv = h->prm.loam_rot_conv;
+    a->c.iters = h->prm.loam_iters; a->c.early_exit = h->prm.loam_early_exit;
+    memcpy(a->init_pose, pose, 16 * sizeof(double));
+    a->state = h->loam_state.as<LoamState>();
+    a->partials = h->loam_partials.as<double>();
+    a->reduced = nullptr;
+    a->n_partials = loam_grid_blocks((uint32_t)n_src);
+    a->trace = h->prm.record_trace ? h->loam_trace.as<LoamTrace>() : nullptr;
+    a->result = h->result_dev;
+    a->use_tile = h->use_tile;
+    for (int d = 0; d < 3; ++d) { a->tile_lo[d] = h->tile_lo[d]; a->tile_hi[d] = h->tile_hi[d]; }
+}
+
+int build_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
+    double cell = 1.0;
+    if (h->method == kLoam) cell = grid_cell_for(h->prm.loam_knn_max_sq);
+    hipError_t e = h->grid.build(d_dst, n_dst, stride_floats, cell, h->stream, &h->err);
+    if (e != hipSuccess) return 1;
+    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
+    return 0;
+}
+
+// After a synchronisation: did the device-side build overflow the cell table?  Then grow and rebuild.
+// Returns 0 ok (no overflow), 2 rebuilt (caller must rerun), 1 error.
+int check_grid_overflow(pcr_handle* h, int overflow, uint64_t need_cells) {
+    if (!overflow) return 0;
+    if (h->grid.grow_cells(need_cells, &h->err) != hipSuccess) return 1;
+    if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
+    return 2;
+}
+
+int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged,
+             bool index_timed) {
+    if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
+    if (ensure_loam_buffers(h)) return 1;
+    const int iters = std::max(0, h->prm.loam_iters);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        LoamArgs a;
+        fill_loam_args(h, &a, d_src, n_src, stride_floats, pose);
+        if (h->comm) a.reduced = h->loam_reduced.as<double>();
+        h->result_host->pad = 0;
+        if (h->profile >= 1 && !index_timed) { H_TRY(hipEventRecord(h->ev_start, h->stream)); H_TRY(hipEventRecord(h->ev_index, h->stream)); }
+        const bool per_kernel = h->profile >= 2;
+        if (per_kernel) {
+            while ((int)h->ev_kernel.size() < 2 * iters) { hipEvent_t e; H_TRY(hipEventCreate(&e)); h->ev_kernel.push_back(e); }
+        }
+        for (int k = 0; k < iters; ++k) {
+            if (per_kernel) H_TRY(hipEventRecord(h->ev_kernel[2 * k], h->stream));
+            H_TRY(loam_launch_iteration(a, k, h->stream));
+            if (per_kernel) H_TRY(hipEventRecord(h->ev_kernel[2 * k + 1], h->stream));
+            if (h->comm) {
+                H_TRY(loam_launch_reduce(a, k, h->loam_reduced.as<double>(), h->stream));
+                int rc = g_rccl.allreduce(h->loam_reduced.p, h->loam_reduced.p, kAccum, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+                if (rc != 0) return fail(h, "ncclAllReduce failed with code " + std::to_string(rc));
+            }
+        }
+        H_TRY(loam_launch_finalize(a, iters, h->stream));
+        if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_end, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        const LoamResult r = *h->result_host;
+        if (r.pad != 1) return fail(h, "LOAM finalize kernel did not complete");
+        int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells);
+        if (ov == 1) return 1;
+        if (ov == 2) { index_timed = false; continue; }
+        memcpy(pose, r.pose, 16 * sizeof(double));
+        if (converged) *converged = r.converged;
+        h->stats.iterations = r.iters_run;
+        h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
+        h->stats.kernel_ms = 0; h->stats.kernel_launches = 0;
+        if (h->profile >= 1) {
+            float ms = 0;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_end)); h->stats.total_ms = ms;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_index)); h->stats.index_ms = ms;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_index, h->ev_end)); h->stats.solve_ms = ms;
+        }
+        if (per_kernel) {
+            // only launches that linearised count (the loop may have ended early)
+            const int used = std::min(iters, r.converged || r.fail ? r.iters_run : iters);
+            for (int k = 0; k < used; ++k) {
+                float ms = 0;
+                H_TRY(hipEventElapsedTime(&ms, h->ev_kernel[2 * k], h->ev_kernel[2 * k + 1]));
+                h->stats.kernel_ms += ms; h->stats.kernel_launches++;
+            }
+        }
+        if (h->prm.record_trace && iters > 0) {
+            h->trace_host.resize(iters);
+            H_TRY(hipMemcpy(h->trace_host.data(), h->loam_trace.p, (size_t)iters * sizeof(LoamTrace), hipMemcpyDeviceToHost));
+            h->trace_iters = r.iters_run;
+        }
+        return 0;
+    }
+    return fail(h, "target index could not be sized");
+}
+
+int stage_host(pcr_handle* h, DeviceBuf* buf, const void* src, size_t n, size_t stride_bytes, const float** out) {
+    const size_t bytes = n * stride_bytes;
+    H_TRY(buf->reserve(bytes ? bytes : 16));
+    if (bytes) H_TRY(hipMemcpyAsync(buf->p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = buf->as<float>();
+    return 0;
+}
+
+int check_stride(pcr_handle* h, size_t stride_bytes) {
+    if (stride_bytes < 12 || stride_bytes % 4 != 0) return fail(h, "stride_bytes must be a multiple of 4 and >= 12");
+    return 0;
+}
+
+int set_device(pcr_handle* h) {
+    H_TRY(hipSetDevice(h->device));
+    return 0;
+}
+
+int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst, size_t stride_bytes,
+                double pose[16], int* converged, bool on_device) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!pose) return fail(h, "pose_inout is NULL");
+    if ((n_src && !src) || (n_dst && !dst)) return fail(h, "NULL cloud with nonzero size");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (h->method != kLoam) return fail(h, "method not available in this build yet");
+    const float *d_src, *d_dst;
+    if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_start, h->stream));
+    if (on_device) { d_src = (const float*)src; d_dst = (const float*)dst; }
+    else {
+        if (stage_host(h, &h->tgt_stage, dst, n_dst, stride_bytes, &d_dst)) return 1;
+        if (stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    }
+    // the reference rebuilds its index on every call (LoamRegister.cpp:110); so do we
+    if (build_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
+    if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
+    return run_loam(h, d_src, n_src, stride_bytes / 4, pose, converged, true);
+}
+
+}  // namespace
+
+extern "C" {
+
+void pcr_default_params(pcr_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(pcr_params);
+    p->device = -1;
+    p->loam_iters = 8; p->loam_early_exit = 1;
+    p->loam_knn_max_sq = (double)1.0f; p->loam_plane_thresh = (double)0.2f; p->loam_point_thresh = (double)0.1f;
+    p->loam_pos_conv = (double)5e-3f; p->loam_rot_conv = (double)5e-3f;
+    p->ndt_resolution = 1.0; p->ndt_step_size = 0.1; p->ndt_outlier_ratio = 0.55; p->ndt_trans_eps = 0.1;
+    p->ndt_max_iters = 35; p->ndt_min_points = 6;
+    p->vgicp_resolution = 1.0; p->vgicp_k_corr = 20; p->vgicp_max_iters = 64; p->vgicp_lm_inner = 10;
+    p->vgicp_rot_eps = 2e-3; p->vgicp_trans_eps = 5e-4; p->vgicp_lm_init_scale = 1e-9;
+    p->record_trace = 0;
+}
+
+pcr_handle* pcr_create(const char* method, const pcr_params* p) {
+    g_create_error.clear();
+    if (!method) { g_create_error = "method is NULL"; return nullptr; }
+    Method m;
+    if (!strcmp(method, "loam")) m = kLoam;
+    else if (!strcmp(method, "ndt")) m = kNdt;
+    else if (!strcmp(method, "vgicp")) m = kVgicp;
+    else {
+        // the reference factory throws on an unknown frontend.pcr (LidarOdometry.cpp:50-54)
+        g_create_error = std::string("such pcr type(") + method + ") is not exist";
+        return nullptr;
+    }
+    pcr_handle* h = new pcr_handle();
+    h->method = m;
+    pcr_default_params(&h->prm);
+    if (p) {
+        if (p->struct_size != sizeof(pcr_params)) { g_create_error = "pcr_params.struct_size mismatch (call pcr_default_params first)"; delete h; return nullptr; }
+        h->prm = *p;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        delete h; return nullptr;
+    }
+    if (h->prm.device >= 0) h->device = h->prm.device;
+    else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    if (h->device >= ndev) { g_create_error = "device ordinal out of range"; delete h; return nullptr; }
+    if ((e = hipSetDevice(h->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev_start)) != hipSuccess || (e = hipEventCreate(&h->ev_index)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev_end)) != hipSuccess) {
+        g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
+        delete h; return nullptr;
+    }
+    h->own_stream = true;
+    memset(&h->stats, 0, sizeof(h->stats));
+    return h;
+}
+
+void pcr_destroy(pcr_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
+    h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
+    h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
+    h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release();
+    if (h->result_host) (void)hipHostFree(h->result_host);
+    for (hipEvent_t e : h->ev_kernel) (void)hipEventDestroy(e);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_index) (void)hipEventDestroy(h->ev_index);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* pcr_last_error(const pcr_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pcr_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst, size_t stride_bytes,
+                 double pose_inout[16], int* converged) {
+    return do_scan2map(h, src, n_src, dst, n_dst, stride_bytes, pose_inout, converged, false);
+}
+
+int pcr_scan2map_device(pcr_handle* h, const void* d_src, size_t n_src, const void* d_dst, size_t n_dst,
+                        size_t stride_bytes, double pose_inout[16], int* converged) {
+    return do_scan2map(h, d_src, n_src, d_dst, n_dst, stride_bytes, pose_inout, converged, true);
+}
+
+int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_bytes, int on_device) {
+    if (!h) return 1;
+    h->err.clear();
+    if (n_dst && !dst) return fail(h, "NULL cloud with nonzero size");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    // the library copies what it keeps: the index holds its own sorted copy, but a rebuild after a
+    // cell-table overflow needs the raw points, so they are staged in HBM either way
+    const size_t bytes = n_dst * stride_bytes;
+    H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
+    if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4)) return 1;
+    // settle the cell-table size now so that pcr_align never has to rebuild
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        GridHeader hdr;
+        H_TRY(hipMemcpyAsync(&hdr, h->grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        int ov = check_grid_overflow(h, hdr.overflow, hdr.n_cells);
+        if (ov == 1) return 1;
+        if (ov == 0) return 0;
+    }
+    return fail(h, "target index could not be sized");
+}
+
+int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, double pose_inout[16],
+              int* converged) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!pose_inout) return fail(h, "pose_inout is NULL");
+    if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
+    if (h->method != kLoam) return fail(h, "method not available in this build yet");
+    const float* d_src = (const float*)src;
+    if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    return run_loam(h, d_src, n_src, stride_bytes / 4, pose_inout, converged, false);
+}
+
+int pcr_invalidate_target(pcr_handle* h) {
+    if (!h) return 1;
+    h->have_target = false; h->grid.valid = false;
+    return 0;
+}
+
+double pcr_fitness(pcr_handle* h) {
+    if (!h) return -1.0;
+    // PointCloudRegister::getFitnessScore() returns 0 unless overridden (PointCloudRegister.hpp:34);
+    // only VgicpRegister overrides it (VgicpRegister.cpp:42-45)
+    if (h->method != kVgicp) return 0.0;
+    return h->fitness;
+}
+
+int pcr_loam_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
+                       const double pose[16], double JtJ[36], double JtE[6], int64_t* n_accepted, int8_t* status,
+                       double* rows, int32_t* nn) {
+    if (!h) return 1;
+    h->err.clear();
+    if (h->method != kLoam) return fail(h, "pcr_loam_linearize needs a loam handle");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
+    if (ensure_loam_buffers(h)) return 1;
+    const float* d_src = (const float*)src;
+    if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    LoamArgs a;
+    fill_loam_args(h, &a, d_src, n_src, stride_bytes / 4, pose);
+    a.trace = nullptr;
+    if (status) { H_TRY(h->dbg_status.reserve(n_src + 16)); a.dbg_status = h->dbg_status.as<int8_t>(); }
+    if (rows) { H_TRY(h->dbg_rows.reserve(n_src * 7 * sizeof(double) + 16)); a.dbg_rows = h->dbg_rows.as<double>(); }
+    if (nn) { H_TRY(h->dbg_nn.reserve(n_src * 5 * sizeof(int32_t) + 16)); a.dbg_nn = h->dbg_nn.as<int32_t>(); }
+    H_TRY(loam_launch_iteration(a, 0, h->stream));
+    H_TRY(loam_launch_reduce(a, 0, h->loam_reduced.as<double>(), h->stream));
+    double sums[kAccum];
+    H_TRY(hipMemcpyAsync(sums, h->loam_reduced.p, sizeof(sums), hipMemcpyDeviceToHost, h->stream));
+    if (status) H_TRY(hipMemcpyAsync(status, h->dbg_status.p, n_src, hipMemcpyDeviceToHost, h->stream));
+    if (rows) H_TRY(hipMemcpyAsync(rows, h->dbg_rows.p, n_src * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (nn) H_TRY(hipMemcpyAsync(nn, h->dbg_nn.p, n_src * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    int q = 0;
+    for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { JtJ[r * 6 + c] = JtJ[c * 6 + r] = sums[q++]; }
+    for (int r = 0; r < 6; ++r) JtE[r] = sums[21 + r];
+    if (n_accepted) *n_accepted = (int64_t)sums[27];
+    return 0;
+}
+
+int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int64_t* n, double* x) {
+    if (!h) return 1;
+    if (!h->prm.record_trace) return fail(h, "trace not recorded: set pcr_params.record_trace");
+    if (n_iters) *n_iters = h->trace_iters;
+    for (int i = 0; i < h->trace_iters && i < (int)h->trace_host.size(); ++i) {
+        const LoamTrace& t = h->trace_host[i];
+        if (JtJ) memcpy(JtJ + i * 36, t.JtJ, sizeof(t.JtJ));
+        if (JtE) memcpy(JtE + i * 6, t.JtE, sizeof(t.JtE));
+        if (x) memcpy(x + i * 6, t.x, sizeof(t.x));
+        if (n) n[i] = t.n;
+    }
+    return 0;
+}
+
+int pcr_get_stats(pcr_handle* h, pcr_stats* out) {
+    if (!h || !out) return 1;
+    *out = h->stats;
+    return 0;
+}
+
+int pcr_set_profile(pcr_handle* h, int level) {
+    if (!h) return 1;
+    h->profile = level < 0 ? 0 : (level > 2 ? 2 : level);
+    return 0;
+}
+
+int pcr_set_stream(pcr_handle* h, void* hip_stream) {
+    if (!h) return 1;
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return 0;
+}
+
+int pcr_set_query_tile(pcr_handle* h, const double lo[3], const double hi[3]) {
+    if (!h) return 1;
+    if (!lo || !hi || lo[0] > hi[0]) { h->use_tile = 0; return 0; }
+    h->use_tile = 1;
+    for (int d = 0; d < 3; ++d) { h->tile_lo[d] = lo[d]; h->tile_hi[d] = hi[d]; }
+    return 0;
+}
+
+int pcr_comm_unique_id(void* out128) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!out128 || !g_rccl.load(&g_create_error)) return 1;
+    NcclId id;
+    int rc = g_rccl.get_id(&id);
+    if (rc != 0) { g_create_error = "ncclGetUniqueId failed with code " + std::to_string(rc); return 1; }
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, "bad communicator arguments");
+    if (set_device(h)) return 1;
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.load(&h->err)) return 1;
+    NcclId id;
+    memcpy(&id, unique_id128, sizeof(id));
+    int rc = g_rccl.init_rank(&h->comm, nranks, id, rank);
+    if (rc != 0) { h->comm = nullptr; return fail(h, "ncclCommInitRank failed with code " + std::to_string(rc)); }
+    h->nranks = nranks;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// grid_index.hip -- uniform-grid spatial index over the target cloud (gfx950).
+//
+// Replaces the reference's per-call kd-tree build, Kdtree::setInputCloud ->
+// nanoflann buildIndex (reference PCR/src/LoamRegister.cpp:110,
+// third_parties/nanoflann/include/nanoflann/nanoflann.hpp:1542-1564): a serial
+// O(N log N) recursive split there, five streaming passes here:
+//   bbox partials -> header + clear -> histogram -> 3-step exclusive scan -> scatter.
+// Algorithmic traffic: 16 B read + 16 B written per target point.
+// Everything is enqueued on one stream with no host synchronisation; the grid
+// geometry lives in a device-side GridHeader that the later kernels read.
+#include "pcr_internal.h"
+
+namespace pcr {
+
+static constexpr int kScanPerThread = 8;
+static constexpr int kScanBlock = 256;
+static constexpr int kScanTile = kScanPerThread * kScanBlock;  // 2048 cells per block
+
+// ---- wave64 helpers --------------------------------------------------------
+__device__ inline float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---- 1. per-block bounding boxes -------------------------------------------
+__global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
+                                                        float* __restrict__ partials) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float* p = pts + (size_t)i * stride;
+        float x = p[0], y = p[1], z = p[2];
+        if (isfinite(x) && isfinite(y) && isfinite(z)) {
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+    __shared__ float sh[4][6];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float a = wave_min(mn[d]), b = wave_max(mx[d]);
+        if (lane == 0) { sh[wave][d] = a; sh[wave][3 + d] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
+        partials[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// ---- 2. header (every block, redundantly) + clear of the cell counters -------
+__global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __restrict__ partials, int n_partials,
+                                                                GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count,
+                                                                uint64_t capacity, double cell, uint32_t n_points) {
+    __shared__ float sh[4][6];
+    __shared__ uint64_t sh_ncells;
+    __shared__ int sh_bad;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < n_partials; b += 256) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = fminf(mn[d], partials[b * 6 + d]);
+            mx[d] = fmaxf(mx[d], partials[b * 6 + 3 + d]);
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float a = wave_min(mn[d]), b = wave_max(mx[d]);
+        if (lane == 0) { sh[wave][d] = a; sh[wave][3 + d] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        GridHeader h;
+        h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n_points;
+        h.empty = 0; h.overflow = 0;
+        double nc = 1.0;
+        for (int d = 0; d < 3; ++d) {
+            float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
+            float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
+            if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
+            double clo = floor((double)lo * h.inv_cell), chi = floor((double)hi * h.inv_cell);
+            h.origin[d] = (clo - kPad) * cell;
+            double dim = chi - clo + 1.0 + 2.0 * kPad;
+            h.dims[d] = dim < 2.0e9 ? (int32_t)dim : 0x7fffffff;
+            nc *= dim;
+        }
+        // keys are uint32 and the table holds n_cells + 1 starts
+        if (nc + 1.0 > (double)capacity || nc > 4.0e9) { h.overflow = 1; h.n_cells = nc < 1.8e19 ? (uint64_t)nc : ~0ull; }
+        else h.n_cells = (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2];
+        if (blockIdx.x == 0) *hdr = h;
+        sh_ncells = h.n_cells; sh_bad = h.overflow;
+    }
+    __syncthreads();
+    if (sh_bad) return;
+    const uint64_t total = sh_ncells + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) cell_count[i] = 0;
+}
+
+__device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key) {
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) return false;
+    // exact: float -> double, origin a multiple of the power-of-two cell
+    const double fx = floor(((double)x - h.origin[0]) * h.inv_cell);
+    const double fy = floor(((double)y - h.origin[1]) * h.inv_cell);
+    const double fz = floor(((double)z - h.origin[2]) * h.inv_cell);
+    const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
+    *key = (cz * (uint32_t)h.dims[1] + cy) * (uint32_t)h.dims[0] + cx;
+    return true;
+}
+
+// ---- 3. histogram --------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
+                                                         const GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count) {
+    const GridHeader h = *hdr;
+    if (h.overflow || h.empty) return;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float* p = pts + (size_t)i * stride;
+        uint32_t key;
+        if (point_key(h, p[0], p[1], p[2], &key)) atomicAdd(&cell_count[key], 1u);
+    }
+}
+
+// ---- 4. exclusive scan of the counters (three steps) ------------------------------
+__device__ inline uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* sh /* >= 4 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) off += sh[w]; tot += sh[w]; }
+    *total = tot;
+    return off + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void grid_scan_local_kernel(const uint32_t* __restrict__ cell_count,
+                                                                    uint32_t* __restrict__ cell_start,
+                                                                    uint32_t* __restrict__ block_sums,
+                                                                    const GridHeader* __restrict__ hdr) {
+    __shared__ uint32_t sh[4];
+    if (hdr->overflow) return;
+    const uint64_t total = hdr->n_cells + 1;
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
+    if ((uint64_t)blockIdx.x * kScanTile >= total) return;
+    uint32_t v[kScanPerThread], s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) { v[j] = (base + j < total) ? cell_count[base + j] : 0u; s += v[j]; }
+    uint32_t tot;
+    uint32_t off = block_exclusive_scan_256(s, &tot, sh);
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) { if (base + j < total) cell_start[base + j] = off; off += v[j]; }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_sums_kernel(uint32_t* __restrict__ block_sums,
+                                                              const GridHeader* __restrict__ hdr) {
+    __shared__ uint32_t sh_w[16];
+    if (hdr->overflow) return;
+    const uint64_t total = hdr->n_cells + 1;
+    const uint32_t nb = (uint32_t)((total + kScanTile - 1) / kScanTile);
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nb);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += block_sums[i];
+    // block-wide exclusive scan of s over 1024 threads (16 waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) sh_w[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += sh_w[w];
+    uint32_t run = off + inc - s;
+    for (uint32_t i = lo; i < hi; ++i) { uint32_t t = block_sums[i]; block_sums[i] = run; run += t; }
+}
+
+__global__ __launch_bounds__(kScanBlock) void grid_scan_add_kernel(uint32_t* __restrict__ cell_start,
+                                                                  const uint32_t* __restrict__ block_sums,
+                                                                  const GridHeader* __restrict__ hdr) {
+    if (hdr->overflow) return;
+    const uint64_t total = hdr->n_cells + 1;
+    if ((uint64_t)blockIdx.x * kScanTile >= total) return;
+    const uint32_t add = block_sums[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) if (base + j < total) cell_start[base + j] += add;
+}
+
+// ---- 5. scatter into cell order --------------------------------------------------
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
+                                                           const GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count,
+                                                           const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted) {
+    const GridHeader h = *hdr;
+    if (h.overflow || h.empty) return;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float* p = pts + (size_t)i * stride;
+        const float x = p[0], y = p[1], z = p[2];
+        uint32_t key;
+        if (point_key(h, x, y, z, &key)) {
+            // slots of a cell are handed out from the back; the order inside a cell is
+            // immaterial (the k-NN breaks distance ties on the original index in .w)
+            const uint32_t slot = atomicSub(&cell_count[key], 1u) - 1u;
+            sorted[cell_start[key] + slot] = make_float4(x, y, z, __uint_as_float(i));
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------
+hipError_t DeviceBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; cap = 0; return e; }
+    cap = want;
+    return hipSuccess;
+}
+void DeviceBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+}
+
+void GridIndex::release() {
+    sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
+    bbox_partials.release(); header.release();
+    cell_capacity = 0; valid = false; n_points = 0;
+}
+
+hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
+    if (need_cells > 4000000000ull) {
+        if (err) *err = "target bounding box needs " + std::to_string(need_cells) + " grid cells (> 4e9): cloud too sparse for the dense index";
+        return hipErrorInvalidValue;
+    }
+    const size_t want = (size_t)need_cells + need_cells / 2 + 4096;
+    cell_count.release(); cell_start.release(); block_sums.release();
+    hipError_t e;
+    if ((e = cell_count.reserve(want * sizeof(uint32_t))) != hipSuccess || (e = cell_start.reserve(want * sizeof(uint32_t))) != hipSuccess ||
+        (e = block_sums.reserve((want / kScanTile + 2) * sizeof(uint32_t))) != hipSuccess) {
+        if (err) *err = std::string("hipMalloc of the cell table failed: ") + hipGetErrorString(e);
+        cell_capacity = 0;
+        return e;
+    }
+    cell_capacity = want;
+    return hipSuccess;
+}
+
+#define PCR_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { if (err) *err = std::string(#x) + ": " + hipGetErrorString(_e); return _e; } } while (0)
+
+hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err) {
+    valid = false;
+    if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
+    PCR_TRY(sorted.reserve((n ? n : 1) * sizeof(float4)));
+    PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
+    PCR_TRY(header.reserve(sizeof(GridHeader)));
+    if (cell_capacity == 0) {
+        // first guess; a too-small table is detected on the device (header.overflow)
+        // and the caller grows it with grow_cells() and retries
+        size_t guess = 1u << 20;
+        PCR_TRY(cell_count.reserve(guess * sizeof(uint32_t)));
+        PCR_TRY(cell_start.reserve(guess * sizeof(uint32_t)));
+        cell_capacity = guess;
+        PCR_TRY(block_sums.reserve((guess / kScanTile + 2) * sizeof(uint32_t)));
+    }
+    const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
+    const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>());
+    const int clear_blocks = (int)std::min<size_t>(2048, cell_capacity / 1024 + 1);
+    hipLaunchKernelGGL(grid_header_clear_kernel, dim3(clear_blocks), dim3(256), 0, s, bbox_partials.as<float>(), kBBoxBlocks,
+                       header.as<GridHeader>(), cell_count.as<uint32_t>(), (uint64_t)cell_capacity, cell, n32);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
+                       cell_count.as<uint32_t>());
+    const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(grid_scan_local_kernel, dim3(scan_blocks), dim3(kScanBlock), 0, s, cell_count.as<uint32_t>(),
+                       cell_start.as<uint32_t>(), block_sums.as<uint32_t>(), header.as<GridHeader>());
+    hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums.as<uint32_t>(), header.as<GridHeader>());
+    hipLaunchKernelGGL(grid_scan_add_kernel, dim3(scan_blocks), dim3(kScanBlock), 0, s, cell_start.as<uint32_t>(),
+                       block_sums.as<uint32_t>(), header.as<GridHeader>());
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
+                       cell_count.as<uint32_t>(), cell_start.as<uint32_t>(), sorted.as<float4>());
+    PCR_TRY(hipGetLastError());
+    n_points = n;
+    valid = true;
+    return hipSuccess;
+}
+
+}  // namespace pcr

@@ -1,0 +1,127 @@
+// pcr_internal.h -- shared host/device declarations of libpcr_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pcr_hip.h"
+
+namespace pcr {
+
+// ---------------------------------------------------------------------------
+// Uniform-grid spatial index over the target cloud ("voxel tiles").
+//
+// Replaces the reference's per-call nanoflann kd-tree (LoamRegister.cpp:110;
+// nanoflann.hpp:1542-1564).  Cell edge = the k-NN gate radius (1 m for the
+// reference constants), so every neighbour that can pass the gate
+// lies in the 3x3x3 block around the query's cell.  Points are counting-sorted by
+// linear cell key (x fastest), so the three x-adjacent cells of one (y,z) row
+// are ONE contiguous run of float4s: a query reads 9 runs.
+// ---------------------------------------------------------------------------
+struct GridHeader {
+    double origin[3];        // lower corner of cell (0,0,0); a multiple of `cell`
+    double cell;             // edge length (a power of two >= gate radius: x/cell is exact)
+    double inv_cell;
+    int32_t dims[3];         // cells per axis, including 2 pad cells on every side
+    uint32_t n_points;       // points kept (finite coordinates)
+    uint64_t n_cells;        // dims[0]*dims[1]*dims[2]
+    int32_t overflow;        // n_cells + 1 exceeds the allocated cell table
+    int32_t empty;           // no finite point
+};
+
+struct GridView {            // what kernels need to query the index
+    const GridHeader* hdr;
+    const float4* pts;       // sorted by cell; .w = original index (uint bits)
+    const uint32_t* cell_start;  // n_cells + 1 entries
+};
+
+static constexpr int kPad = 2;           // pad cells per side (see grid_index.hip)
+static constexpr int kBBoxBlocks = 256;  // partial bounding boxes
+
+// ---------------------------------------------------------------------------
+// LOAM Gauss-Newton state carried between launches (device memory).
+// ---------------------------------------------------------------------------
+struct LoamState {
+    double pose[16];     // column-major map<-lidar
+    int32_t done;        // 1: loop finished (converged, too few points, or error)
+    int32_t converged;   // isConverge (PointCloudRegister.hpp:15)
+    int32_t iters_run;   // linearisations whose result was consumed
+    int32_t fail;        // 1: fewer than 6 accepted points (LoamRegister.cpp:173-176)
+};
+
+static constexpr int kAccum = 32;        // 21 JtJ (upper) + 6 JtE + 1 count, padded
+static constexpr int kMaxPartials = 512; // linearisation blocks
+
+struct LoamConsts {
+    double knn_max_sq, plane_thresh, point_thresh, pos_conv, rot_conv;
+    int32_t iters, early_exit;
+};
+
+struct LoamResult {          // written by the finalize launch into host-mapped memory
+    double pose[16];         // after T2SE3
+    int32_t converged, iters_run, fail, grid_overflow, grid_empty, pad;
+    uint64_t grid_cells;     // cells the target needs (to grow the table on overflow)
+};
+
+struct LoamTrace {           // per consumed linearisation
+    double JtJ[36];
+    double JtE[6];
+    double x[6];
+    int64_t n;
+};
+
+struct LoamArgs {
+    const float* src;        // scan points, stride in floats
+    uint32_t n_src;
+    uint32_t src_stride;
+    GridView grid;
+    LoamConsts c;
+    double init_pose[16];    // initial guess, consumed by launch 0
+    LoamState* state;        // [2], ping-pong by launch parity
+    double* partials;        // [2][kMaxPartials][kAccum]
+    const double* reduced;   // non-null: partial sums already reduced (and all-reduced) into kAccum doubles
+    uint32_t n_partials;     // blocks of the linearisation grid
+    LoamTrace* trace;        // [iters] or null
+    LoamResult* result;      // final pose (after T2SE3) and flags
+    // optional per-point outputs (tests): null in production
+    int8_t* dbg_status;
+    double* dbg_rows;
+    int32_t* dbg_nn;
+    // optional query tile (multi-GPU): process only queries inside [lo,hi)
+    int32_t use_tile;
+    double tile_lo[3], tile_hi[3];
+};
+
+// host-side launchers (grid_index.hip / loam.hip)
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct GridIndex {
+    DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header;
+    size_t cell_capacity = 0;   // entries available in cell_count / cell_start
+    size_t n_points = 0;
+    bool valid = false;
+    GridView view() const {
+        return GridView{header.as<GridHeader>(), sorted.as<float4>(), cell_start.as<uint32_t>()};
+    }
+    // Enqueue the build of the index over n points (device pointer, stride in floats).
+    // No host synchronisation unless the cell table must grow.  cell = grid edge.
+    hipError_t build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s,
+                     std::string* err);
+    // Make room for `need_cells` cells (+1 start) after the device reported overflow.
+    hipError_t grow_cells(uint64_t need_cells, std::string* err);
+    void release();
+};
+
+hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s);
+hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s);
+hipError_t loam_launch_reduce(const LoamArgs& a, int k, double* d_out, hipStream_t s);
+uint32_t loam_grid_blocks(uint32_t n_src);
+
+}  // namespace pcr

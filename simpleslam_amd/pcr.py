@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's registration plugin over the C ABI.
+
+Reference interface (compiled C++): PCR::PointCloudRegister with
+``bool scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res)`` and
+``scalar_t getFitnessScore()`` (reference PCR/include/PCR/PointCloudRegister.hpp:12-38),
+implemented by LoamRegister / NdtRegister / VgicpRegister and selected by the config
+key ``frontend.pcr`` (reference frontend/src/LidarOdometry.cpp:44-54).  The classes
+below keep those names and meanings; every call goes through libpcr_hip.so
+(include/pcr_hip.h) -- there is no CPU fallback: if the HIP library or a GPU is
+missing, construction raises.
+
+Clouds are float32 arrays of shape (n, 4) [x y z intensity] or (n, 8)
+(pcl::PointXYZI layout), either numpy (host) or torch tensors resident in HBM.
+Poses are 4x4 float64 numpy arrays (map <- lidar).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
+
+
+class PcrParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32),
+        ("loam_iters", C.c_int32), ("loam_early_exit", C.c_int32),
+        ("loam_knn_max_sq", C.c_double), ("loam_plane_thresh", C.c_double), ("loam_point_thresh", C.c_double),
+        ("loam_pos_conv", C.c_double), ("loam_rot_conv", C.c_double),
+        ("ndt_resolution", C.c_double), ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double),
+        ("ndt_trans_eps", C.c_double), ("ndt_max_iters", C.c_int32), ("ndt_min_points", C.c_int32),
+        ("vgicp_resolution", C.c_double), ("vgicp_k_corr", C.c_int32), ("vgicp_max_iters", C.c_int32),
+        ("vgicp_lm_inner", C.c_int32), ("vgicp_rot_eps", C.c_double), ("vgicp_trans_eps", C.c_double),
+        ("vgicp_lm_init_scale", C.c_double),
+        ("record_trace", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class PcrStats(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_double), ("index_ms", C.c_double), ("solve_ms", C.c_double), ("kernel_ms", C.c_double),
+        ("kernel_launches", C.c_int32), ("iterations", C.c_int32), ("n_src", C.c_int64), ("n_dst", C.c_int64),
+    ]
+
+
+# every symbol include/pcr_hip.h declares
+ABI_SYMBOLS = [
+    "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
+    "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace",
+    "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpcr_hip.so and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C simpleslam_amd/csrc`). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.pcr_default_params.argtypes = [C.POINTER(PcrParams)]
+    L.pcr_default_params.restype = None
+    L.pcr_create.argtypes = [C.c_char_p, C.POINTER(PcrParams)]
+    L.pcr_create.restype = vp
+    L.pcr_destroy.argtypes = [vp]
+    L.pcr_destroy.restype = None
+    L.pcr_last_error.argtypes = [vp]
+    L.pcr_last_error.restype = C.c_char_p
+    L.pcr_scan2map.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, dp, ip]
+    L.pcr_scan2map_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, dp, ip]
+    L.pcr_set_target.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.pcr_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, ip]
+    L.pcr_invalidate_target.argtypes = [vp]
+    L.pcr_fitness.argtypes = [vp]
+    L.pcr_fitness.restype = C.c_double
+    L.pcr_loam_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, C.POINTER(C.c_int64), vp, vp, vp]
+    L.pcr_get_trace.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, vp, vp]
+    L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
+    L.pcr_set_profile.argtypes = [vp, C.c_int]
+    L.pcr_set_stream.argtypes = [vp, vp]
+    L.pcr_set_query_tile.argtypes = [vp, dp, dp]
+    L.pcr_comm_unique_id.argtypes = [vp]
+    L.pcr_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def default_params(**overrides):
+    p = PcrParams()
+    load_library().pcr_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"pcr_params has no field {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+class PcrError(RuntimeError):
+    pass
+
+
+def _cloud(x):
+    """-> (pointer, n, stride_bytes, on_device, keepalive)"""
+    if hasattr(x, "data_ptr"):  # torch tensor
+        import torch
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] < 3 or not x.is_contiguous():
+            raise ValueError("cloud tensors must be contiguous float32 of shape (n, >=3)")
+        return C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1] * 4, 1 if x.is_cuda else 0, x
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("clouds must have shape (n, >=3)")
+    return a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1] * 4, 0, a
+
+
+def _pose_in(T):
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape != (4, 4):
+        raise ValueError("pose must be 4x4")
+    return np.ascontiguousarray(T.T).reshape(16).copy()  # column-major
+
+
+def _pose_out(buf):
+    return buf.reshape(4, 4).T.copy()
+
+
+class PointCloudRegister:
+    """PCR::PointCloudRegister (reference PointCloudRegister.hpp:12-38)."""
+
+    method = None
+
+    def __init__(self, params=None, **overrides):
+        self._lib = load_library()
+        if params is None:
+            params = default_params(**overrides)
+        elif overrides:
+            for k, v in overrides.items():
+                setattr(params, k, v)
+        self.params = params
+        self._h = self._lib.pcr_create(self.method.encode(), C.byref(params))
+        if not self._h:
+            raise PcrError(self._lib.pcr_last_error(None).decode())
+        self.isConverge = False
+
+    # -- reference interface ------------------------------------------------
+    def scan2Map(self, src, dst, res):
+        """Refine `res` (4x4, map<-lidar) in place; returns isConverge.
+        The target index is rebuilt on every call, like the reference (LoamRegister.cpp:110)."""
+        sp, sn, ss, sdev, _k1 = _cloud(src)
+        dp_, dn, ds, ddev, _k2 = _cloud(dst)
+        if ss != ds:
+            raise ValueError("src and dst must share a point stride")
+        if sdev != ddev:
+            raise ValueError("src and dst must both be host arrays or both be device tensors")
+        pose = _pose_in(res)
+        conv = C.c_int(0)
+        fn = self._lib.pcr_scan2map_device if sdev else self._lib.pcr_scan2map
+        self._check(fn(self._h, sp, sn, dp_, dn, ss, pose.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
+        np.asarray(res)[...] = _pose_out(pose)
+        self.isConverge = bool(conv.value)
+        return self.isConverge
+
+    def getFitnessScore(self):
+        return float(self._lib.pcr_fitness(self._h))
+
+    # -- static-map localisation (reference test/loc.cpp) ----------------------
+    def setTarget(self, dst):
+        p, n, s, dev, _k = _cloud(dst)
+        self._check(self._lib.pcr_set_target(self._h, p, n, s, dev))
+
+    def align(self, src, res):
+        p, n, s, dev, _k = _cloud(src)
+        pose = _pose_in(res)
+        conv = C.c_int(0)
+        self._check(self._lib.pcr_align(self._h, p, n, s, dev, pose.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
+        np.asarray(res)[...] = _pose_out(pose)
+        self.isConverge = bool(conv.value)
+        return self.isConverge
+
+    def invalidateTarget(self):
+        self._check(self._lib.pcr_invalidate_target(self._h))
+
+    # -- introspection ---------------------------------------------------------
+    def stats(self):
+        st = PcrStats()
+        self._check(self._lib.pcr_get_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in PcrStats._fields_}
+
+    def set_profile(self, level):
+        self._check(self._lib.pcr_set_profile(self._h, int(level)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.pcr_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_query_tile(self, lo, hi):
+        lo = np.ascontiguousarray(lo, np.float64)
+        hi = np.ascontiguousarray(hi, np.float64)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.pcr_set_query_tile(self._h, lo.ctypes.data_as(dp), hi.ctypes.data_as(dp)))
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.pcr_comm_init(self._h, C.cast(buf, C.c_void_p), rank, nranks))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PcrError(self._lib.pcr_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pcr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LoamRegister(PointCloudRegister):
+    """PCR::LoamRegister (reference PCR/src/LoamRegister.cpp)."""
+    method = "loam"
+
+    def linearize(self, src, pose, per_point=False):
+        """One linearisation against the current target (setTarget): dict(JtJ, JtE, n[, status, rows, nn])."""
+        p, n, s, dev, _k = _cloud(src)
+        pc = _pose_in(pose)
+        JtJ = np.zeros(36)
+        JtE = np.zeros(6)
+        cnt = C.c_int64(0)
+        status = np.zeros(n, np.int8) if per_point else None
+        rows = np.zeros((n, 7)) if per_point else None
+        nn = np.zeros((n, 5), np.int32) if per_point else None
+        dp = C.POINTER(C.c_double)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self._check(self._lib.pcr_loam_linearize(self._h, p, n, s, dev, pc.ctypes.data_as(dp), JtJ.ctypes.data_as(dp),
+                                                 JtE.ctypes.data_as(dp), C.byref(cnt), vp(status), vp(rows), vp(nn)))
+        out = dict(JtJ=JtJ.reshape(6, 6), JtE=JtE, n=int(cnt.value))
+        if per_point:
+            out.update(status=status, rows=rows, nn=nn)
+        return out
+
+    def trace(self):
+        """Per-iteration normal equations of the last call (needs record_trace=1)."""
+        it = max(1, self.params.loam_iters)
+        JtJ, JtE, n, x = np.zeros((it, 36)), np.zeros((it, 6)), np.zeros(it, np.int64), np.zeros((it, 6))
+        k = C.c_int32(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.pcr_get_trace(self._h, C.byref(k), vp(JtJ), vp(JtE), vp(n), vp(x)))
+        k = k.value
+        return dict(iters_run=k, JtJ=JtJ[:k].reshape(-1, 6, 6), JtE=JtE[:k], n=n[:k], x=x[:k])
+
+
+class NdtRegister(PointCloudRegister):
+    """PCR::NdtRegister (reference PCR/src/NdtRegister.cpp)."""
+    method = "ndt"
+
+
+class VgicpRegister(PointCloudRegister):
+    """PCR::VgicpRegister (reference PCR/src/VgicpRegister.cpp)."""
+    method = "vgicp"
+
+
+def make_register(pcr_type, **overrides):
+    """The reference's factory on cfg["frontend"]["pcr"] (LidarOdometry.cpp:32,44-54)."""
+    table = {"loam": LoamRegister, "ndt": NdtRegister, "vgicp": VgicpRegister}
+    if pcr_type not in table:
+        raise RuntimeError(f"such pcr type({pcr_type}) is not exist, please implemented your self!")
+    return table[pcr_type](**overrides)
+
+
+def comm_unique_id():
+    buf = (C.c_char * 128)()
+    if load_library().pcr_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+        raise PcrError(load_library().pcr_last_error(None).decode())
+    return bytes(buf)

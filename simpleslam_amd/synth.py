@@ -29,6 +29,18 @@ class World:
     boxes: np.ndarray    # (B,4) x0 y0 x1 y1 of the buildings (z in [0,HEIGHT])
 
 
+def map_origin(blocks):
+    """World coordinates of the map frame's origin: a street point SENSOR_Z + 0.2 m above the
+    ground, like a SLAM map whose origin is the first key-frame's lidar pose (the reference's
+    tf.lidar_height is 2.0, config/params.json:20).  LOAM writes planes as x.p + 1 = 0
+    (LoamRegister.cpp:29-35), which cannot represent a plane through the origin, so the
+    synthetic surfaces must stay away from it as real ones do."""
+    mid = (blocks // 2) * PITCH
+    if blocks == 1:
+        return np.array([6.0, 4.0, SENSOR_Z + 0.2])
+    return np.array([mid + 7.0, mid - 4.0, SENSOR_Z + 0.2])
+
+
 def _world(blocks):
     c = np.arange(blocks) * PITCH + (PITCH - BUILDING) / 2
     x0, y0 = np.meshgrid(c, c, indexing="ij")
@@ -96,7 +108,7 @@ def make_map(n_points, seed=0, noise=0.01):
     sel = rng.permutation(pts.shape[0])[:n_points]
     sel.sort()
     out = np.empty((n_points, 4), np.float32)
-    out[:, :3] = pts[sel]
+    out[:, :3] = pts[sel] - map_origin(blocks)
     out[:, 3] = rng.uniform(0, 255, n_points)
     return World(blocks, side, s, boxes), out
 
@@ -155,7 +167,7 @@ def scan_pose(world, k=0, seed=0):
     Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
     T = np.eye(4)
     T[:3, :3] = Rz @ Ry @ Rx
-    T[:3, 3] = [x, y, SENSOR_Z]
+    T[:3, 3] = np.array([x, y, SENSOR_Z]) - map_origin(world.blocks)
     return T
 
 
@@ -177,7 +189,7 @@ def make_scan(world, k=0, seed=0, beams=64, azimuths=1024, noise=0.02):
     for _ in range(64):
         ds = np.stack([np.cos(el_g[pending]) * np.cos(az_g[pending]), np.cos(el_g[pending]) * np.sin(az_g[pending]),
                        np.sin(el_g[pending])], 1)
-        t = _raycast(world, T[:3, 3], ds @ T[:3, :3].T)
+        t = _raycast(world, T[:3, 3] + map_origin(world.blocks), ds @ T[:3, :3].T)
         hit = np.isfinite(t)
         rng_out[pending[hit]] = t[hit]
         dirs[pending[hit]] = ds[hit]
