@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/s of the LOAM scan-to-map hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): pcr=loam, 65 536-point scan vs 1 M-point sub-map,
+10 Gauss-Newton iterations with early exit off, target index rebuilt on every call (as the
+reference does, PCR/src/LoamRegister.cpp:110), inputs resident in HBM.  One "step" = one
+scan2Map call through the C ABI (pcr_scan2map_device).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank holds a full map
+replica and registers its own scans (scans are independent objects: no data-path
+collective) -> weak scaling, value = all ranks' scans / max-over-ranks time.
+`--shard-map` instead shards the map tiles across ranks with an RCCL all-reduce of the
+normal equations per iteration (BASELINE.json configs[3]); it is not the default line.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_SCAN = 65_536
+SEED = 20261003
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--map-points", type=int, default=1_000_000)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
+    ap.add_argument("--shard-map", action="store_true", help="shard map tiles across ranks + RCCL all-reduce (config 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from simpleslam_amd import LoamRegister, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
+    # ---- synthetic workload (same map on every rank; scans differ per rank) ----
+    world, map_np = synth.make_map(args.map_points, seed=SEED + 2)
+    scans, inits, truths = [], [], []
+    for j in range(args.scans):
+        k = rank * args.scans + j
+        s, T = synth.make_scan(world, k, seed=SEED + 2)
+        assert s.shape[0] == N_SCAN
+        scans.append(s)
+        truths.append(T)
+        inits.append(synth.perturb(T, SEED + 2 + k))
+
+    reg = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0)
+    d_map_full = torch.from_numpy(map_np).to(dev)
+    d_scans = [torch.from_numpy(s).to(dev) for s in scans]
+    d_map = d_map_full
+    scaling = "weak"
+    parallelism = f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"
+    if args.shard_map and world_size > 1:
+        from simpleslam_amd import shard
+        tile = shard.tile_for_rank(map_np, rank, world_size)
+        d_map = torch.from_numpy(tile.points).to(dev)
+        reg.set_query_tile(tile.lo, tile.hi)
+        uid = [shard.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        reg.comm_init(uid[0], rank, world_size)
+        d_scans = [torch.from_numpy(s).to(dev) for s in (synth.make_scan(world, j, seed=SEED + 2)[0] for j in range(args.scans))]
+        inits = [synth.perturb(synth.scan_pose(world, j, SEED + 2), SEED + 2 + j) for j in range(args.scans)]
+        scaling = "strong"
+        parallelism = f"map tiles x{world_size} + RCCL all-reduce of JtJ/JtE"
+
+    def step(i):
+        pose = inits[i % args.scans].copy()
+        reg.scan2Map(d_scans[i % args.scans], d_map, pose)
+        return pose
+
+    reg.set_profile(0)
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    units = args.steps * (1 if args.shard_map else world_size)
+    value = units / elapsed
+
+    out = {
+        "metric": "scans/s (65 k-pt scan vs 1 M-pt submap, LOAM 10 iters) + pose RMSE vs CPU ref",
+        "value": value, "unit": "scans/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"pcr=loam, {N_SCAN}-pt 64-beam scan vs {args.map_points}-pt submap, {args.iters} GN iters, "
+                               "early exit off, index rebuilt per call, inputs in HBM",
+                   "parallelism": parallelism, "scans_cycled": args.scans},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (loam_iterate_kernel), live, HIP events on its stream ----
+        reg.set_profile(2)
+        k_ms, k_n, idx_ms, tot_ms = 0.0, 0, 0.0, 0.0
+        reps = 16
+        for i in range(reps):
+            step(i)
+            st = reg.stats()
+            k_ms += st["kernel_ms"]; k_n += st["kernel_launches"]; idx_ms += st["index_ms"]; tot_ms += st["total_ms"]
+        reg.set_profile(0)
+        avg_s = (k_ms / max(1, k_n)) * 1e-3
+        alg_bytes = 96 * N_SCAN + 216          # per linearisation launch
+        achieved = alg_bytes / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "loam_iterate_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "kernel": "loam_iterate_kernel", "avg_launch_us": avg_s * 1e6,
+                           "algorithmic_bytes_per_launch": alg_bytes,
+                           "index_build_us": 1e3 * idx_ms / reps,
+                           "index_build_GBs": 32 * args.map_points / (idx_ms / reps * 1e-3) / 1e9 if idx_ms > 0 else None,
+                           "device_ms_per_scan": tot_ms / reps}
+
+        # ---- pose parity + CPU baseline: the oracle (a port) on this host's cores ----
+        if not args.no_cpu_baseline and not args.shard_map:
+            import oracle
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            prm = oracle.loam_params(iters=args.iters, early_exit=0, threads=cores)
+            n_done, t_cpu, et, er = 0, 0.0, [], []
+            while n_done < args.scans and (n_done < 1 or t_cpu < args.cpu_budget_s):
+                c0 = time.perf_counter()
+                ref, _, _ = oracle.loam_scan2map(scans[n_done], map_np, inits[n_done], prm)
+                t_cpu += time.perf_counter() - c0
+                dt, dr = synth.pose_error(step(n_done), ref)
+                et.append(dt); er.append(dr)
+                n_done += 1
+            out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n_done} of the same scans (kd-tree rebuilt per call + {args.iters} iterations), "
+                                             f"{t_cpu:.1f} s wall, OpenMP threads = {cores}"}
+            out["pose_rmse_vs_cpu"] = {"trans_m": float(np.sqrt(np.mean(np.square(et)))), "rot_rad": float(np.sqrt(np.mean(np.square(er)))),
+                                       "max_trans_m": float(max(et)), "max_rot_rad": float(max(er)), "scans": n_done,
+                                       "tolerance": "1e-4 m / 1e-4 rad"}
+        print(json.dumps(out), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -266,7 +266,7 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err) {
     valid = false;
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
-    PCR_TRY(sorted.reserve((n ? n : 1) * sizeof(float4)));
+    PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
     PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
     PCR_TRY(header.reserve(sizeof(GridHeader)));
     if (cell_capacity == 0) {

@@ -71,6 +71,8 @@ struct LoamTrace {           // per consumed linearisation
     int64_t n;
 };
 
+struct NnCacheEntry;
+
 struct LoamArgs {
     const float* src;        // scan points, stride in floats
     uint32_t n_src;
@@ -89,8 +91,14 @@ struct LoamArgs {
     double* dbg_rows;
     int32_t* dbg_nn;
     // optional query tile (multi-GPU): process only queries inside [lo,hi)
+    struct NnCacheEntry* nn_cache;   // [n_src] neighbours of the previous iteration (loam.hip), or null
+    float4* q_cache;         // [n_src] query positions of the previous iteration
+    int32_t src_indexed;     // src is the cell-sorted float4 copy: .w = original scan index
     int32_t use_tile;
     double tile_lo[3], tile_hi[3];
+    // profiling aid (pcr_params.reserved[0]): skip phases to price them.  bit0: candidate loop,
+    // bit1: plane fit and everything after it, bit2: prologue solve.  Results are then meaningless.
+    int32_t ablate;
 };
 
 // host-side launchers (grid_index.hip / loam.hip)
@@ -116,6 +124,17 @@ struct GridIndex {
                      std::string* err);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
+    void release();
+};
+
+struct Pose16 { double m[16]; };
+
+// Stable sort of the scan by target-grid cell of the initially transformed point (query_sort.hip).
+struct QuerySorter {
+    DeviceBuf keys[2], vals[2], counts, sorted;
+    hipError_t sort(const float* d_src, size_t n, size_t stride_floats, const Pose16& pose, const GridIndex& grid,
+                    hipStream_t s, std::string* err);
+    const float* sorted_points() const { return sorted.as<float>(); }
     void release();
 };
 
