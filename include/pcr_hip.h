@@ -128,6 +128,15 @@ int pcr_loam_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stri
  * for it < *n_iters: JtJ[it*36..], JtE[it*6..], n[it], x[it*6..]. Arrays sized for loam_iters. */
 int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int64_t* n, double* x);
 
+/* VGICP introspection.  Per-point covariances as fast_gicp::FastGICP::calculate_covariances forms
+ * them (fast_gicp_impl.hpp:241-297; 20-NN, PLANE regularisation): cov_out[n*6] = xx xy xz yy yz zz. */
+int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double* cov_out);
+/* One FastVGICP::linearize (fast_vgicp_impl.hpp:119-180) at `pose` against the current target
+ * (pcr_set_target): H (36, row-major, twist = [rotation; translation]), b (6), sum of errors,
+ * number of source points with a voxel correspondence. */
+int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
+                        const double pose[16], double H[36], double b[6], double* error, int64_t* n_corr);
+
 int pcr_get_stats(pcr_handle* h, pcr_stats* out);
 /* 0: no timing events; 1: phase events (default); 2: also an event pair around every
  * launch of the dominant kernel (adds host work; for roofline measurement only). */

@@ -235,3 +235,112 @@ def ref_knn(pts, queries_f32, k=5):
     R.ref_kd_knn_batch(h, _p(q), q.shape[0], q.shape[1], k, _p(idx), _p(d2))
     R.ref_kd_free(h)
     return idx, d2
+
+
+# ---------------------------------------------------------------------------
+# VGICP restatement (oracle/vgicp_oracle.c)
+# ---------------------------------------------------------------------------
+class VgicpParams(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("k_corr", C.c_int), ("max_iters", C.c_int), ("lm_inner", C.c_int),
+                ("rot_eps", C.c_double), ("trans_eps", C.c_double), ("lm_init", C.c_double), ("threads", C.c_int)]
+
+
+def _vg():
+    L = lib()
+    if not getattr(L, "_vg_ready", False):
+        L.oracle_vgicp_default_params.argtypes = [C.POINTER(VgicpParams)]
+        L.oracle_sym3_eig.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_vgicp_covariances.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_vgicp_scan2map.restype = C.c_int
+        L.oracle_vgicp_scan2map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                            C.POINTER(VgicpParams), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_vgicp_linearize.restype = C.c_long
+        L.oracle_vgicp_linearize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                             C.POINTER(VgicpParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_vgicp_voxel_at.restype = C.c_int
+        L.oracle_vgicp_voxel_at.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_fitness_score.restype = C.c_double
+        L.oracle_fitness_score.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double]
+        L.oracle_kd_knn_f32.restype = C.c_int
+        L.oracle_kd_knn_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L._vg_ready = True
+    return L
+
+
+def vgicp_params(**kw):
+    p = VgicpParams()
+    _vg().oracle_vgicp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def sym3_eig(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(3, 3)
+    w, V = np.zeros(3), np.zeros(9)
+    _vg().oracle_sym3_eig(_p(A), _p(w), _p(V))
+    return w, V.reshape(3, 3)
+
+
+def vgicp_covariances(pts, k=20, threads=1):
+    pts = _f32(pts)
+    covs = np.zeros((pts.shape[0], 3, 3))
+    _vg().oracle_vgicp_covariances(_p(pts), pts.shape[0], pts.shape[1], k, _p(covs), threads)
+    return covs
+
+
+def knn_f32(pts, queries_f32, k):
+    """Exact k-NN with float squared distances (PCL/FLANN semantics), ties on the lower index."""
+    pts = _f32(pts)
+    q = np.ascontiguousarray(queries_f32, np.float32).reshape(-1, 3)
+    L = _vg()
+    h = L.oracle_kd_build(_p(pts), pts.shape[0], pts.shape[1])
+    idx = np.full((q.shape[0], k), -1, np.int32)
+    d2 = np.full((q.shape[0], k), np.inf, np.float32)
+    for i in range(q.shape[0]):
+        L.oracle_kd_knn_f32(h, _p(q[i]), k, _p(idx[i]), _p(d2[i]))
+    L.oracle_kd_free(h)
+    return idx, d2
+
+
+def vgicp_scan2map(src, dst, pose, params=None, src_covs=None, dst_covs=None):
+    src, dst = _f32(src), _f32(dst)
+    assert src.shape[1] == dst.shape[1]
+    params = params or vgicp_params()
+    pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16).copy()
+    info = np.zeros(4, np.int64)
+    sc = np.ascontiguousarray(src_covs, np.float64) if src_covs is not None else None
+    dc = np.ascontiguousarray(dst_covs, np.float64) if dst_covs is not None else None
+    conv = _vg().oracle_vgicp_scan2map(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc), C.byref(params),
+                                       _p(sc), _p(dc), _p(info))
+    return pc.reshape(4, 4).T.copy(), bool(conv), dict(outer=int(info[0]), linearizations=int(info[1]),
+                                                       error_evals=int(info[2]), correspondences=int(info[3]))
+
+
+def vgicp_linearize(src, dst, pose, src_covs, dst_covs, params=None):
+    src, dst = _f32(src), _f32(dst)
+    params = params or vgicp_params()
+    pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16).copy()
+    sc = np.ascontiguousarray(src_covs, np.float64)
+    dc = np.ascontiguousarray(dst_covs, np.float64)
+    H, b, err = np.zeros(36), np.zeros(6), C.c_double(0)
+    nc = _vg().oracle_vgicp_linearize(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc), C.byref(params),
+                                      _p(sc), _p(dc), _p(H), _p(b), C.byref(err))
+    return dict(H=H.reshape(6, 6), b=b, err=err.value, n=int(nc))
+
+
+def vgicp_voxel_at(dst, dst_covs, res, p):
+    dst = _f32(dst)
+    dc = np.ascontiguousarray(dst_covs, np.float64)
+    pp = np.ascontiguousarray(p, np.float64)
+    mean, cov = np.zeros(3), np.zeros(9)
+    n = _vg().oracle_vgicp_voxel_at(_p(dst), dst.shape[0], dst.shape[1], _p(dc), float(res), _p(pp), _p(mean), _p(cov))
+    return n, mean, cov.reshape(3, 3)
+
+
+def fitness_score(src, dst, pose, max_range=1.7976931348623157e308):
+    src, dst = _f32(src), _f32(dst)
+    pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16).copy()
+    return float(_vg().oracle_fitness_score(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc), float(max_range)))

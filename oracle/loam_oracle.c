@@ -211,6 +211,45 @@ int oracle_kd_knn(const kd_tree *t, const double q[3], int k, int32_t *idx_out, 
     return s.count;
 }
 
+/* ---- float-distance variant: pcl::search::KdTree / FLANN L2_Simple<float> semantics
+ * (squared distance accumulated x, y, z in FLOAT), used by the VGICP covariances
+ * (fast_gicp_impl.hpp:253) and the PCL fitness score. ---- */
+static inline double sqdist_f32(const float q[3], const kd_tree *t, int32_t i)
+{
+    float r = 0.0f;
+    for (int d = 0; d < 3; ++d) {
+        float diff = q[d] - t->pts[(size_t)i * t->stride + d];
+        r += diff * diff;
+    }
+    return (double)r;
+}
+
+static void kd_search_rec_f32(const kd_tree *t, int32_t id, const float q[3], knn_set *s)
+{
+    const kd_node *nd = &t->nodes[id];
+    if (nd->left < 0) {
+        for (int32_t i = nd->lo; i < nd->hi; ++i) knn_add(s, sqdist_f32(q, t, t->perm[i]), t->perm[i]);
+        return;
+    }
+    double v = (double)q[nd->dim];
+    double gl = v - nd->split_lo; gl = gl > 0 ? gl : 0;
+    double gr = nd->split_hi - v; gr = gr > 0 ? gr : 0;
+    int32_t first = (gl <= gr) ? nd->left : nd->right;
+    int32_t second = (gl <= gr) ? nd->right : nd->left;
+    double gsecond = (gl <= gr) ? gr : gl;
+    kd_search_rec_f32(t, first, q, s);
+    /* float rounding of the distances: prune with a relative margin */
+    if (s->count < s->k || gsecond * gsecond * (1.0 - 1e-5) <= s->d[s->k - 1]) kd_search_rec_f32(t, second, q, s);
+}
+
+int oracle_kd_knn_f32(const kd_tree *t, const float q[3], int k, int32_t *idx_out, float *d_out)
+{
+    knn_set s; s.k = k > 32 ? 32 : k; s.count = 0;
+    if (t->n > 0) kd_search_rec_f32(t, 0, q, &s);
+    for (int i = 0; i < s.count; ++i) { idx_out[i] = s.idx[i]; d_out[i] = (float)s.d[i]; }
+    return s.count;
+}
+
 /* brute-force exact k-NN (independent of the tree; for small fixtures) */
 int oracle_knn_brute(const float *pts, size_t n, size_t stride_floats, const double q[3], int k,
                      int32_t *idx_out, double *d_out)

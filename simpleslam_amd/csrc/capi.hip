@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "pcr_internal.h"
+#include "small_math.h"
 
 using namespace pcr;
 
@@ -73,6 +74,14 @@ struct pcr_handle {
     LoamResult* result_dev = nullptr;
     std::vector<LoamTrace> trace_host;
     int trace_iters = 0;
+
+    // VGICP work memory
+    GridIndex src_grid;
+    DeviceBuf tgt_cov6, src_cov6, vox_slot, vox, vox_count, corr_slot, corr_M, vg_partials;
+    double* out32_host = nullptr;        // host-mapped: 32 doubles written by sum_partials_kernel
+    double* out32_dev = nullptr;
+    bool vg_target_ready = false;
+    int vg_outer = 0, vg_lin = 0, vg_err = 0;
 
     // multi-GPU
     int use_tile = 0;
@@ -249,6 +258,159 @@ int set_device(pcr_handle* h) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// VGICP host driver: PCL align() + LsqRegistration (lsq_registration_impl.hpp:53-171)
+// ---------------------------------------------------------------------------------
+int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (g.build(d_pts, n, stride_floats, cell, h->stream, &h->err) != hipSuccess) return 1;
+        GridHeader hdr;
+        H_TRY(hipMemcpyAsync(&hdr, g.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        if (!hdr.overflow) return 0;
+        if (g.grow_cells(hdr.n_cells, &h->err) != hipSuccess) return 1;
+    }
+    return fail(h, "index could not be sized");
+}
+
+int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
+    h->vg_target_ready = false;
+    const double res = h->prm.vgicp_resolution;
+    if (!(res > 0)) return fail(h, "vgicp_resolution must be positive");
+    if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
+    if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res)) return 1;
+    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
+    H_TRY(h->tgt_cov6.reserve((n_dst + 1) * 6 * sizeof(double)));
+    const uint64_t slot_cap = 2 * (uint64_t)h->grid.cell_capacity + 64;
+    H_TRY(h->vox_slot.reserve(slot_cap * sizeof(uint32_t)));
+    H_TRY(h->vox.reserve((n_dst + 1) * sizeof(VgicpVoxel)));
+    H_TRY(h->vox_count.reserve(16));
+    H_TRY(vgicp_launch_cov(h->grid, d_dst, stride_floats, n_dst, h->tgt_cov6.as<double>(), h->stream));
+    H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox_slot.as<uint32_t>(), slot_cap, h->vox.as<VgicpVoxel>(),
+                              h->vox_count.as<uint32_t>(), h->stream));
+    h->vg_target_ready = true;
+    return 0;
+}
+
+void host_make_delta(const double d[6], double D[16]) {
+    // so3_exp (so3.hpp:58-77) -> Quaterniond::toRotationMatrix; translation d[3:6]
+    const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double imag, real;
+    if (th2 < 1e-10) {
+        const double q4 = th2 * th2;
+        imag = 0.5 - 1.0 / 48.0 * th2 + 1.0 / 3840.0 * q4;
+        real = 1.0 - 1.0 / 8.0 * th2 + 1.0 / 384.0 * q4;
+    } else {
+        const double th = sqrt(th2), hf = 0.5 * th;
+        imag = sin(hf) / th; real = cos(hf);
+    }
+    const double w = real, x = imag * d[0], y = imag * d[1], z = imag * d[2];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
+                 tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    for (int i = 0; i < 16; ++i) D[i] = 0;
+    D[0] = 1 - (tyy + tzz); D[4] = txy - twz; D[8] = txz + twy;
+    D[1] = txy + twz; D[5] = 1 - (txx + tzz); D[9] = tyz - twx;
+    D[2] = txz - twy; D[6] = tyz + twx; D[10] = 1 - (txx + tyy);
+    D[12] = d[3]; D[13] = d[4]; D[14] = d[5]; D[15] = 1;
+}
+
+void host_mul44(const double A[16], const double B[16], double C[16]) {
+    double o[16];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) { double s = 0; for (int k = 0; k < 4; ++k) s += A[k * 4 + r] * B[c * 4 + k]; o[c * 4 + r] = s; }
+    o[3] = o[7] = o[11] = 0; o[15] = 1;
+    memcpy(C, o, sizeof o);
+}
+
+bool host_is_converged(const double D[16], double rot_eps, double trans_eps) {
+    double rmax = 0, tmax = 0;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) rmax = std::max(rmax, fabs(D[c * 4 + r] - (r == c ? 1.0 : 0.0)) * (1.0 / rot_eps));
+    for (int r = 0; r < 3; ++r) tmax = std::max(tmax, fabs(D[12 + r]) * (1.0 / trans_eps));
+    return std::max(rmax, tmax) < 1;
+}
+
+int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged) {
+    if (!h->vg_target_ready) return fail(h, "no target prepared");
+    if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
+    if (!h->out32_host) {
+        H_TRY(hipHostMalloc((void**)&h->out32_host, 32 * sizeof(double), hipHostMallocMapped));
+        H_TRY(hipHostGetDevicePointer((void**)&h->out32_dev, h->out32_host, 0));
+    }
+    // source covariances over the source's own index (fast_gicp_impl.hpp:103-108)
+    if (settle_grid(h, h->src_grid, d_src, n_src, stride_floats, h->prm.vgicp_resolution)) return 1;
+    H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
+    H_TRY(vgicp_launch_cov(h->src_grid, d_src, stride_floats, n_src, h->src_cov6.as<double>(), h->stream));
+    H_TRY(h->corr_slot.reserve((n_src + 1) * sizeof(uint32_t)));
+    H_TRY(h->corr_M.reserve((n_src + 1) * 6 * sizeof(double)));
+    H_TRY(h->vg_partials.reserve((size_t)512 * 32 * sizeof(double)));
+    VgicpArgs a;
+    a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)stride_floats;
+    a.src_cov6 = h->src_cov6.as<double>();
+    a.hdr = h->grid.header.as<GridHeader>();
+    a.vox_slot = h->vox_slot.as<uint32_t>(); a.slot_capacity = 2 * (uint64_t)h->grid.cell_capacity + 64;
+    a.vox = h->vox.as<VgicpVoxel>();
+    a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
+    a.partials = h->vg_partials.as<double>();
+
+    Pose16 x0;
+    for (int i = 0; i < 16; ++i) x0.m[i] = (double)(float)pose[i];     // guess handed over as Matrix4f (VgicpRegister.cpp:36)
+    double lambda = -1.0;
+    bool conv = false;
+    h->vg_outer = h->vg_lin = h->vg_err = 0;
+    for (int it = 0; it < h->prm.vgicp_max_iters && !conv; ++it) {
+        h->vg_outer = it + 1;
+        H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        ++h->vg_lin;
+        double H[36], b[6], D[16];
+        int q = 0;
+        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[r * 6 + c] = H[c * 6 + r] = h->out32_host[q++]; }
+        for (int r = 0; r < 6; ++r) b[r] = h->out32_host[21 + r];
+        const double y0 = h->out32_host[27];
+        if (lambda < 0.0) { double mx = 0; for (int i = 0; i < 6; ++i) mx = std::max(mx, fabs(H[i * 7])); lambda = h->prm.vgicp_lm_init_scale * mx; }
+        double nu = 2.0;
+        bool ok = false;
+        for (int i = 0; i < h->prm.vgicp_lm_inner; ++i) {
+            double A[36], rhs[6], d[6];
+            memcpy(A, H, sizeof A);
+            for (int k = 0; k < 6; ++k) { A[k * 7] += lambda; rhs[k] = -b[k]; }
+            ldlt6_solve(A, rhs, d);
+            host_make_delta(d, D);
+            Pose16 xi;
+            host_mul44(D, x0.m, xi.m);
+            H_TRY(vgicp_launch_error(a, xi, h->out32_dev, h->stream));
+            H_TRY(hipStreamSynchronize(h->stream));
+            ++h->vg_err;
+            const double yi = h->out32_host[0];
+            double den = 0;
+            for (int k = 0; k < 6; ++k) den += d[k] * (lambda * d[k] - b[k]);
+            const double rho = (y0 - yi) / den;
+            if (rho < 0) {
+                if (host_is_converged(D, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps)) { ok = true; break; }
+                lambda = nu * lambda; nu = 2 * nu;
+                continue;
+            }
+            x0 = xi;
+            const double f = 1 - pow(2 * rho - 1, 3);
+            lambda = lambda * std::max(1.0 / 3.0, f);
+            ok = true;
+            break;
+        }
+        if (!ok) break;                                  // "lm not converged!!"
+        conv = host_is_converged(D, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps);
+    }
+    for (int i = 0; i < 16; ++i) pose[i] = (double)(float)x0.m[i];     // final_transformation_ is a Matrix4f
+    if (converged) *converged = conv ? 1 : 0;
+    // pcl::Registration::getFitnessScore() of the aligned source (VgicpRegister.cpp:42-45)
+    H_TRY(fitness_launch(h->grid, d_src, n_src, stride_floats, pose, 1.7976931348623157e308, h->vg_partials.as<double>(), h->out32_dev, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    h->fitness = h->out32_host[1] > 0 ? h->out32_host[0] / h->out32_host[1] : 1.7976931348623157e308;
+    h->stats.iterations = h->vg_outer; h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
+    h->stats.kernel_launches = h->vg_lin + h->vg_err;
+    return 0;
+}
+
 int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst, size_t stride_bytes,
                 double pose[16], int* converged, bool on_device) {
     if (!h) return 1;
@@ -256,13 +418,29 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     if (!pose) return fail(h, "pose_inout is NULL");
     if ((n_src && !src) || (n_dst && !dst)) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
-    if (h->method != kLoam) return fail(h, "method not available in this build yet");
+    if (h->method == kNdt) return fail(h, "method not available in this build yet");
     const float *d_src, *d_dst;
     if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_start, h->stream));
     if (on_device) { d_src = (const float*)src; d_dst = (const float*)dst; }
     else {
         if (stage_host(h, &h->tgt_stage, dst, n_dst, stride_bytes, &d_dst)) return 1;
         if (stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    }
+    if (h->method == kVgicp) {
+        // the reference keeps its target structures while the cloud POINTER is unchanged and goes stale
+        // when the cloud is edited in place; this entry point always rebuilds them
+        if (vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
+        if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
+        if (run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
+        if (h->profile >= 1) {
+            H_TRY(hipEventRecord(h->ev_end, h->stream));
+            H_TRY(hipEventSynchronize(h->ev_end));
+            float ms = 0;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_end)); h->stats.total_ms = ms;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_index)); h->stats.index_ms = ms;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_index, h->ev_end)); h->stats.solve_ms = ms;
+        }
+        return 0;
     }
     // the reference rebuilds its index on every call (LoamRegister.cpp:110); so do we
     if (build_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
@@ -334,6 +512,9 @@ void pcr_destroy(pcr_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release(); h->sorter.release();
+    h->src_grid.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox_slot.release(); h->vox.release();
+    h->vox_count.release(); h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
+    if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
     h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->q_cache.release();
     if (h->result_host) (void)hipHostFree(h->result_host);
@@ -367,6 +548,8 @@ int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_b
     const size_t bytes = n_dst * stride_bytes;
     H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
     if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (h->method == kVgicp) return vgicp_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
+    if (h->method == kNdt) return fail(h, "method not available in this build yet");
     if (build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4)) return 1;
     // settle the cell-table size now so that pcr_align never has to rebuild
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -388,15 +571,16 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
-    if (h->method != kLoam) return fail(h, "method not available in this build yet");
+    if (h->method == kNdt) return fail(h, "method not available in this build yet");
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    if (h->method == kVgicp) return run_vgicp(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);
     return run_loam(h, d_src, n_src, stride_bytes / 4, pose_inout, converged, false);
 }
 
 int pcr_invalidate_target(pcr_handle* h) {
     if (!h) return 1;
-    h->have_target = false; h->grid.valid = false;
+    h->have_target = false; h->grid.valid = false; h->vg_target_ready = false;
     return 0;
 }
 
@@ -443,6 +627,62 @@ int pcr_loam_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stri
     for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { JtJ[r * 6 + c] = JtJ[c * 6 + r] = sums[q++]; }
     for (int r = 0; r < 6; ++r) JtE[r] = sums[21 + r];
     if (n_accepted) *n_accepted = (int64_t)sums[27];
+    return 0;
+}
+
+int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double* cov_out) {
+    if (!h) return 1;
+    h->err.clear();
+    if (h->method != kVgicp) return fail(h, "pcr_vgicp_covariances needs a vgicp handle");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    const float* d_pts = (const float*)pts;
+    if (!on_device && stage_host(h, &h->src_stage, pts, n, stride_bytes, &d_pts)) return 1;
+    if (settle_grid(h, h->src_grid, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution)) return 1;
+    H_TRY(h->src_cov6.reserve((n + 1) * 6 * sizeof(double)));
+    H_TRY(hipMemsetAsync(h->src_cov6.p, 0, (n + 1) * 6 * sizeof(double), h->stream));
+    H_TRY(vgicp_launch_cov(h->src_grid, d_pts, stride_bytes / 4, n, h->src_cov6.as<double>(), h->stream));
+    H_TRY(hipMemcpyAsync(cov_out, h->src_cov6.p, n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, const double pose[16],
+                        double H[36], double b[6], double* error, int64_t* n_corr) {
+    if (!h) return 1;
+    h->err.clear();
+    if (h->method != kVgicp) return fail(h, "pcr_vgicp_linearize needs a vgicp handle");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (!h->vg_target_ready) return fail(h, "no target: call pcr_set_target first");
+    const float* d_src = (const float*)src;
+    if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    // run the driver's set-up with zero iterations, then one linearisation at the given pose
+    const int saved = h->prm.vgicp_max_iters;
+    h->prm.vgicp_max_iters = 0;
+    double tmp[16];
+    memcpy(tmp, pose, sizeof tmp);
+    int conv = 0;
+    const int rc = run_vgicp(h, d_src, n_src, stride_bytes / 4, tmp, &conv);
+    h->prm.vgicp_max_iters = saved;
+    if (rc) return 1;
+    VgicpArgs a;
+    a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)(stride_bytes / 4);
+    a.src_cov6 = h->src_cov6.as<double>();
+    a.hdr = h->grid.header.as<GridHeader>();
+    a.vox_slot = h->vox_slot.as<uint32_t>(); a.slot_capacity = 2 * (uint64_t)h->grid.cell_capacity + 64;
+    a.vox = h->vox.as<VgicpVoxel>();
+    a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
+    a.partials = h->vg_partials.as<double>();
+    Pose16 T;
+    memcpy(T.m, pose, sizeof T.m);
+    H_TRY(vgicp_launch_linearize(a, T, h->out32_dev, h->stream));
+    std::vector<uint32_t> slots(n_src);
+    if (n_src) H_TRY(hipMemcpyAsync(slots.data(), h->corr_slot.p, n_src * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    int q = 0;
+    for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[r * 6 + c] = H[c * 6 + r] = h->out32_host[q++]; }
+    for (int r = 0; r < 6; ++r) b[r] = h->out32_host[21 + r];
+    if (error) *error = h->out32_host[27];
+    if (n_corr) { int64_t c = 0; for (uint32_t v : slots) c += v != 0; *n_corr = c; }
     return 0;
 }
 

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __r
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
             float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
             if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
-            double clo = floor((double)lo * h.inv_cell), chi = floor((double)hi * h.inv_cell);
+            double clo = floor((double)lo / cell), chi = floor((double)hi / cell);
+            h.org[d] = clo - kPad;
             h.origin[d] = (clo - kPad) * cell;
             double dim = chi - clo + 1.0 + 2.0 * kPad;
             h.dims[d] = dim < 2.0e9 ? (int32_t)dim : 0x7fffffff;
@@ -107,10 +108,12 @@ __global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __r
 
 __device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key) {
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) return false;
-    // exact: float -> double, origin a multiple of the power-of-two cell
-    const double fx = floor(((double)x - h.origin[0]) * h.inv_cell);
-    const double fy = floor(((double)y - h.origin[1]) * h.inv_cell);
-    const double fz = floor(((double)z - h.origin[2]) * h.inv_cell);
+    // cell index = floor(x / cell) - org.  For a power-of-two cell (LOAM) x / cell is exact and this
+    // equals floor((x - origin) / cell); for any other edge (VGICP/NDT resolutions) it is the single
+    // definition every kernel uses, so a point and its queries always agree on the cell.
+    const double fx = floor((double)x / h.cell) - h.org[0];
+    const double fy = floor((double)y / h.cell) - h.org[1];
+    const double fz = floor((double)z / h.cell) - h.org[2];
     const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
     *key = (cz * (uint32_t)h.dims[1] + cy) * (uint32_t)h.dims[0] + cx;
     return true;

@@ -20,7 +20,8 @@ namespace pcr {
 // are ONE contiguous run of float4s: a query reads 9 runs.
 // ---------------------------------------------------------------------------
 struct GridHeader {
-    double origin[3];        // lower corner of cell (0,0,0); a multiple of `cell`
+    double origin[3];        // lower corner of cell (0,0,0) = org * cell
+    double org[3];           // integer-valued: cell (i,j,k) spans [(org+i)*cell, (org+i+1)*cell)
     double cell;             // edge length (a power of two >= gate radius: x/cell is exact)
     double inv_cell;
     int32_t dims[3];         // cells per axis, including 2 pad cells on every side
@@ -38,6 +39,8 @@ struct GridView {            // what kernels need to query the index
 
 static constexpr int kPad = 2;           // pad cells per side (see grid_index.hip)
 static constexpr int kBBoxBlocks = 256;  // partial bounding boxes
+
+struct Pose16 { double m[16]; };
 
 // ---------------------------------------------------------------------------
 // LOAM Gauss-Newton state carried between launches (device memory).
@@ -127,8 +130,6 @@ struct GridIndex {
     void release();
 };
 
-struct Pose16 { double m[16]; };
-
 // Stable sort of the scan by target-grid cell of the initially transformed point (query_sort.hip).
 struct QuerySorter {
     DeviceBuf keys[2], vals[2], counts, sorted;
@@ -137,6 +138,36 @@ struct QuerySorter {
     const float* sorted_points() const { return sorted.as<float>(); }
     void release();
 };
+
+// ---------------------------------------------------------------------------
+// VGICP (vgicp.hip)
+// ---------------------------------------------------------------------------
+struct VgicpVoxel {          // fast_vgicp_voxel.hpp:59-82 (GaussianVoxel, ADDITIVE, finalized)
+    double mean[3];
+    double cov[6];           // xx xy xz yy yz zz
+    double w;                // sqrt(num_points)
+    uint32_t n, pad;
+};
+
+struct VgicpArgs {
+    const float* src; uint32_t n_src, src_stride;
+    const double* src_cov6;      // per source point, original order
+    const GridHeader* hdr;       // target index header (voxel lattice = index grid shifted by half a cell)
+    const uint32_t* vox_slot; uint64_t slot_capacity;
+    const VgicpVoxel* vox;
+    uint32_t* corr_slot;         // [n_src] voxel slot + 1 of the correspondence, 0 = none
+    double* corr_M;              // [n_src][6] Mahalanobis matrix of the correspondence
+    double* partials;            // [blocks][32]
+};
+
+hipError_t vgicp_launch_cov(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, double* d_cov6, hipStream_t s);
+hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, uint32_t* d_slot, uint64_t slot_capacity, VgicpVoxel* d_vox,
+                               uint32_t* d_count, hipStream_t s);
+hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s);
+hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s);
+hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
+                          double* d_partials, double* d_out32, hipStream_t s);
+uint32_t vgicp_blocks(uint32_t n_src);
 
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s);
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s);

@@ -1,0 +1,497 @@
+// vgicp.hip -- voxelised GICP scan-to-map on gfx950 (hand-written HIP).
+//
+// Kernels for the reference's PCR::VgicpRegister::scan2Map (PCR/src/VgicpRegister.cpp:30-45),
+// i.e. fast_gicp::FastVGICP under PCL's align():
+//   V2 per-point covariances      fast_gicp_impl.hpp:241-297  (serial there: 20-NN over a FLANN
+//      kd-tree, 4x20 f64 neighbours, cov/20, JacobiSVD, PLANE regularisation U diag(1,1,1e-3) V^T)
+//      -> vgicp_cov_kernel: exact ring search on the uniform grid, float distances like FLANN
+//   V3 Gaussian voxel map         pclomp/fast_vgicp_voxel.hpp:105-174 (serial unordered_map, ADDITIVE)
+//      -> vgicp_voxel_kernel: one thread per voxel, fixed-point sums (order independent)
+//   V4/V5 correspondences, Mahalanobis, linearize, compute_error   fast_vgicp_impl.hpp:73-204
+//      -> vgicp_linearize_kernel / vgicp_error_kernel, fixed-order reductions
+//   V6 LM driver                  lsq_registration_impl.hpp:53-171 -> host code in capi.hip
+// Also the PCL fitness score (pcl::Registration::getFitnessScore, VgicpRegister.cpp:42-45).
+#include "pcr_internal.h"
+#include "small_math.h"
+
+namespace pcr {
+
+// ------------------------------------------------------------------------------
+// exact K nearest neighbours by ring search; float squared distances (x,y,z order, no FMA:
+// FLANN L2_Simple<float>), ties on the lower original index.  key = dist_bits << 32 | index.
+// ------------------------------------------------------------------------------
+template <int K>
+struct KeyList {
+    unsigned long long k[K];
+};
+
+template <int K>
+__device__ __forceinline__ void keylist_insert(KeyList<K>& L, unsigned long long key) {
+    bool c[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) c[i] = key < L.k[i];
+#pragma unroll
+    for (int i = K - 1; i >= 1; --i) L.k[i] = c[i - 1] ? L.k[i - 1] : (c[i] ? key : L.k[i]);
+    L.k[0] = c[0] ? key : L.k[0];
+}
+
+template <int K>
+__device__ __forceinline__ void ring_scan_run(const float4* __restrict__ pts, uint32_t s, uint32_t e, float qx, float qy, float qz,
+                                              KeyList<K>& L) {
+    for (uint32_t j = s; j < e; ++j) {
+        const float4 p = pts[j];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        float d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(p.w);
+        if (key < L.k[K - 1]) keylist_insert<K>(L, key);
+    }
+}
+
+// Searches outward ring by ring until the K-th distance is provably final.  max_sq: neighbours
+// farther than this are not needed (FLT_MAX for none).
+template <int K>
+__device__ __forceinline__ void ring_knn(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                         float qx, float qy, float qz, float max_sq, KeyList<K>& L) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) L.k[i] = ~0ull;
+    if (h.empty || h.overflow) return;
+    const int d0 = h.dims[0], d1 = h.dims[1], d2 = h.dims[2];
+    double fx = floor((double)qx / h.cell) - h.org[0], fy = floor((double)qy / h.cell) - h.org[1], fz = floor((double)qz / h.cell) - h.org[2];
+    // centre cell, clamped into the grid (queries of the fitness score may lie outside)
+    const int cx = (int)fmin(fmax(fx, 0.0), (double)(d0 - 1)), cy = (int)fmin(fmax(fy, 0.0), (double)(d1 - 1)),
+              cz = (int)fmin(fmax(fz, 0.0), (double)(d2 - 1));
+    const int rmax = max(max(max(cx, d0 - 1 - cx), max(cy, d1 - 1 - cy)), max(cz, d2 - 1 - cz));
+    for (int r = 1; r <= max(rmax, 1); ++r) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, d2 - 1), y0 = max(cy - r, 0), y1 = min(cy + r, d1 - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, d0 - 1);
+        for (int z = z0; z <= z1; ++z) {
+            for (int y = y0; y <= y1; ++y) {
+                const uint32_t row = ((uint32_t)z * (uint32_t)d1 + (uint32_t)y) * (uint32_t)d0;
+                const bool shell_row = r == 1 || z == cz - r || z == cz + r || y == cy - r || y == cy + r;
+                if (shell_row) {
+                    ring_scan_run<K>(pts, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, L);
+                } else {
+                    if (cx - r >= 0) ring_scan_run<K>(pts, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, L);
+                    if (cx + r <= d0 - 1) ring_scan_run<K>(pts, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, L);
+                }
+            }
+        }
+        // every point not yet visited lies beyond a face of the block [c-r, c+r]; faces on the
+        // grid boundary have nothing behind them
+        double bound = 1e300;
+        if (cx - r > 0) bound = fmin(bound, (double)qx - (h.org[0] + (double)(cx - r)) * h.cell);
+        if (cx + r < d0 - 1) bound = fmin(bound, (h.org[0] + (double)(cx + r + 1)) * h.cell - (double)qx);
+        if (cy - r > 0) bound = fmin(bound, (double)qy - (h.org[1] + (double)(cy - r)) * h.cell);
+        if (cy + r < d1 - 1) bound = fmin(bound, (h.org[1] + (double)(cy + r + 1)) * h.cell - (double)qy);
+        if (cz - r > 0) bound = fmin(bound, (double)qz - (h.org[2] + (double)(cz - r)) * h.cell);
+        if (cz + r < d2 - 1) bound = fmin(bound, (h.org[2] + (double)(cz + r + 1)) * h.cell - (double)qz);
+        if (bound >= 1e299) break;   // the block covers the whole grid
+        const double b2 = bound > 0 ? bound * bound * (1.0 - 1e-5) : 0.0;   // margin: float distances
+        if (b2 > (double)max_sq) break;
+        if (L.k[K - 1] != ~0ull && (double)__uint_as_float((uint32_t)(L.k[K - 1] >> 32)) < b2) break;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi; eigenvalues descending, V columns
+// ------------------------------------------------------------------------------
+__device__ inline void sym3_eig(const double A[6] /* xx xy xz yy yz zz */, double w[3], double V[3][3]) {
+    double a[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] != 0.0) {
+                    const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+                }
+            }
+        }
+    }
+    // sort descending with static indexing
+    double e0 = a[0][0], e1 = a[1][1], e2 = a[2][2];
+    double c0[3] = {v[0][0], v[1][0], v[2][0]}, c1[3] = {v[0][1], v[1][1], v[2][1]}, c2[3] = {v[0][2], v[1][2], v[2][2]};
+#define SWAPCOL(ea, ca, eb, cb) if (eb > ea) { double t_ = ea; ea = eb; eb = t_; for (int k_ = 0; k_ < 3; ++k_) { double u_ = ca[k_]; ca[k_] = cb[k_]; cb[k_] = u_; } }
+    // same selection order as the oracle: position 0 vs 1, 0 vs 2, then 1 vs 2
+    SWAPCOL(e0, c0, e1, c1) SWAPCOL(e0, c0, e2, c2) SWAPCOL(e1, c1, e2, c2)
+#undef SWAPCOL
+    w[0] = e0; w[1] = e1; w[2] = e2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { V[k][0] = c0[k]; V[k][1] = c1[k]; V[k][2] = c2[k]; }
+}
+
+// ------------------------------------------------------------------------------
+// V2: covariance of every point of an indexed cloud (thread per cell-sorted point)
+// cov6 is indexed by the ORIGINAL point index: xx xy xz yy yz zz
+// ------------------------------------------------------------------------------
+static constexpr int kCovK = 20;
+
+__global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, const float* __restrict__ orig, uint32_t stride, uint32_t n_sorted_max,
+                                                        double* __restrict__ cov6) {
+    const GridHeader h = *g.hdr;
+    if (h.empty || h.overflow) return;
+    const uint32_t n = g.cell_start[h.n_cells];   // points actually indexed (finite ones)
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n && j < n_sorted_max; j += gridDim.x * 256) {
+        const float4 q = g.pts[j];
+        KeyList<kCovK> L;
+        ring_knn<kCovK>(h, g.pts, g.cell_start, q.x, q.y, q.z, 3.0e38f, L);
+        // fast_gicp_impl.hpp:255-262: neighbours as f64, minus their mean, N N^T / k
+        double mx = 0, my = 0, mz = 0;
+        int found = 0;
+#pragma unroll
+        for (int i = 0; i < kCovK; ++i) {
+            if (L.k[i] != ~0ull) {
+                const float* p = orig + (size_t)(uint32_t)L.k[i] * stride;
+                mx += (double)p[0]; my += (double)p[1]; mz += (double)p[2];
+                ++found;
+            }
+        }
+        mx /= (double)kCovK; my /= (double)kCovK; mz /= (double)kCovK;
+        double C[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < kCovK; ++i) {
+            if (L.k[i] != ~0ull) {
+                const float* p = orig + (size_t)(uint32_t)L.k[i] * stride;
+                const double c0 = (double)p[0] - mx, c1 = (double)p[1] - my, c2 = (double)p[2] - mz;
+                C[0] += c0 * c0; C[1] += c0 * c1; C[2] += c0 * c2; C[3] += c1 * c1; C[4] += c1 * c2; C[5] += c2 * c2;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) C[e] /= (double)kCovK;
+        double w[3], V[3][3];
+        sym3_eig(C, w, V);
+        // PLANE: singular values replaced by (1, 1, 1e-3)   fast_gicp_impl.hpp:279-281,292
+        const double val[3] = {1.0, 1.0, 1e-3};
+        double out[6];
+        int o = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = r; c < 3; ++c) {
+                double s = 0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) s += V[r][e] * val[e] * V[c][e];
+                out[o++] = s;
+            }
+        }
+        double* dst = cov6 + (size_t)__float_as_uint(q.w) * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) dst[e] = out[e];
+        (void)found;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// V3: Gaussian voxel map.  Reference voxel coordinate c = floor(x/res - 0.5)
+// (fast_vgicp_voxel.hpp:158-160): the voxel lattice is the index grid shifted by half a cell,
+// so voxel v (local index c - org + 1, in [0, dims]) overlaps the 8 grid cells {v-1, v}^3.
+// One thread per voxel scans those cells and keeps the points whose coordinate is c.
+// Sums are fixed point (2^44 per unit), hence independent of the order of the points.
+// ------------------------------------------------------------------------------
+static constexpr double kFix = 17592186044416.0;   // 2^44
+
+__global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const float* __restrict__ orig_unused, const double* __restrict__ cov6,
+                                                          uint32_t* __restrict__ vox_slot, uint64_t slot_capacity,
+                                                          VgicpVoxel* __restrict__ vox, uint32_t* __restrict__ vox_count) {
+    const GridHeader h = *g.hdr;
+    if (h.overflow) return;
+    const uint64_t v0 = (uint64_t)h.dims[0] + 1, v1 = (uint64_t)h.dims[1] + 1, v2 = (uint64_t)h.dims[2] + 1;
+    const uint64_t total = v0 * v1 * v2;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total && t < slot_capacity; t += (uint64_t)gridDim.x * 256) {
+        const int vx = (int)(t % v0), vy = (int)((t / v0) % v1), vz = (int)(t / (v0 * v1));
+        // reference coordinate of this voxel and its lower corner
+        const double cxr = h.org[0] + vx - 1, cyr = h.org[1] + vy - 1, czr = h.org[2] + vz - 1;
+        const double ox = (cxr + 0.5) * h.cell, oy = (cyr + 0.5) * h.cell, oz = (czr + 0.5) * h.cell;
+        long long sm[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t cnt = 0;
+        if (!h.empty) {
+            for (int dz = -1; dz <= 0; ++dz) {
+                const int z = vz + dz;
+                if (z < 0 || z >= h.dims[2]) continue;
+                for (int dy = -1; dy <= 0; ++dy) {
+                    const int y = vy + dy;
+                    if (y < 0 || y >= h.dims[1]) continue;
+                    const int xa = max(vx - 1, 0), xb = min(vx, h.dims[0] - 1);
+                    if (xa > xb) continue;
+                    const uint32_t row = ((uint32_t)z * (uint32_t)h.dims[1] + (uint32_t)y) * (uint32_t)h.dims[0];
+                    const uint32_t s = g.cell_start[row + xa], e = g.cell_start[row + xb + 1];
+                    for (uint32_t j = s; j < e; ++j) {
+                        const float4 p = g.pts[j];
+                        const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
+                        if (floor(px / h.cell - 0.5) == cxr && floor(py / h.cell - 0.5) == cyr && floor(pz / h.cell - 0.5) == czr) {
+                            ++cnt;
+                            sm[0] += llrint((px - ox) * kFix); sm[1] += llrint((py - oy) * kFix); sm[2] += llrint((pz - oz) * kFix);
+                            const double* c = cov6 + (size_t)__float_as_uint(p.w) * 6;
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) sc[k] += llrint(c[k] * kFix);
+                        }
+                    }
+                }
+            }
+        }
+        uint32_t slot = 0;
+        if (cnt) {
+            slot = atomicAdd(vox_count, 1u) + 1;   // placement only; the stored values do not depend on it
+            VgicpVoxel v;
+            const double inv = 1.0 / (double)cnt;
+            v.mean[0] = ox + (double)sm[0] / kFix * inv; v.mean[1] = oy + (double)sm[1] / kFix * inv; v.mean[2] = oz + (double)sm[2] / kFix * inv;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v.cov[k] = (double)sc[k] / kFix * inv;
+            v.w = sqrt((double)cnt);   // fast_vgicp_impl.hpp:149
+            v.n = cnt;
+            vox[slot - 1] = v;
+        }
+        vox_slot[t] = slot;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// V4/V5: one linearisation (update_correspondences + linearize)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3_sym(const double S[6], double M[6]) {
+    const double a = S[0], b = S[1], c = S[2], d = S[3], e = S[4], f = S[5];
+    const double A = d * f - e * e, B = c * e - b * f, Cc = b * e - c * d;
+    const double det = a * A + b * B + c * Cc;
+    const double id = 1.0 / det;
+    M[0] = A * id; M[1] = B * id; M[2] = Cc * id;
+    M[3] = (a * f - c * c) * id; M[4] = (b * c - a * e) * id; M[5] = (a * d - b * b) * id;
+}
+
+__device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint32_t* __restrict__ vox_slot, uint64_t slot_capacity,
+                                                 const double tp[3]) {
+    if (h.overflow || h.empty) return 0;
+    const double vx = floor(tp[0] / h.cell - 0.5) - h.org[0] + 1.0, vy = floor(tp[1] / h.cell - 0.5) - h.org[1] + 1.0,
+                 vz = floor(tp[2] / h.cell - 0.5) - h.org[2] + 1.0;
+    if (!(vx >= 0.0 && vx <= (double)h.dims[0] && vy >= 0.0 && vy <= (double)h.dims[1] && vz >= 0.0 && vz <= (double)h.dims[2])) return 0;
+    const uint64_t t = ((uint64_t)vz * ((uint64_t)h.dims[1] + 1) + (uint64_t)vy) * ((uint64_t)h.dims[0] + 1) + (uint64_t)vx;
+    return t < slot_capacity ? vox_slot[t] : 0;
+}
+
+static constexpr int kLinStride = 258;
+
+__global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a, const Pose16 T) {
+    __shared__ double sh[28 * kLinStride];
+    __shared__ double sh_sum[8 * 32];
+    const GridHeader h = *a.hdr;
+    const int tid = threadIdx.x, e = tid & 31, ch = tid >> 5;
+    double acc = 0.0;
+    for (uint32_t base = blockIdx.x * 256; base < a.n_src; base += gridDim.x * 256) {
+        const uint32_t i = base + tid;
+        double v[28];
+#pragma unroll
+        for (int k = 0; k < 28; ++k) v[k] = 0.0;
+        if (i < a.n_src) {
+            const float* sp = a.src + (size_t)i * a.src_stride;
+            const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
+            double tp[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
+            const uint32_t slot = vgicp_lookup(h, a.vox_slot, a.slot_capacity, tp);
+            a.corr_slot[i] = slot;
+            if (slot) {
+                const VgicpVoxel vx = a.vox[slot - 1];
+                const double* ca = a.src_cov6 + (size_t)i * 6;
+                const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
+                double RC[3][3], S[6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) RC[r][c] = T.m[r] * CA[0][c] + T.m[4 + r] * CA[1][c] + T.m[8 + r] * CA[2][c];
+                int o = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = r; c < 3; ++c) { S[o] = vx.cov[o] + (RC[r][0] * T.m[c] + RC[r][1] * T.m[4 + c] + RC[r][2] * T.m[8 + c]); ++o; }
+                double M6[6];
+                inv3_sym(S, M6);   // (C_B + T C_A T^T)^-1, fast_vgicp_impl.hpp:104-115
+#pragma unroll
+                for (int k = 0; k < 6; ++k) a.corr_M[(size_t)i * 6 + k] = M6[k];
+                const double M[3][3] = {{M6[0], M6[1], M6[2]}, {M6[1], M6[3], M6[4]}, {M6[2], M6[4], M6[5]}};
+                const double er[3] = {vx.mean[0] - tp[0], vx.mean[1] - tp[1], vx.mean[2] - tp[2]};
+                double Me[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Me[r] = M[r][0] * er[0] + M[r][1] * er[1] + M[r][2] * er[2];
+                const double w = vx.w;
+                // J = [skew(Tp) | -I]   fast_vgicp_impl.hpp:156-158, so3.hpp:21-31
+                const double J[3][6] = {{0, -tp[2], tp[1], -1, 0, 0}, {tp[2], 0, -tp[0], 0, -1, 0}, {-tp[1], tp[0], 0, 0, 0, -1}};
+                double MJ[3][6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) MJ[r][c] = M[r][0] * J[0][c] + M[r][1] * J[1][c] + M[r][2] * J[2][c];
+                int q = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) v[q++] = w * (J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c]);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) v[21 + r] = w * (J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2]);
+                v[27] = w * (er[0] * Me[0] + er[1] * Me[1] + er[2] * Me[2]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 28; ++k) sh[k * kLinStride + tid] = v[k];
+        __syncthreads();
+        if (e < 28) {
+            const double* row = sh + e * kLinStride + ch * 32;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) acc += row[k];
+        }
+        __syncthreads();
+    }
+    sh_sum[ch * 32 + e] = e < 28 ? acc : 0.0;
+    __syncthreads();
+    if (tid < 32) {
+        double s = sh_sum[tid];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) s += sh_sum[c * 32 + tid];
+        a.partials[(size_t)blockIdx.x * 32 + tid] = s;
+    }
+}
+
+// compute_error (fast_vgicp_impl.hpp:183-204): same correspondences and Mahalanobis matrices, new pose
+__global__ __launch_bounds__(256) void vgicp_error_kernel(const VgicpArgs a, const Pose16 T) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n_src; i += gridDim.x * 256) {
+        const uint32_t slot = a.corr_slot[i];
+        if (slot) {
+            const float* sp = a.src + (size_t)i * a.src_stride;
+            const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
+            const VgicpVoxel vx = a.vox[slot - 1];
+            double er[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) er[r] = vx.mean[r] - (T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0);
+            const double* M6 = a.corr_M + (size_t)i * 6;
+            const double Me0 = M6[0] * er[0] + M6[1] * er[1] + M6[2] * er[2], Me1 = M6[1] * er[0] + M6[3] * er[1] + M6[4] * er[2],
+                         Me2 = M6[2] * er[0] + M6[4] * er[1] + M6[5] * er[2];
+            acc += vx.w * (er[0] * Me0 + er[1] * Me1 + er[2] * Me2);
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    // fixed-order tree
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.partials[(size_t)blockIdx.x * 32] = sh[0];
+        for (int k = 1; k < 32; ++k) a.partials[(size_t)blockIdx.x * 32 + k] = 0.0;
+    }
+}
+
+// fold per-block partials (32 doubles each) into 32 doubles, fixed order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+    __shared__ double sh[8 * 32];
+    const int t = threadIdx.x, comp = t & 31, slice = t >> 5;
+    double acc = 0.0;
+    for (uint32_t b = slice; b < nblocks; b += 8) acc += partials[(size_t)b * 32 + comp];
+    sh[slice * 32 + comp] = acc;
+    __syncthreads();
+    if (t < 32) {
+        double v = sh[t];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) v += sh[s * 32 + t];
+        out[t] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// PCL fitness score: mean squared 1-NN distance of the transformed source
+// (pcl::transformPointCloud in float, float kd-tree distances)
+// ------------------------------------------------------------------------------
+struct PoseF16 { float m[16]; };
+
+__global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* __restrict__ src, uint32_t n_src, uint32_t stride,
+                                                      const PoseF16 T, float max_range, double* __restrict__ partials) {
+    __shared__ double sh[256];
+    __shared__ double shc[256];
+    const GridHeader h = *g.hdr;
+    double acc = 0.0, cnt = 0.0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_src; i += gridDim.x * 256) {
+        const float* p = src + (size_t)i * stride;
+        const float qx = T.m[0] * p[0] + T.m[4] * p[1] + T.m[8] * p[2] + T.m[12];
+        const float qy = T.m[1] * p[0] + T.m[5] * p[1] + T.m[9] * p[2] + T.m[13];
+        const float qz = T.m[2] * p[0] + T.m[6] * p[1] + T.m[10] * p[2] + T.m[14];
+        KeyList<1> L;
+        ring_knn<1>(h, g.pts, g.cell_start, qx, qy, qz, max_range, L);
+        if (L.k[0] != ~0ull) {
+            const float d = __uint_as_float((uint32_t)(L.k[0] >> 32));
+            if (d <= max_range) { acc += (double)d; cnt += 1.0; }
+        }
+    }
+    sh[threadIdx.x] = acc; shc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shc[threadIdx.x] += shc[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * 32] = sh[0]; partials[(size_t)blockIdx.x * 32 + 1] = shc[0];
+        for (int k = 2; k < 32; ++k) partials[(size_t)blockIdx.x * 32 + k] = 0.0;
+    }
+}
+
+// ---- host launchers ---------------------------------------------------------------
+hipError_t vgicp_launch_cov(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, double* d_cov6, hipStream_t s) {
+    const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
+    hipLaunchKernelGGL(vgicp_cov_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6);
+    return hipGetLastError();
+}
+
+hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, uint32_t* d_slot, uint64_t slot_capacity, VgicpVoxel* d_vox,
+                               uint32_t* d_count, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const int blocks = (int)std::min<uint64_t>(65535, slot_capacity / 256 + 1);
+    hipLaunchKernelGGL(vgicp_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), (const float*)nullptr, d_cov6, d_slot, slot_capacity, d_vox,
+                       d_count);
+    return hipGetLastError();
+}
+
+uint32_t vgicp_blocks(uint32_t n_src) {
+    uint32_t b = (n_src + 255) / 256;
+    return b < 1 ? 1 : (b > 512 ? 512 : b);
+}
+
+hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s) {
+    const uint32_t nb = vgicp_blocks(a.n_src);
+    hipLaunchKernelGGL(vgicp_linearize_kernel, dim3(nb), dim3(256), 0, s, a, T);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32);
+    return hipGetLastError();
+}
+
+hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s) {
+    const uint32_t nb = vgicp_blocks(a.n_src);
+    hipLaunchKernelGGL(vgicp_error_kernel, dim3(nb), dim3(256), 0, s, a, T);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32);
+    return hipGetLastError();
+}
+
+hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
+                          double* d_partials, double* d_out32, hipStream_t s) {
+    PoseF16 T;
+    for (int i = 0; i < 16; ++i) T.m[i] = (float)pose[i];
+    const uint32_t nb = vgicp_blocks((uint32_t)n_src);
+    const float mr = max_range >= 3.0e38 ? 3.0e38f : (float)max_range;
+    hipLaunchKernelGGL(fitness_kernel, dim3(nb), dim3(256), 0, s, grid.view(), d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, mr, d_partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, d_partials, nb, d_out32);
+    return hipGetLastError();
+}
+
+}  // namespace pcr

@@ -48,7 +48,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace",
-    "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
 ]
 
 _lib = None
@@ -83,6 +83,8 @@ def load_library():
     L.pcr_fitness.restype = C.c_double
     L.pcr_loam_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, C.POINTER(C.c_int64), vp, vp, vp]
     L.pcr_get_trace.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, vp, vp]
+    L.pcr_vgicp_covariances.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
+    L.pcr_vgicp_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
     L.pcr_set_profile.argtypes = [vp, C.c_int]
     L.pcr_set_stream.argtypes = [vp, vp]
@@ -267,6 +269,32 @@ class NdtRegister(PointCloudRegister):
 class VgicpRegister(PointCloudRegister):
     """PCR::VgicpRegister (reference PCR/src/VgicpRegister.cpp)."""
     method = "vgicp"
+
+    def initForLC(self):
+        """VgicpRegister::initForLC (VgicpRegister.cpp:21-28): loop-closure settings.  Must be called
+        before the first registration (parameters are fixed at pcr_create): use
+        VgicpRegister(vgicp_max_iters=100, vgicp_trans_eps=1e-6) instead."""
+        raise NotImplementedError("construct with vgicp_max_iters=100, vgicp_trans_eps=1e-6")
+
+    def covariances(self, pts):
+        """(n,3,3) per-point covariances (fast_gicp_impl.hpp:241-297)."""
+        p, n, s, dev, _k = _cloud(pts)
+        c6 = np.zeros((n, 6))
+        self._check(self._lib.pcr_vgicp_covariances(self._h, p, n, s, dev, c6.ctypes.data_as(C.c_void_p)))
+        out = np.zeros((n, 3, 3))
+        out[:, 0, 0], out[:, 0, 1], out[:, 0, 2], out[:, 1, 1], out[:, 1, 2], out[:, 2, 2] = c6.T
+        out[:, 1, 0], out[:, 2, 0], out[:, 2, 1] = out[:, 0, 1], out[:, 0, 2], out[:, 1, 2]
+        return out
+
+    def linearize(self, src, pose):
+        p, n, s, dev, _k = _cloud(src)
+        pc = _pose_in(pose)
+        H, b = np.zeros(36), np.zeros(6)
+        err, nc = C.c_double(0), C.c_int64(0)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.pcr_vgicp_linearize(self._h, p, n, s, dev, pc.ctypes.data_as(dp), H.ctypes.data_as(dp),
+                                                  b.ctypes.data_as(dp), C.byref(err), C.byref(nc)))
+        return dict(H=H.reshape(6, 6), b=b, err=err.value, n=int(nc.value))
 
 
 def make_register(pcr_type, **overrides):
