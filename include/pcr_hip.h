@@ -137,6 +137,13 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
 int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
                         const double pose[16], double H[36], double b[6], double* error, int64_t* n_corr);
 
+/* NDT introspection: one computeDerivatives pass (ndt_omp_impl.hpp:180-285) at the parameter vector
+ * p = [tx ty tz, roll pitch yaw] (Translation * Rx * Ry * Rz, ndt_omp_impl.hpp:146-149) against the current
+ * target (pcr_set_target): score, gradient (6), Hessian (36, row-major) and, when hess_d != NULL, the
+ * double-precision Hessian of computeHessian (ndt_omp_impl.hpp:541-645) at the same pose. */
+int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
+                        const double p[6], double* score, double grad[6], double hess[36], double* hess_d);
+
 int pcr_get_stats(pcr_handle* h, pcr_stats* out);
 /* 0: no timing events; 1: phase events (default); 2: also an event pair around every
  * launch of the dominant kernel (adds host work; for roofline measurement only). */

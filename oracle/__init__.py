@@ -344,3 +344,81 @@ def fitness_score(src, dst, pose, max_range=1.7976931348623157e308):
     src, dst = _f32(src), _f32(dst)
     pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16).copy()
     return float(_vg().oracle_fitness_score(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc), float(max_range)))
+
+
+# ---------------------------------------------------------------------------
+# NDT restatement (oracle/ndt_oracle.c)
+# ---------------------------------------------------------------------------
+class NdtParams(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("step_size", C.c_double), ("outlier_ratio", C.c_double), ("trans_eps", C.c_double),
+                ("max_iters", C.c_int), ("min_points", C.c_int), ("eig_mult", C.c_double)]
+
+
+def _nd():
+    L = lib()
+    if not getattr(L, "_nd_ready", False):
+        L.oracle_ndt_default_params.argtypes = [C.POINTER(NdtParams)]
+        L.oracle_ndt_scan2map.restype = C.c_int
+        L.oracle_ndt_scan2map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(NdtParams),
+                                          C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_ndt_derivatives.restype = C.c_double
+        L.oracle_ndt_derivatives.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(NdtParams),
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_ndt_leaf_at.restype = C.c_int
+        L.oracle_ndt_leaf_at.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(NdtParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_svd6_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L._nd_ready = True
+    return L
+
+
+def ndt_params(**kw):
+    p = NdtParams()
+    _nd().oracle_ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def svd6_solve(A, b):
+    A = np.ascontiguousarray(A, np.float64).reshape(6, 6)
+    b = np.ascontiguousarray(b, np.float64).reshape(6)
+    x = np.zeros(6)
+    _nd().oracle_svd6_solve(_p(A), _p(b), _p(x))
+    return x
+
+
+def ndt_scan2map(src, dst, pose, params=None):
+    src, dst = _f32(src), _f32(dst)
+    assert src.shape[1] == dst.shape[1]
+    params = params or ndt_params()
+    pc = np.ascontiguousarray(np.asarray(pose, np.float64).T).reshape(16).copy()
+    info = np.zeros(3, np.int64)
+    sc = C.c_double(0)
+    conv = _nd().oracle_ndt_scan2map(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc), C.byref(params), _p(info), C.byref(sc))
+    return pc.reshape(4, 4).T.copy(), bool(conv), dict(iterations=int(info[0]), derivative_passes=int(info[1]),
+                                                       hessian_passes=int(info[2]), score=sc.value)
+
+
+def ndt_derivatives(src, dst, p6, params=None, double_hessian=False):
+    """score, gradient(6), Hessian(6x6) of computeDerivatives at p = [t; euler xyz]; optionally computeHessian's f64 Hessian."""
+    src, dst = _f32(src), _f32(dst)
+    params = params or ndt_params()
+    p6 = np.ascontiguousarray(p6, np.float64).reshape(6)
+    g, H = np.zeros(6), np.zeros(36)
+    Hd = np.zeros(36) if double_hessian else None
+    s = _nd().oracle_ndt_derivatives(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(p6), C.byref(params), _p(g), _p(H), _p(Hd))
+    out = dict(score=float(s), grad=g, hess=H.reshape(6, 6))
+    if double_hessian:
+        out["hess_d"] = Hd.reshape(6, 6)
+    return out
+
+
+def ndt_leaf_at(dst, p, params=None):
+    dst = _f32(dst)
+    params = params or ndt_params()
+    pp = np.ascontiguousarray(p, np.float32).reshape(3)
+    mean, cov, icov = np.zeros(3), np.zeros(9), np.zeros(9)
+    n = _nd().oracle_ndt_leaf_at(_p(dst), dst.shape[0], dst.shape[1], C.byref(params), _p(pp), _p(mean), _p(cov), _p(icov))
+    return n, mean, cov.reshape(3, 3), icov.reshape(3, 3)

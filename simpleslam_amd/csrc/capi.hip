@@ -83,6 +83,14 @@ struct pcr_handle {
     bool vg_target_ready = false;
     int vg_outer = 0, vg_lin = 0, vg_err = 0;
 
+    // NDT work memory
+    DeviceBuf nd_slot, nd_vox, nd_count, nd_partials;
+    double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
+    double* out48_dev = nullptr;
+    bool nd_target_ready = false;
+    int nd_iters = 0, nd_deriv = 0, nd_hess = 0;
+    double nd_score = 0;
+
     // multi-GPU
     int use_tile = 0;
     double tile_lo[3] = {0, 0, 0}, tile_hi[3] = {0, 0, 0};
@@ -411,6 +419,285 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// NDT host driver: pclomp::NormalDistributionsTransform::computeTransformation
+// (ndt_omp_impl.hpp:81-171) with the More-Thuente line search (:649-932).
+// ---------------------------------------------------------------------------------
+int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
+    h->nd_target_ready = false;
+    const double res = (double)(float)h->prm.ndt_resolution;     // resolution_ is a float (ndt_omp.h)
+    if (!(res > 0)) return fail(h, "ndt_resolution must be positive");
+    if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res)) return 1;
+    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
+    H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
+    H_TRY(h->nd_vox.reserve((n_dst / std::max(1, h->prm.ndt_min_points) + 2) * sizeof(NdtVoxel)));
+    H_TRY(h->nd_count.reserve(16));
+    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>(),
+                            h->prm.ndt_min_points, 0.01, h->stream));
+    h->nd_target_ready = true;
+    return 0;
+}
+
+namespace ndt_host {
+// Eigen::AngleAxisf(angle, Unit{X,Y,Z}).toRotationMatrix(), row-major
+void angle_axis(float angle, int axis, float R[9]) {
+    float ax[3] = {0, 0, 0}; ax[axis] = 1.0f;
+    const float s = sinf(angle), c = cosf(angle);
+    const float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    const float c1[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+    float tmp;
+    tmp = c1[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+    tmp = c1[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+    tmp = c1[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+    for (int d = 0; d < 3; ++d) R[d * 3 + d] = c1[d] * ax[d] + c;
+}
+void mul33(const float A[9], const float B[9], float C[9]) {
+    float o[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { float s = A[r * 3] * B[c]; s += A[r * 3 + 1] * B[3 + c]; s += A[r * 3 + 2] * B[6 + c]; o[r * 3 + c] = s; }
+    memcpy(C, o, sizeof o);
+}
+// Translation(x[0:3]) * Rx * Ry * Rz evaluated in float (ndt_omp_impl.hpp:146-149,827-830)
+void pose_from_p(const double x[6], NdtPose* T) {
+    float Rx[9], Ry[9], Rz[9], M[9];
+    angle_axis((float)x[3], 0, Rx); angle_axis((float)x[4], 1, Ry); angle_axis((float)x[5], 2, Rz);
+    mul33(Rx, Ry, M); mul33(M, Rz, T->R);
+    T->t[0] = (float)x[0]; T->t[1] = (float)x[1]; T->t[2] = (float)x[2];
+}
+// Matrix3f::eulerAngles(0, 1, 2)
+void euler_xyz(const float R[9], float out[3]) {
+    const float pi = 3.14159265358979323846f;
+    float r0 = atan2f(R[1 * 3 + 2], R[2 * 3 + 2]);
+    const float c2 = sqrtf(R[0] * R[0] + R[1] * R[1]);
+    float r1;
+    if (r0 > 0.f) { r0 -= pi; r1 = atan2f(-R[2], -c2); }
+    else r1 = atan2f(-R[2], c2);
+    const float s1 = sinf(r0), c1 = cosf(r0);
+    const float r2 = atan2f(s1 * R[2 * 3 + 0] - c1 * R[1 * 3 + 0], c1 * R[1 * 3 + 1] - s1 * R[2 * 3 + 1]);
+    out[0] = -r0; out[1] = -r1; out[2] = -r2;
+}
+void angle_derivatives(const double p[6], NdtAngles* a) {
+    double cx, cy, cz, sx, sy, sz;
+    if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
+    if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
+    if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
+    const double J[8][3] = {
+        {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)}, {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},
+        {(-sy * cz), sy * sz, cy}, {sx * cy * cz, (-sx * cy * sz), sx * sy}, {(-cx * cy * cz), cx * cy * sz, (-cx * sy)},
+        {(-cy * sz), (-cy * cz), 0}, {(cx * cz - sx * sy * sz), (-cx * sz - sx * sy * cz), 0}, {(sx * cz + cx * sy * sz), (cx * sy * cz - sx * sz), 0}};
+    const double Hh[15][3] = {
+        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), sx * cy}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), (-cx * cy)},
+        {(cx * cy * cz), (-cx * cy * sz), (cx * sy)}, {(sx * cy * cz), (-sx * cy * sz), (sx * sy)},
+        {(-sx * cz - cx * sy * sz), (sx * sz - cx * sy * cz), 0}, {(cx * cz - sx * sy * sz), (-sx * sy * cz - cx * sz), 0},
+        {(-cy * cz), (cy * sz), (-sy)}, {(-sx * sy * cz), (sx * sy * sz), (sx * cy)}, {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},
+        {(sy * sz), (sy * cz), 0}, {(-sx * cy * sz), (-sx * cy * cz), 0}, {(cx * cy * sz), (cx * cy * cz), 0},
+        {(-cy * cz), (cy * sz), 0}, {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) { a->jd[r][c] = J[r][c]; a->j[r][c] = (float)J[r][c]; }
+    for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) { a->hd[r][c] = Hh[r][c]; a->h[r][c] = (float)Hh[r][c]; }
+    a->h[6][2] = (float)(sy);   // the float table (:384) writes (sy) where h_ang_d1_ (:362) has (-sy)
+}
+// JacobiSVD<Matrix6d>::solve: one-sided Jacobi, pseudo-inverse with Eigen's default threshold
+void svd6_solve(const double A_in[36], const double b[6], double x[6]) {
+    double U[6][6], V[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { U[i][j] = A_in[i * 6 + j]; V[i][j] = i == j; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 6; ++k) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
+                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 6; ++k) {
+                    const double up = U[k][p], uq = U[k][q]; U[k][p] = c * up - s * uq; U[k][q] = s * up + c * uq;
+                    const double vp = V[k][p], vq = V[k][q]; V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sig[6], smax = 0;
+    for (int j = 0; j < 6; ++j) { double s = 0; for (int k = 0; k < 6; ++k) s += U[k][j] * U[k][j]; sig[j] = sqrt(s); smax = std::max(smax, sig[j]); }
+    const double thr = 6.0 * 2.220446049250313e-16 * smax;
+    for (int i = 0; i < 6; ++i) x[i] = 0;
+    for (int j = 0; j < 6; ++j) {
+        if (!(sig[j] > thr)) continue;
+        double ub = 0;
+        for (int k = 0; k < 6; ++k) ub += (U[k][j] / sig[j]) * b[k];
+        for (int i = 0; i < 6; ++i) x[i] += V[i][j] * (ub / sig[j]);
+    }
+}
+bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
+    if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
+    else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    else if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    return true;
+}
+double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+    if (f_t > f_l) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        return std::fabs(a_c - a_l) < std::fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+    } else if (g_t * g_l < 0) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        return std::fabs(a_c - a_t) >= std::fabs(a_s - a_t) ? a_c : a_s;
+    } else if (std::fabs(g_t) <= std::fabs(g_l)) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        const double nx = std::fabs(a_c - a_t) < std::fabs(a_s - a_t) ? a_c : a_s;
+        const double lim = a_t + 0.66 * (a_u - a_t);
+        return a_t > a_l ? std::min(lim, nx) : std::max(lim, nx);
+    }
+    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = std::sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+}  // namespace ndt_host
+
+struct NdtRun {
+    pcr_handle* h; NdtArgs a; NdtPose T; NdtAngles ang;
+};
+
+// computeDerivatives at parameters p with the cloud transformed by T: score, gradient, Hessian
+int ndt_derivatives(NdtRun* r, const double p[6], bool compute_hessian, double* score, double grad[6], double hess[36]) {
+    pcr_handle* h = r->h;
+    ndt_host::angle_derivatives(p, &r->ang);
+    if (r->a.n_src == 0) { *score = 0; memset(grad, 0, 6 * sizeof(double)); memset(hess, 0, 36 * sizeof(double)); return 0; }
+    H_TRY(ndt_launch_derivatives(r->a, r->T, r->ang, compute_hessian ? 1 : 0, h->out48_dev, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    ++h->nd_deriv;
+    *score = h->out48_host[0];
+    for (int i = 0; i < 6; ++i) grad[i] = h->out48_host[1 + i];
+    for (int i = 0; i < 36; ++i) hess[i] = compute_hessian ? h->out48_host[7 + i] : 0.0;
+    return 0;
+}
+
+int ndt_step_length(NdtRun* r, const double x[6], double dir[6], double step_init, double step_max, double step_min, double* score,
+                    double grad[6], double hess[36], double* a_out) {
+    using namespace ndt_host;
+    pcr_handle* h = r->h;
+    double phi_0 = -*score, d_phi_0 = 0;
+    for (int i = 0; i < 6; ++i) d_phi_0 += grad[i] * dir[i];
+    d_phi_0 = -d_phi_0;
+    if (d_phi_0 >= 0) {
+        if (d_phi_0 == 0) { *a_out = 0; return 0; }
+        d_phi_0 *= -1;
+        for (int i = 0; i < 6; ++i) dir[i] *= -1;
+    }
+    const int max_it = 10;
+    int it = 0;
+    const double mu = 1.e-4, nu = 0.9;
+    double a_l = 0, a_u = 0;
+    double f_l = phi_0 - phi_0 - mu * d_phi_0 * a_l, g_l = d_phi_0 - mu * d_phi_0;
+    double f_u = phi_0 - phi_0 - mu * d_phi_0 * a_u, g_u = d_phi_0 - mu * d_phi_0;
+    bool interval_converged = (step_max - step_min) < 0, open_interval = true;
+    double a_t = step_init;
+    a_t = std::min(a_t, step_max);
+    a_t = std::max(a_t, step_min);
+    double x_t[6];
+    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
+    pose_from_p(x_t, &r->T);
+    if (ndt_derivatives(r, x_t, true, score, grad, hess)) return 1;
+    double phi_t = -*score, d_phi_t = 0;
+    for (int i = 0; i < 6; ++i) d_phi_t += grad[i] * dir[i];
+    d_phi_t = -d_phi_t;
+    double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+    while (!interval_converged && it < max_it && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+        if (open_interval) a_t = trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else a_t = trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        a_t = std::min(a_t, step_max);
+        a_t = std::max(a_t, step_min);
+        for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
+        pose_from_p(x_t, &r->T);
+        if (ndt_derivatives(r, x_t, false, score, grad, hess)) return 1;
+        phi_t = -*score; d_phi_t = 0;
+        for (int i = 0; i < 6; ++i) d_phi_t += grad[i] * dir[i];
+        d_phi_t = -d_phi_t;
+        psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t; d_psi_t = d_phi_t - mu * d_phi_0;
+        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+            open_interval = false;
+            f_l = f_l + phi_0 - mu * d_phi_0 * a_l; g_l = g_l + mu * d_phi_0;
+            f_u = f_u + phi_0 - mu * d_phi_0 * a_u; g_u = g_u + mu * d_phi_0;
+        }
+        if (open_interval) interval_converged = update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else interval_converged = update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        it++;
+    }
+    if (it && r->a.n_src) {   // computeHessian (:928-929), double precision, with the tables of the last pass
+        H_TRY(ndt_launch_hessian(r->a, r->T, r->ang, h->out48_dev, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        ++h->nd_hess;
+        for (int i = 0; i < 36; ++i) hess[i] = h->out48_host[7 + i];
+    }
+    *a_out = a_t;
+    return 0;
+}
+
+int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged) {
+    using namespace ndt_host;
+    if (!h->nd_target_ready) return fail(h, "no target prepared");
+    if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
+    if (!h->out48_host) {
+        H_TRY(hipHostMalloc((void**)&h->out48_host, 48 * sizeof(double), hipHostMallocMapped));
+        H_TRY(hipHostGetDevicePointer((void**)&h->out48_dev, h->out48_host, 0));
+    }
+    H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));
+    NdtRun r;
+    r.h = h;
+    r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)stride_floats;
+    r.a.hdr = h->grid.header.as<GridHeader>(); r.a.vox_slot = h->nd_slot.as<uint32_t>(); r.a.vox = h->nd_vox.as<NdtVoxel>();
+    r.a.partials = h->nd_partials.as<double>();
+    {   // Gauss constants (ndt_omp_impl.hpp:86-93)
+        const double res = (double)(float)h->prm.ndt_resolution;
+        const double c1 = 10 * (1 - h->prm.ndt_outlier_ratio), c2 = h->prm.ndt_outlier_ratio / pow(res, 3);
+        const double d3 = -log(c2);
+        r.a.d1 = -log(c1 + c2) - d3;
+        r.a.d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / r.a.d1);
+    }
+    h->nd_iters = h->nd_deriv = h->nd_hess = 0;
+    // guess handed over as Matrix4f (NdtRegister.cpp:27)
+    float G[16];
+    for (int i = 0; i < 16; ++i) G[i] = (float)pose[i];
+    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) r.T.R[rr * 3 + c] = G[c * 4 + rr]; r.T.t[rr] = G[12 + rr]; }
+    NdtPose final_T = r.T;
+    float eul[3];
+    euler_xyz(r.T.R, eul);     // Transform::rotation() taken as the linear part
+    double p[6] = {r.T.t[0], r.T.t[1], r.T.t[2], eul[0], eul[1], eul[2]}, delta_p[6], grad[6], hess[36], score = 0;
+    if (ndt_derivatives(&r, p, true, &score, grad, hess)) return 1;
+    bool conv = false;
+    int nr_it = 0;
+    while (!conv) {
+        double rhs[6];
+        for (int i = 0; i < 6; ++i) rhs[i] = -grad[i];
+        svd6_solve(hess, rhs, delta_p);
+        double nrm = 0;
+        for (int i = 0; i < 6; ++i) nrm += delta_p[i] * delta_p[i];
+        nrm = sqrt(nrm);
+        if (nrm == 0 || nrm != nrm) { conv = nrm == nrm; break; }
+        for (int i = 0; i < 6; ++i) delta_p[i] /= nrm;
+        double a_t = 0;
+        if (ndt_step_length(&r, p, delta_p, nrm, h->prm.ndt_step_size, h->prm.ndt_trans_eps / 2, &score, grad, hess, &a_t)) return 1;
+        nrm = a_t;
+        for (int i = 0; i < 6; ++i) delta_p[i] *= nrm;
+        final_T = r.T;
+        for (int i = 0; i < 6; ++i) p[i] += delta_p[i];
+        if (nr_it > h->prm.ndt_max_iters || (nr_it && fabs(nrm) < h->prm.ndt_trans_eps)) conv = true;
+        nr_it++;
+    }
+    for (int i = 0; i < 16; ++i) pose[i] = 0;
+    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) pose[c * 4 + rr] = (double)final_T.R[rr * 3 + c]; pose[12 + rr] = (double)final_T.t[rr]; }
+    pose[15] = 1.0;
+    if (converged) *converged = conv ? 1 : 0;
+    h->nd_iters = nr_it; h->nd_score = score;
+    h->stats.iterations = nr_it; h->stats.kernel_launches = h->nd_deriv + h->nd_hess;
+    h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
+    return 0;
+}
+
 int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst, size_t stride_bytes,
                 double pose[16], int* converged, bool on_device) {
     if (!h) return 1;
@@ -418,13 +705,27 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     if (!pose) return fail(h, "pose_inout is NULL");
     if ((n_src && !src) || (n_dst && !dst)) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
-    if (h->method == kNdt) return fail(h, "method not available in this build yet");
     const float *d_src, *d_dst;
     if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_start, h->stream));
     if (on_device) { d_src = (const float*)src; d_dst = (const float*)dst; }
     else {
         if (stage_host(h, &h->tgt_stage, dst, n_dst, stride_bytes, &d_dst)) return 1;
         if (stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    }
+    if (h->method == kNdt) {
+        // NdtRegister::scan2Map calls setInputTarget every time, which rebuilds the voxel grid (NdtRegister.cpp:23)
+        if (ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
+        if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
+        if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
+        if (h->profile >= 1) {
+            H_TRY(hipEventRecord(h->ev_end, h->stream));
+            H_TRY(hipEventSynchronize(h->ev_end));
+            float ms = 0;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_end)); h->stats.total_ms = ms;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_index)); h->stats.index_ms = ms;
+            H_TRY(hipEventElapsedTime(&ms, h->ev_index, h->ev_end)); h->stats.solve_ms = ms;
+        }
+        return 0;
     }
     if (h->method == kVgicp) {
         // the reference keeps its target structures while the cloud POINTER is unchanged and goes stale
@@ -515,6 +816,8 @@ void pcr_destroy(pcr_handle* h) {
     h->src_grid.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox_slot.release(); h->vox.release();
     h->vox_count.release(); h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
     if (h->out32_host) (void)hipHostFree(h->out32_host);
+    h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_partials.release();
+    if (h->out48_host) (void)hipHostFree(h->out48_host);
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
     h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->q_cache.release();
     if (h->result_host) (void)hipHostFree(h->result_host);
@@ -549,7 +852,7 @@ int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_b
     H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
     if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     if (h->method == kVgicp) return vgicp_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
-    if (h->method == kNdt) return fail(h, "method not available in this build yet");
+    if (h->method == kNdt) return ndt_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
     if (build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4)) return 1;
     // settle the cell-table size now so that pcr_align never has to rebuild
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -571,16 +874,16 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
-    if (h->method == kNdt) return fail(h, "method not available in this build yet");
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    if (h->method == kNdt) return run_ndt(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);
     if (h->method == kVgicp) return run_vgicp(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);
     return run_loam(h, d_src, n_src, stride_bytes / 4, pose_inout, converged, false);
 }
 
 int pcr_invalidate_target(pcr_handle* h) {
     if (!h) return 1;
-    h->have_target = false; h->grid.valid = false; h->vg_target_ready = false;
+    h->have_target = false; h->grid.valid = false; h->vg_target_ready = false; h->nd_target_ready = false;
     return 0;
 }
 
@@ -683,6 +986,41 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     for (int r = 0; r < 6; ++r) b[r] = h->out32_host[21 + r];
     if (error) *error = h->out32_host[27];
     if (n_corr) { int64_t c = 0; for (uint32_t v : slots) c += v != 0; *n_corr = c; }
+    return 0;
+}
+
+int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, const double p[6],
+                        double* score, double grad[6], double hess[36], double* hess_d) {
+    if (!h) return 1;
+    h->err.clear();
+    if (h->method != kNdt) return fail(h, "pcr_ndt_derivatives needs an ndt handle");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (!h->nd_target_ready) return fail(h, "no target: call pcr_set_target first");
+    const float* d_src = (const float*)src;
+    if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    if (!h->out48_host) {
+        H_TRY(hipHostMalloc((void**)&h->out48_host, 48 * sizeof(double), hipHostMallocMapped));
+        H_TRY(hipHostGetDevicePointer((void**)&h->out48_dev, h->out48_host, 0));
+    }
+    H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));
+    NdtRun r;
+    r.h = h;
+    r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)(stride_bytes / 4);
+    r.a.hdr = h->grid.header.as<GridHeader>(); r.a.vox_slot = h->nd_slot.as<uint32_t>(); r.a.vox = h->nd_vox.as<NdtVoxel>();
+    r.a.partials = h->nd_partials.as<double>();
+    const double res = (double)(float)h->prm.ndt_resolution;
+    const double c1 = 10 * (1 - h->prm.ndt_outlier_ratio), c2 = h->prm.ndt_outlier_ratio / pow(res, 3), d3 = -log(c2);
+    r.a.d1 = -log(c1 + c2) - d3;
+    r.a.d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / r.a.d1);
+    ndt_host::pose_from_p(p, &r.T);
+    double sc = 0;
+    if (ndt_derivatives(&r, p, true, &sc, grad, hess)) return 1;
+    if (score) *score = sc;
+    if (hess_d && n_src) {
+        H_TRY(ndt_launch_hessian(r.a, r.T, r.ang, h->out48_dev, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < 36; ++i) hess_d[i] = h->out48_host[7 + i];
+    }
     return 0;
 }
 

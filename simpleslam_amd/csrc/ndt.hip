@@ -1,0 +1,398 @@
+// ndt.hip -- NDT scan-to-map (pclomp::NormalDistributionsTransform, DIRECT7) on gfx950.
+//
+// Kernels for the reference's PCR::NdtRegister::scan2Map (PCR/src/NdtRegister.cpp:21-31):
+//   N1 voxel Gaussians   voxel_grid_covariance_omp_impl.hpp:49-370 (serial std::map there)
+//      -> ndt_voxel_kernel: one thread per cell of the uniform index (cell = resolution):
+//         centred fixed-point sums (order independent), covariance * (n-1)/n, Jacobi eigen
+//         decomposition, eigenvalue inflation 0.01 * lambda_max, inverse
+//   N3 computeDerivatives / updateDerivatives   ndt_omp_impl.hpp:180-285,399-440,485-537
+//      -> ndt_derivatives_kernel: per source point, <= 7 neighbour cells (N6, :374-433),
+//         FLOAT inner math exactly as the reference orders it, f64 accumulation, fixed-order sums
+//   N5 computeHessian / updateHessian           ndt_omp_impl.hpp:541-645 (serial, double)
+//      -> ndt_hessian_kernel
+//   N2/N4 Newton step + More-Thuente line search: host code in capi.hip.
+#include "pcr_internal.h"
+#include "small_math.h"
+
+namespace pcr {
+
+__device__ inline void sym3_eig_asc(const double A[6], double w[3], double V[3][3]);   // below
+
+// cyclic Jacobi, eigenvalues ASCENDING (Eigen::SelfAdjointEigenSolver order), V columns
+__device__ inline void sym3_eig_asc(const double A[6] /* xx xy xz yy yz zz */, double w[3], double V[3][3]) {
+    double a[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] != 0.0) {
+                    const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+                }
+            }
+        }
+    }
+    double e0 = a[0][0], e1 = a[1][1], e2 = a[2][2];
+    double c0[3] = {v[0][0], v[1][0], v[2][0]}, c1[3] = {v[0][1], v[1][1], v[2][1]}, c2[3] = {v[0][2], v[1][2], v[2][2]};
+#define SWAPCOL(ea, ca, eb, cb) if (eb < ea) { double t_ = ea; ea = eb; eb = t_; for (int k_ = 0; k_ < 3; ++k_) { double u_ = ca[k_]; ca[k_] = cb[k_]; cb[k_] = u_; } }
+    SWAPCOL(e0, c0, e1, c1) SWAPCOL(e0, c0, e2, c2) SWAPCOL(e1, c1, e2, c2)
+#undef SWAPCOL
+    w[0] = e0; w[1] = e1; w[2] = e2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { V[k][0] = c0[k]; V[k][1] = c1[k]; V[k][2] = c2[k]; }
+}
+
+__device__ inline void inv3_general(const double m[9], double out[9]) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02, id = 1.0 / det;
+    out[0] = c00 * id; out[1] = (m[2] * m[7] - m[1] * m[8]) * id; out[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    out[3] = c01 * id; out[4] = (m[0] * m[8] - m[2] * m[6]) * id; out[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    out[6] = c02 * id; out[7] = (m[1] * m[6] - m[0] * m[7]) * id; out[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// ------------------------------------------------------------------------------
+// N1: voxel Gaussians, one thread per index cell
+// ------------------------------------------------------------------------------
+static constexpr double kFix1 = 17592186044416.0;   // 2^44 for sums of (x - c)
+static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(x - c)^T
+
+__global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, uint32_t* __restrict__ vox_slot, NdtVoxel* __restrict__ vox,
+                                                        uint32_t* __restrict__ vox_count, int min_points, double eig_mult) {
+    const GridHeader h = *g.hdr;
+    if (h.overflow) return;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < h.n_cells; t += (uint64_t)gridDim.x * 256) {
+        const uint32_t s = g.cell_start[t], e = g.cell_start[t + 1];
+        const int n = (int)(e - s);
+        uint32_t slot = 0;
+        if (!h.empty && n >= min_points) {
+            const int cx = (int)(t % (uint64_t)h.dims[0]), cy = (int)((t / (uint64_t)h.dims[0]) % (uint64_t)h.dims[1]),
+                      cz = (int)(t / ((uint64_t)h.dims[0] * (uint64_t)h.dims[1]));
+            const double ox = (h.org[0] + cx + 0.5) * h.cell, oy = (h.org[1] + cy + 0.5) * h.cell, oz = (h.org[2] + cz + 0.5) * h.cell;
+            long long s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t j = s; j < e; ++j) {
+                const float4 p = g.pts[j];
+                const double dx = (double)p.x - ox, dy = (double)p.y - oy, dz = (double)p.z - oz;
+                s1[0] += llrint(dx * kFix1); s1[1] += llrint(dy * kFix1); s1[2] += llrint(dz * kFix1);
+                s2[0] += llrint(dx * dx * kFix2); s2[1] += llrint(dx * dy * kFix2); s2[2] += llrint(dx * dz * kFix2);
+                s2[3] += llrint(dy * dy * kFix2); s2[4] += llrint(dy * dz * kFix2); s2[5] += llrint(dz * dz * kFix2);
+            }
+            const double inv = 1.0 / (double)n;
+            const double m1[3] = {(double)s1[0] / kFix1 * inv, (double)s1[1] / kFix1 * inv, (double)s1[2] / kFix1 * inv};
+            // population covariance (shift invariant), then the reference's (n-1)/n factor (:329-330)
+            double C[6];
+            C[0] = (double)s2[0] / kFix2 * inv - m1[0] * m1[0]; C[1] = (double)s2[1] / kFix2 * inv - m1[0] * m1[1];
+            C[2] = (double)s2[2] / kFix2 * inv - m1[0] * m1[2]; C[3] = (double)s2[3] / kFix2 * inv - m1[1] * m1[1];
+            C[4] = (double)s2[4] / kFix2 * inv - m1[1] * m1[2]; C[5] = (double)s2[5] / kFix2 * inv - m1[2] * m1[2];
+            const double f = ((double)n - 1.0) / (double)n;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) C[k] *= f;
+            double w[3], V[3][3];
+            sym3_eig_asc(C, w, V);
+            bool ok = !(w[0] < 0 || w[1] < 0 || w[2] <= 0);            // :337-341
+            double cov[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+            if (ok) {
+                const double minev = eig_mult * w[2];                   // :345-356
+                if (w[0] < minev) {
+                    w[0] = minev;
+                    if (w[1] < minev) w[1] = minev;
+                    double E[9], Ei[9], T[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { E[r * 3] = V[r][0]; E[r * 3 + 1] = V[r][1]; E[r * 3 + 2] = V[r][2]; }
+                    inv3_general(E, Ei);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) T[r * 3 + c] = E[r * 3 + c] * w[c];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) cov[r * 3 + c] = T[r * 3] * Ei[c] + T[r * 3 + 1] * Ei[3 + c] + T[r * 3 + 2] * Ei[6 + c];
+                }
+                NdtVoxel v;
+                inv3_general(cov, v.icov);                               // :359
+                double mx = v.icov[0], mn = v.icov[0];
+#pragma unroll
+                for (int k = 1; k < 9; ++k) { mx = fmax(mx, v.icov[k]); mn = fmin(mn, v.icov[k]); }
+                if (isinf(mx) || isinf(mn)) ok = false;
+                if (ok) {
+                    v.mean[0] = ox + m1[0]; v.mean[1] = oy + m1[1]; v.mean[2] = oz + m1[2];
+                    v.n = n; v.pad = 0;
+                    slot = atomicAdd(vox_count, 1u) + 1;                // placement only
+                    vox[slot - 1] = v;
+                }
+            }
+        }
+        vox_slot[t] = slot;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// neighbourhood: centre cell then +x -x +y -y +z -z (:419-433)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int ndt_neighbours(const GridHeader& h, const uint32_t* __restrict__ vox_slot, float tx, float ty, float tz,
+                                              uint32_t slots[7]) {
+    int n = 0;
+    if (h.overflow || h.empty) return 0;
+    // floor(p / leaf) evaluated in float like the reference (:380-382)
+    const float leaf = (float)h.cell;
+    const double fx = (double)floorf(tx / leaf) - h.org[0], fy = (double)floorf(ty / leaf) - h.org[1], fz = (double)floorf(tz / leaf) - h.org[2];
+    if (!(fx >= -1.0 && fx <= (double)h.dims[0] && fy >= -1.0 && fy <= (double)h.dims[1] && fz >= -1.0 && fz <= (double)h.dims[2])) return 0;
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    const int off[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int x = cx + off[k][0], y = cy + off[k][1], z = cz + off[k][2];
+        if (x >= 0 && x < h.dims[0] && y >= 0 && y < h.dims[1] && z >= 0 && z < h.dims[2]) {
+            const uint32_t s = vox_slot[((uint64_t)z * (uint64_t)h.dims[1] + (uint64_t)y) * (uint64_t)h.dims[0] + (uint64_t)x];
+            if (s) slots[n++] = s;
+        }
+    }
+    return n;
+}
+
+static constexpr int kNdtBlock = 128;
+static constexpr int kNdtStride = 130;
+static constexpr int kNdtComp = 43;    // score, gradient 6, Hessian 36
+
+// fold v[43] of every thread of the block into partials[block][48] in a fixed order
+__device__ __forceinline__ void ndt_block_reduce(double* sh /* [43][kNdtStride] */, double* sh2 /* [2][64] */, const double v[kNdtComp],
+                                                 double& acc, bool last, double* __restrict__ partials) {
+    const int tid = threadIdx.x, e = tid & 63, ch = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < kNdtComp; ++k) sh[k * kNdtStride + tid] = v[k];
+    __syncthreads();
+    if (e < kNdtComp) {
+        const double* row = sh + e * kNdtStride + ch * 64;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) acc += row[k];
+    }
+    __syncthreads();
+    if (last) {
+        sh2[ch * 64 + e] = e < kNdtComp ? acc : 0.0;
+        __syncthreads();
+        if (tid < 48) partials[(size_t)blockIdx.x * 48 + tid] = tid < kNdtComp ? sh2[tid] + sh2[64 + tid] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// N3: computeDerivatives
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang, int compute_hessian) {
+    __shared__ double sh[kNdtComp * kNdtStride];
+    __shared__ double sh2[2 * 64];
+    const GridHeader h = *a.hdr;
+    const float gauss_d2 = (float)a.d2;
+    double acc = 0.0;
+    const uint32_t step = gridDim.x * kNdtBlock;
+    for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
+        const uint32_t idx = base + threadIdx.x;
+        double v[kNdtComp];
+#pragma unroll
+        for (int k = 0; k < kNdtComp; ++k) v[k] = 0.0;
+        if (idx < a.n_src) {
+            const float* xp = a.src + (size_t)idx * a.src_stride;
+            const float x4[3] = {xp[0], xp[1], xp[2]};
+            // pcl::transformPointCloud in float
+            float tp[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { float s = T.R[r * 3] * x4[0]; s += T.R[r * 3 + 1] * x4[1]; s += T.R[r * 3 + 2] * x4[2]; s += T.t[r]; tp[r] = s; }
+            uint32_t slots[7];
+            const int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            if (nn > 0) {
+                // computePointDerivatives (float): :399-440
+                float pg[3][6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) pg[r][c] = (r == c) ? 1.0f : 0.0f;
+                float xj[8], xh[15];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { float s = ang.j[r][0] * x4[0]; s += ang.j[r][1] * x4[1]; s += ang.j[r][2] * x4[2]; xj[r] = s; }
+                pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
+#pragma unroll
+                for (int r = 0; r < 15; ++r) { float s = ang.h[r][0] * x4[0]; s += ang.h[r][1] * x4[1]; s += ang.h[r][2] * x4[2]; xh[r] = s; }
+                // second derivatives of the transform for parameter pairs (i,j), i,j in 3..5; index (i-3)*3+(j-3)
+                const float ph[9][3] = {{0, xh[0], xh[1]}, {0, xh[2], xh[3]}, {0, xh[4], xh[5]},
+                                        {0, xh[2], xh[3]}, {xh[6], xh[7], xh[8]}, {xh[9], xh[10], xh[11]},
+                                        {0, xh[4], xh[5]}, {xh[9], xh[10], xh[11]}, {xh[12], xh[13], xh[14]}};
+                for (int k = 0; k < nn; ++k) {
+                    const NdtVoxel cell = a.vox[slots[k] - 1];
+                    const double xt[3] = {(double)tp[0] - cell.mean[0], (double)tp[1] - cell.mean[1], (double)tp[2] - cell.mean[2]};
+                    const float x4t[3] = {(float)xt[0], (float)xt[1], (float)xt[2]};
+                    float ci[3][3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) ci[r][c] = (float)cell.icov[r * 3 + c];
+                    float xc[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { float s = x4t[0] * ci[0][c]; s += x4t[1] * ci[1][c]; s += x4t[2] * ci[2][c]; xc[c] = s; }
+                    float dot = x4t[0] * xc[0]; dot += x4t[1] * xc[1]; dot += x4t[2] * xc[2];
+                    float e = expf(-gauss_d2 * dot * 0.5f);                      // :497
+                    const float score_inc = (float)(-a.d1 * (double)e);          // :499
+                    e = gauss_d2 * e;
+                    if (e > 1 || e < 0 || e != e) continue;                      // :504-505
+                    e = (float)((double)e * a.d1);
+                    float cpg[3][6];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) { float s = ci[r][0] * pg[0][c]; s += ci[r][1] * pg[1][c]; s += ci[r][2] * pg[2][c]; cpg[r][c] = s; }
+                    float xcpg[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) { float s = x4t[0] * cpg[0][c]; s += x4t[1] * cpg[1][c]; s += x4t[2] * cpg[2][c]; xcpg[c] = s; }
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v[1 + c] += (double)(e * xcpg[c]);
+                    if (compute_hessian) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) {
+                                float xph = 0.0f;
+                                if (i >= 3 && j >= 3) {
+                                    const float* q = ph[(i - 3) * 3 + (j - 3)];
+                                    xph = xc[0] * q[0]; xph += xc[1] * q[1]; xph += xc[2] * q[2];
+                                }
+                                float pgc = pg[0][j] * cpg[0][i]; pgc += pg[1][j] * cpg[1][i]; pgc += pg[2][j] * cpg[2][i];   // (PG^T C PG)(j,i)
+                                v[7 + i * 6 + j] += (double)(e * (-gauss_d2 * xcpg[i] * xcpg[j] + xph + pgc));
+                            }
+                        }
+                    }
+                    v[0] += (double)score_inc;
+                }
+            }
+        }
+        ndt_block_reduce(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// N5: computeHessian (double)
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+    __shared__ double sh[kNdtComp * kNdtStride];
+    __shared__ double sh2[2 * 64];
+    const GridHeader h = *a.hdr;
+    double acc = 0.0;
+    const uint32_t step = gridDim.x * kNdtBlock;
+    for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
+        const uint32_t idx = base + threadIdx.x;
+        double v[kNdtComp];
+#pragma unroll
+        for (int k = 0; k < kNdtComp; ++k) v[k] = 0.0;
+        if (idx < a.n_src) {
+            const float* xp = a.src + (size_t)idx * a.src_stride;
+            float tp[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { float s = T.R[r * 3] * xp[0]; s += T.R[r * 3 + 1] * xp[1]; s += T.R[r * 3 + 2] * xp[2]; s += T.t[r]; tp[r] = s; }
+            uint32_t slots[7];
+            const int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            if (nn > 0) {
+                const double x[3] = {(double)xp[0], (double)xp[1], (double)xp[2]};
+                double pg[3][6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) pg[r][c] = (r == c) ? 1.0 : 0.0;
+                double dj[8], dh[15];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dj[r] = x[0] * ang.jd[r][0] + x[1] * ang.jd[r][1] + x[2] * ang.jd[r][2];
+#pragma unroll
+                for (int r = 0; r < 15; ++r) dh[r] = x[0] * ang.hd[r][0] + x[1] * ang.hd[r][1] + x[2] * ang.hd[r][2];
+                pg[1][3] = dj[0]; pg[2][3] = dj[1]; pg[0][4] = dj[2]; pg[1][4] = dj[3]; pg[2][4] = dj[4]; pg[0][5] = dj[5]; pg[1][5] = dj[6]; pg[2][5] = dj[7];
+                const double ph[9][3] = {{0, dh[0], dh[1]}, {0, dh[2], dh[3]}, {0, dh[4], dh[5]},
+                                         {0, dh[2], dh[3]}, {dh[6], dh[7], dh[8]}, {dh[9], dh[10], dh[11]},
+                                         {0, dh[4], dh[5]}, {dh[9], dh[10], dh[11]}, {dh[12], dh[13], dh[14]}};
+                for (int k = 0; k < nn; ++k) {
+                    const NdtVoxel cell = a.vox[slots[k] - 1];
+                    const double xt[3] = {(double)tp[0] - cell.mean[0], (double)tp[1] - cell.mean[1], (double)tp[2] - cell.mean[2]};
+                    const double* ci = cell.icov;
+                    double cx[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) cx[r] = ci[r * 3] * xt[0] + ci[r * 3 + 1] * xt[1] + ci[r * 3 + 2] * xt[2];
+                    double e = a.d2 * exp(-a.d2 * (xt[0] * cx[0] + xt[1] * cx[1] + xt[2] * cx[2]) / 2);     // :623
+                    if (e > 1 || e < 0 || e != e) continue;
+                    e *= a.d1;
+                    double cpg[6][3], xd[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) cpg[i][r] = ci[r * 3] * pg[0][i] + ci[r * 3 + 1] * pg[1][i] + ci[r * 3 + 2] * pg[2][i];
+                        xd[i] = xt[0] * cpg[i][0] + xt[1] * cpg[i][1] + xt[2] * cpg[i][2];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            double t2 = 0.0;
+                            if (i >= 3 && j >= 3) {
+                                const double* q = ph[(i - 3) * 3 + (j - 3)];
+                                double cph[3];
+#pragma unroll
+                                for (int r = 0; r < 3; ++r) cph[r] = ci[r * 3] * q[0] + ci[r * 3 + 1] * q[1] + ci[r * 3 + 2] * q[2];
+                                t2 = xt[0] * cph[0] + xt[1] * cph[1] + xt[2] * cph[2];
+                            }
+                            const double t3 = pg[0][j] * cpg[i][0] + pg[1][j] * cpg[i][1] + pg[2][j] * cpg[i][2];
+                            v[7 + i * 6 + j] += e * (-a.d2 * xd[i] * xd[j] + t2 + t3);
+                        }
+                    }
+                }
+            }
+        }
+        ndt_block_reduce(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
+    }
+}
+
+// fold per-block partials (48 doubles each) into 48 doubles, fixed order
+__global__ __launch_bounds__(192) void ndt_sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+    __shared__ double sh[4 * 48];
+    const int t = threadIdx.x, comp = t % 48, slice = t / 48;
+    double acc = 0.0;
+    for (uint32_t b = slice; b < nblocks; b += 4) acc += partials[(size_t)b * 48 + comp];
+    sh[slice * 48 + comp] = acc;
+    __syncthreads();
+    if (t < 48) out[t] = ((sh[t] + sh[48 + t]) + sh[96 + t]) + sh[144 + t];
+}
+
+// ---- host launchers ---------------------------------------------------------------
+uint32_t ndt_blocks(uint32_t n_src) {
+    uint32_t b = (n_src + kNdtBlock - 1) / kNdtBlock;
+    return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
+
+hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, int min_points, double eig_mult,
+                             hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const int blocks = (int)std::min<size_t>(65535, grid.cell_capacity / 256 + 1);
+    hipLaunchKernelGGL(ndt_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_vox, d_count, min_points, eig_mult);
+    return hipGetLastError();
+}
+
+hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s) {
+    const uint32_t nb = ndt_blocks(a.n_src);
+    hipLaunchKernelGGL(ndt_derivatives_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang, compute_hessian);
+    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(192), 0, s, a.partials, nb, d_out48);
+    return hipGetLastError();
+}
+
+hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s) {
+    const uint32_t nb = ndt_blocks(a.n_src);
+    hipLaunchKernelGGL(ndt_hessian_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
+    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(192), 0, s, a.partials, nb, d_out48);
+    return hipGetLastError();
+}
+
+}  // namespace pcr

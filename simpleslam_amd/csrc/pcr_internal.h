@@ -169,6 +169,33 @@ hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_sr
                           double* d_partials, double* d_out32, hipStream_t s);
 uint32_t vgicp_blocks(uint32_t n_src);
 
+// ---------------------------------------------------------------------------
+// NDT (ndt.hip)
+// ---------------------------------------------------------------------------
+struct NdtVoxel {            // VoxelGridCovariance::Leaf (pclomp/voxel_grid_covariance_omp.h:98-193): mean_, icov_
+    double mean[3];
+    double icov[9];          // row-major
+    int32_t n, pad;
+};
+struct NdtPose { float R[9]; float t[3]; };              // final_transformation_ (Matrix4f), row-major R
+struct NdtAngles {           // computeAngleDerivatives (ndt_omp_impl.hpp:289-395)
+    float j[8][3], h[15][3];         // float tables j_ang / h_ang
+    double jd[8][3], hd[15][3];      // double vectors j_ang_a_.. / h_ang_a2_..
+};
+struct NdtArgs {
+    const float* src; uint32_t n_src, src_stride;
+    const GridHeader* hdr;
+    const uint32_t* vox_slot;
+    const NdtVoxel* vox;
+    double d1, d2;           // gauss_d1_, gauss_d2_ (ndt_omp_impl.hpp:86-93)
+    double* partials;        // [blocks][48]
+};
+hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, int min_points, double eig_mult,
+                             hipStream_t s);
+hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s);
+hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s);
+uint32_t ndt_blocks(uint32_t n_src);
+
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s);
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s);
 hipError_t loam_launch_reduce(const LoamArgs& a, int k, double* d_out, hipStream_t s);

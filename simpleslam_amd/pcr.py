@@ -48,7 +48,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace",
-    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
 ]
 
 _lib = None
@@ -85,6 +85,7 @@ def load_library():
     L.pcr_get_trace.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, vp, vp]
     L.pcr_vgicp_covariances.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.pcr_vgicp_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int64)]
+    L.pcr_ndt_derivatives.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, dp]
     L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
     L.pcr_set_profile.argtypes = [vp, C.c_int]
     L.pcr_set_stream.argtypes = [vp, vp]
@@ -264,6 +265,21 @@ class LoamRegister(PointCloudRegister):
 class NdtRegister(PointCloudRegister):
     """PCR::NdtRegister (reference PCR/src/NdtRegister.cpp)."""
     method = "ndt"
+
+    def derivatives(self, src, p6, double_hessian=False):
+        """One computeDerivatives pass at p = [t; roll pitch yaw] against the current target."""
+        p, n, s, dev, _k = _cloud(src)
+        p6 = np.ascontiguousarray(p6, np.float64).reshape(6)
+        g, H = np.zeros(6), np.zeros(36)
+        Hd = np.zeros(36) if double_hessian else None
+        sc = C.c_double(0)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.pcr_ndt_derivatives(self._h, p, n, s, dev, p6.ctypes.data_as(dp), C.byref(sc), g.ctypes.data_as(dp),
+                                                  H.ctypes.data_as(dp), Hd.ctypes.data_as(dp) if Hd is not None else None))
+        out = dict(score=sc.value, grad=g, hess=H.reshape(6, 6))
+        if double_hessian:
+            out["hess_d"] = Hd.reshape(6, 6)
+        return out
 
 
 class VgicpRegister(PointCloudRegister):

@@ -66,14 +66,15 @@ def _lattice(u0, u1, v0, v1, s, rng):
     return u, v
 
 
-def make_map(n_points, seed=0, noise=0.01):
-    """Map of exactly n_points surface samples at ~0.5 m spacing (the reference's
-    sub-map is voxel-filtered at downSampleVoxelGridSize = 0.5, config/params.json:8)."""
+def make_map(n_points, seed=0, noise=0.01, spacing=0.5):
+    """Map of exactly n_points surface samples at ~`spacing` m (0.5: the reference's sub-map is
+    voxel-filtered at downSampleVoxelGridSize = 0.5, config/params.json:8; NDT wants a denser map --
+    "use ndt maybe no need to downsample", config/params.json:7 -- so its tests pass 0.2)."""
     rng = np.random.default_rng(seed)
-    blocks = max(1, int(round(np.sqrt(n_points / _surface_count(1, 0.5)))))
-    while _surface_count(blocks, 0.5) < n_points * 0.75:
+    blocks = max(1, int(round(np.sqrt(n_points / _surface_count(1, spacing)))))
+    while _surface_count(blocks, spacing) < n_points * 0.75:
         blocks += 1
-    s = 0.5 * np.sqrt(_surface_count(blocks, 0.5) / (1.04 * n_points))
+    s = spacing * np.sqrt(_surface_count(blocks, spacing) / (1.04 * n_points))
     side = blocks * PITCH
     boxes = _world(blocks)
     parts = []
