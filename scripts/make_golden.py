@@ -52,3 +52,27 @@ if oracle.ref_available() or os.path.exists("/root/reference"):
     print("knn_nanoflann:", pts4.shape, q4.shape)
 else:
     print("reference absent and oracle/_ref not built: knn_nanoflann.npz not regenerated")
+
+# ---- VGICP and NDT known-answer fixtures (oracle outputs on small synthetic inputs) ----------
+world, m = synth.make_map(20000, seed=12)
+scan, T = synth.make_scan(world, 0, seed=12, beams=8, azimuths=256)
+T0 = synth.perturb(T, 12, trans=0.2, rot_deg=1.5)
+sc, dc = oracle.vgicp_covariances(scan, 20), oracle.vgicp_covariances(m, 20)
+lin = oracle.vgicp_linearize(scan, m, T0, sc, dc)
+pose, conv, info = oracle.vgicp_scan2map(scan, m, T0)
+np.savez_compressed(os.path.join(out, "vgicp_small.npz"), map=m, scan=scan, truth=T, init=T0, src_cov=sc[::16], H=lin["H"], b=lin["b"],
+                    err=lin["err"], n_corr=lin["n"], pose=pose, converged=conv, outer=info["outer"],
+                    fitness=oracle.fitness_score(scan, m, pose))
+print("vgicp_small:", conv, info, synth.pose_error(pose, T))
+
+world, m = synth.make_map(40000, seed=13, spacing=0.2)
+scan, T = synth.make_scan(world, 0, seed=13, beams=8, azimuths=256)
+T0 = synth.perturb(T, 13, trans=0.08, rot_deg=0.4)
+from scipy.spatial.transform import Rotation as Rot
+p6 = np.concatenate([T0[:3, 3], Rot.from_matrix(T0[:3, :3]).as_euler("XYZ")])
+d = oracle.ndt_derivatives(scan, m, p6, double_hessian=True)
+pose, conv, info = oracle.ndt_scan2map(scan, m, T0)
+assert np.isfinite(pose).all()
+np.savez_compressed(os.path.join(out, "ndt_small.npz"), map=m, scan=scan, truth=T, init=T0, p6=p6, score=d["score"], grad=d["grad"],
+                    hess=d["hess"], hess_d=d["hess_d"], pose=pose, converged=conv, iterations=info["iterations"])
+print("ndt_small:", conv, info, synth.pose_error(pose, T), synth.pose_error(T0, T))

@@ -1,0 +1,122 @@
+// PCR/HipRegister.hpp -- header-only C++ mirror of the reference's registration plugin over the
+// C ABI of libpcr_hip.so (include/pcr_hip.h).  No PCL, no Eigen: the cloud and pose types below have
+// the memory layout of the reference's (pcl::PointXYZI = 32 bytes, Eigen::Isometry3d = 16 doubles
+// column-major), so an adapter for a tree that has PCL+Eigen only forwards pointers.
+//
+// Mirrors (reference): PCR/include/PCR/PointCloudRegister.hpp:12-38, LoamRegister.hpp, NdtRegister.hpp,
+// VgicpRegister.hpp; the factory of frontend/src/LidarOdometry.cpp:44-54.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/pcr_hip.h"
+
+namespace PCR {
+
+using scalar_t = double;                       // common/types/basic.hpp:16
+
+struct alignas(16) PointXYZI {                 // pcl::PointXYZI: x y z 1 | intensity pad pad pad
+    float x = 0, y = 0, z = 0, w = 1.f;
+    float intensity = 0, pad[3] = {0, 0, 0};
+};
+static_assert(sizeof(PointXYZI) == 32, "must match pcl::PointXYZI");
+
+struct PointCloud {
+    std::vector<PointXYZI> points;
+    size_t size() const { return points.size(); }
+};
+using PC_Ptr = std::shared_ptr<PointCloud>;
+using PC_cPtr = std::shared_ptr<const PointCloud>;
+
+struct pose_t {                                // Eigen::Isometry3d: 4x4 column-major
+    double m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double* data() { return m; }
+    const double* data() const { return m; }
+    double& operator()(int r, int c) { return m[c * 4 + r]; }
+    double operator()(int r, int c) const { return m[c * 4 + r]; }
+};
+
+class PointCloudRegister {
+protected:
+    bool isConverge = false;
+    int cores = 1;                             // cfg["cores"]: OpenMP team of the CPU reference; unused on the GPU
+public:
+    using Ptr = std::shared_ptr<PointCloudRegister>;
+    virtual scalar_t getFitnessScore() { return 0; }
+    virtual bool scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res) = 0;
+    virtual ~PointCloudRegister() {}
+};
+
+// Common implementation: one pcr_handle per registrar (own HIP stream and buffers, so the odometry and the
+// loop-closure registrars of the reference can run on their own threads concurrently).
+class HipRegister : public PointCloudRegister {
+protected:
+    pcr_handle* h_ = nullptr;
+    explicit HipRegister(const char* method, const pcr_params* p = nullptr) {
+        h_ = pcr_create(method, p);
+        if (!h_) throw std::runtime_error(pcr_last_error(nullptr));
+    }
+public:
+    HipRegister(const HipRegister&) = delete;
+    HipRegister& operator=(const HipRegister&) = delete;
+    ~HipRegister() override { pcr_destroy(h_); }
+
+    bool scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res) override {
+        int conv = 0;
+        if (pcr_scan2map(h_, src->points.data(), src->size(), dst->points.data(), dst->size(), sizeof(PointXYZI), res.data(), &conv))
+            throw std::runtime_error(pcr_last_error(h_));
+        isConverge = conv != 0;
+        return isConverge;
+    }
+    // static-map localisation (test/loc.cpp): index the map once
+    void setTarget(const PC_cPtr& dst) {
+        if (pcr_set_target(h_, dst->points.data(), dst->size(), sizeof(PointXYZI), 0)) throw std::runtime_error(pcr_last_error(h_));
+    }
+    bool align(const PC_cPtr& src, pose_t& res) {
+        int conv = 0;
+        if (pcr_align(h_, src->points.data(), src->size(), sizeof(PointXYZI), 0, res.data(), &conv)) throw std::runtime_error(pcr_last_error(h_));
+        isConverge = conv != 0;
+        return isConverge;
+    }
+    pcr_handle* handle() { return h_; }
+};
+
+class LoamRegister : public HipRegister {
+public:
+    LoamRegister() : HipRegister("loam") {}
+    explicit LoamRegister(const pcr_params& p) : HipRegister("loam", &p) {}
+};
+
+class NdtRegister : public HipRegister {
+public:
+    NdtRegister() : HipRegister("ndt") {}
+    explicit NdtRegister(const pcr_params& p) : HipRegister("ndt", &p) {}
+};
+
+class VgicpRegister : public HipRegister {
+    static pcr_params lc_params() {            // VgicpRegister::initForLC (VgicpRegister.cpp:21-28)
+        pcr_params p;
+        pcr_default_params(&p);
+        p.vgicp_max_iters = 100;
+        p.vgicp_trans_eps = 1e-6;
+        return p;
+    }
+public:
+    VgicpRegister() : HipRegister("vgicp") {}
+    explicit VgicpRegister(const pcr_params& p) : HipRegister("vgicp", &p) {}
+    // the reference reconfigures an existing object; handles here are configured at creation
+    static std::shared_ptr<VgicpRegister> makeForLC() { return std::make_shared<VgicpRegister>(lc_params()); }
+    scalar_t getFitnessScore() override { return pcr_fitness(h_); }
+};
+
+// frontend/src/LidarOdometry.cpp:44-54
+inline PointCloudRegister::Ptr makeRegister(const std::string& pcr_type) {
+    if (pcr_type == "loam") return std::make_shared<LoamRegister>();
+    if (pcr_type == "ndt") return std::make_shared<NdtRegister>();
+    if (pcr_type == "vgicp") return std::make_shared<VgicpRegister>();
+    throw std::runtime_error("such pcr type(" + pcr_type + ") is not exist, please implemented your self!");
+}
+
+}  // namespace PCR

@@ -1,0 +1,45 @@
+// loc_harness.cpp -- ROS-free counterpart of one pass of the reference's test/loc.cpp +
+// LidarOdometry::generateOdom (frontend/src/LidarOdometry.cpp:170-184): load a map and a scan
+// (raw float32 x y z intensity records), read the initial pose, call scan2Map through the C++ mirror
+// of the plugin interface, print the refined pose.
+//   loc_harness <method> <map.f32> <scan.f32> <init_pose.txt (4x4 row-major, test/align.cpp:85-93)>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+
+#include "PCR/HipRegister.hpp"
+
+static PCR::PC_Ptr load(const char* path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    auto pc = std::make_shared<PCR::PointCloud>();
+    float r[4];
+    while (f.read(reinterpret_cast<char*>(r), sizeof r)) {
+        PCR::PointXYZI p;
+        p.x = r[0]; p.y = r[1]; p.z = r[2]; p.intensity = r[3];
+        pc->points.push_back(p);
+    }
+    return pc;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 5) { std::fprintf(stderr, "usage: %s <loam|ndt|vgicp> <map.f32> <scan.f32> <init_pose.txt>\n", argv[0]); return 2; }
+    try {
+        auto reg = PCR::makeRegister(argv[1]);
+        auto map = load(argv[2]);
+        auto scan = load(argv[3]);
+        PCR::pose_t pose;
+        std::ifstream pf(argv[4]);
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (!(pf >> pose(r, c))) throw std::runtime_error("bad pose file");
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool conv = reg->scan2Map(scan, map, pose);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("method %s  map %zu  scan %zu  converged %d  scan2map %.6f s  fitness %.6f\n", argv[1], map->size(), scan->size(), (int)conv, sec,
+                    reg->getFitnessScore());
+        for (int r = 0; r < 4; ++r) std::printf("%.17g %.17g %.17g %.17g\n", pose(r, 0), pose(r, 1), pose(r, 2), pose(r, 3));
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

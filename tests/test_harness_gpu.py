@@ -1,0 +1,32 @@
+"""The ROS-free C++ harness (counterpart of the reference's test/loc.cpp pass) over the header-only
+mirror of the plugin interface: same answer as the Python host mirror, through the same C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from simpleslam_amd import LoamRegister
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_harness_matches_python(gpu, world_small, tmp_path):
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    assert os.path.exists(exe), "loc_harness not built (run __graft_entry__.build())"
+    w = world_small
+    w["map"].astype(np.float32).tofile(tmp_path / "map.f32")
+    w["scan"].astype(np.float32).tofile(tmp_path / "scan.f32")
+    np.savetxt(tmp_path / "init.txt", w["init"], fmt="%.17g")
+    out = subprocess.run([exe, "loam", str(tmp_path / "map.f32"), str(tmp_path / "scan.f32"), str(tmp_path / "init.txt")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    pose_cpp = np.array([[float(v) for v in ln.split()] for ln in lines[-4:]])
+    pose_py = w["init"].copy()
+    conv = LoamRegister().scan2Map(w["scan"], w["map"], pose_py)
+    assert f"converged {int(conv)}" in lines[0]
+    np.testing.assert_array_equal(pose_cpp, pose_py)
+    bad = subprocess.run([exe, "icp", "a", "b", "c"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "is not exist" in bad.stderr

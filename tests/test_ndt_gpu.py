@@ -67,3 +67,19 @@ def test_static_target_reuse(gpu, nd_world):
     c2 = reg.align(w["scan"], p2)
     assert c1 == c2
     np.testing.assert_array_equal(p1, p2)
+
+
+def test_golden_fixture(gpu):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ndt_small.npz"))
+    reg = NdtRegister()
+    reg.setTarget(g["map"])
+    d = reg.derivatives(g["scan"], g["p6"], double_hessian=True)
+    assert abs(d["score"] - float(g["score"])) <= 2e-5 * abs(float(g["score"]))
+    assert np.abs(d["grad"] - g["grad"]).max() <= 2e-5 * np.abs(g["grad"]).max()
+    assert np.abs(d["hess_d"] - g["hess_d"]).max() <= 1e-8 * np.abs(g["hess_d"]).max()
+    pose = g["init"].copy()
+    conv = reg.scan2Map(g["scan"], g["map"], pose)
+    assert conv == bool(g["converged"]) and reg.stats()["iterations"] == int(g["iterations"])
+    dt, dr = synth.pose_error(pose, g["pose"])
+    assert dt <= 1e-4 and dr <= 1e-4

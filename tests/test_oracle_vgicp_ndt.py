@@ -1,0 +1,168 @@
+"""CPU tests (no GPU): the VGICP and NDT restatements against numpy transcriptions and the committed
+golden vectors (tests/golden/{vgicp,ndt}_small.npz, scripts/make_golden.py)."""
+import os
+
+import numpy as np
+from scipy.spatial.transform import Rotation as Rot
+
+import oracle
+from simpleslam_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_sym3_eig_matches_numpy():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        B = rng.normal(size=(3, 3)) * rng.uniform(1e-3, 10)
+        A = B @ B.T
+        w, V = oracle.sym3_eig(A)
+        wn = np.linalg.eigvalsh(A)[::-1]
+        np.testing.assert_allclose(w, wn, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(V @ np.diag(w) @ V.T, A, rtol=1e-10, atol=1e-13)
+
+
+def test_svd6_solve_matches_numpy():
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        A = rng.normal(size=(6, 6)); A = A + A.T          # symmetric indefinite, like an NDT Hessian
+        b = rng.normal(size=6)
+        x = np.linalg.solve(A, b)
+        np.testing.assert_allclose(oracle.svd6_solve(A, b), x, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(x).max()))
+    # rank deficient -> pseudo-inverse (minimum-norm) solution, as JacobiSVD::solve
+    A = np.diag([3.0, 2.0, 1.0, 0.0, 0.0, 0.0]); b = np.arange(1.0, 7.0)
+    np.testing.assert_allclose(oracle.svd6_solve(A, b), np.linalg.pinv(A) @ b, atol=1e-12)
+
+
+def test_vgicp_covariances_match_numpy_svd():
+    rng = np.random.default_rng(2)
+    pts = np.concatenate([rng.uniform(-5, 5, (3000, 2)), rng.normal(0, 0.02, (3000, 1))], 1).astype(np.float32)   # a noisy plane
+    pts4 = np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], 1)
+    covs = oracle.vgicp_covariances(pts4, 20)
+    idx, d2 = oracle.knn_f32(pts4, pts4[:50, :3], 20)
+    assert (idx[:, 0] == np.arange(50)).all() and (d2[:, 0] == 0).all()      # a point is its own nearest neighbour
+    for i in range(50):
+        nb = pts[idx[i]].astype(np.float64)
+        nb = nb - nb.mean(0)
+        U, S, Vt = np.linalg.svd(nb.T @ nb / 20)
+        np.testing.assert_allclose(covs[i], U @ np.diag([1, 1, 1e-3]) @ Vt, atol=1e-9)
+    # the plane's normal is the 1e-3 direction
+    w, V = np.linalg.eigh(covs[0])
+    assert abs(V[2, 0]) > 0.99 and abs(w[0] - 1e-3) < 1e-9
+
+
+def test_vgicp_voxels_and_linearize_match_numpy():
+    g = np.load(os.path.join(GOLD, "vgicp_small.npz"))
+    m, scan, T0 = g["map"], g["scan"], g["init"]
+    sc, dc = oracle.vgicp_covariances(scan, 20), oracle.vgicp_covariances(m, 20)
+    np.testing.assert_allclose(sc[::16], g["src_cov"], atol=1e-12)
+    # voxel of some map point: ADDITIVE mean of points / covariances with coord floor(x/res - 0.5)
+    coord = np.floor(m[:, :3].astype(np.float64) / 1.0 - 0.5).astype(int)
+    for i in (0, 777, 5000):
+        same = (coord == coord[i]).all(1)
+        n, mean, cov = oracle.vgicp_voxel_at(m, dc, 1.0, m[i, :3].astype(np.float64))
+        assert n == same.sum()
+        np.testing.assert_allclose(mean, m[same, :3].astype(np.float64).mean(0), rtol=1e-12)
+        np.testing.assert_allclose(cov, dc[same].mean(0), rtol=1e-12, atol=1e-15)
+    # linearisation against a direct numpy transcription of fast_vgicp_impl.hpp:73-180
+    lin = oracle.vgicp_linearize(scan, m, T0, sc, dc)
+    H, b, err, nc = np.zeros((6, 6)), np.zeros(6), 0.0, 0
+    vox = {}
+    for i, c in enumerate(map(tuple, coord)):
+        vox.setdefault(c, []).append(i)
+    R, t = T0[:3, :3], T0[:3, 3]
+    for i in range(scan.shape[0]):
+        tp = R @ scan[i, :3].astype(np.float64) + t
+        c = tuple(np.floor(tp / 1.0 - 0.5).astype(int))
+        if c not in vox:
+            continue
+        ids = vox[c]
+        mean, CB = m[ids, :3].astype(np.float64).mean(0), dc[ids].mean(0)
+        M = np.linalg.inv(CB + R @ sc[i] @ R.T)
+        e = mean - tp
+        w = np.sqrt(len(ids))
+        S = np.array([[0, -tp[2], tp[1]], [tp[2], 0, -tp[0]], [-tp[1], tp[0], 0]])
+        J = np.concatenate([S, -np.eye(3)], 1)
+        H += w * J.T @ M @ J; b += w * J.T @ M @ e; err += w * e @ M @ e; nc += 1
+    assert nc == lin["n"] == int(g["n_corr"])
+    np.testing.assert_allclose(lin["H"], H, rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(lin["b"], b, rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(lin["err"], err, rtol=1e-10)
+    np.testing.assert_allclose(lin["H"], g["H"], rtol=1e-12, atol=1e-9)
+
+
+def test_vgicp_golden_end_to_end():
+    g = np.load(os.path.join(GOLD, "vgicp_small.npz"))
+    pose, conv, info = oracle.vgicp_scan2map(g["scan"], g["map"], g["init"])
+    assert conv == bool(g["converged"]) and info["outer"] == int(g["outer"])
+    np.testing.assert_array_equal(pose, g["pose"])
+    np.testing.assert_array_equal(pose, pose.astype(np.float32).astype(np.float64))      # Matrix4f result
+    dt, dr = synth.pose_error(pose, g["truth"])
+    assert dt < 0.03 and dr < 3e-3
+    np.testing.assert_allclose(oracle.fitness_score(g["scan"], g["map"], pose), float(g["fitness"]), rtol=1e-12)
+
+
+def test_ndt_leaf_matches_numpy():
+    g = np.load(os.path.join(GOLD, "ndt_small.npz"))
+    m = g["map"]
+    cell = np.floor(m[:, :3]).astype(int)
+    checked = infl = 0
+    for i in range(0, m.shape[0], 997):
+        same = (cell == cell[i]).all(1)
+        n, mean, cov, icov = oracle.ndt_leaf_at(m, m[i, :3])
+        assert abs(n) == same.sum() or n == -1
+        if same.sum() < 6 or n < 0:
+            continue
+        X = m[same, :3].astype(np.float64)
+        np.testing.assert_allclose(mean, X.mean(0), rtol=1e-12)
+        C = np.cov(X.T, bias=True) * (n - 1.0) / n                      # voxel_grid_covariance_omp_impl.hpp:329-330
+        w, V = np.linalg.eigh(C)
+        if w[0] < 0.01 * w[2]:                                          # eigenvalue inflation, :345-356
+            w = np.maximum(w, 0.01 * w[2]); C = V @ np.diag(w) @ V.T; infl += 1
+        np.testing.assert_allclose(cov, C, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(icov @ cov, np.eye(3), atol=1e-8)
+        checked += 1
+    assert checked > 10 and infl > 0
+
+
+def test_ndt_gradient_is_the_derivative_of_the_score():
+    g = np.load(os.path.join(GOLD, "ndt_small.npz"))
+    d = oracle.ndt_derivatives(g["scan"], g["map"], g["p6"], double_hessian=True)
+    np.testing.assert_allclose(d["score"], float(g["score"]), rtol=1e-12)
+    np.testing.assert_allclose(d["grad"], g["grad"], rtol=1e-12)
+    np.testing.assert_allclose(d["hess"], g["hess"], rtol=1e-12)
+    num = np.zeros(6)
+    for i in range(6):
+        h = 2e-3 if i < 3 else 2e-4
+        pp, pm = g["p6"].copy(), g["p6"].copy()
+        pp[i] += h; pm[i] -= h
+        num[i] = (oracle.ndt_derivatives(g["scan"], g["map"], pp)["score"] - oracle.ndt_derivatives(g["scan"], g["map"], pm)["score"]) / (2 * h)
+    # voxel membership changes make the score only piecewise smooth (2048 points): the analytic gradient
+    # must still point the way the finite differences do
+    cos = num @ d["grad"] / (np.linalg.norm(num) * np.linalg.norm(d["grad"]))
+    assert cos > 0.9, (cos, num, d["grad"])
+    # float and double Hessians differ only by float rounding and the documented d1 sign quirk
+    assert np.abs(d["hess"] - d["hess_d"]).max() < 1e-3 * np.abs(d["hess_d"]).max()
+
+
+def test_ndt_golden_end_to_end():
+    g = np.load(os.path.join(GOLD, "ndt_small.npz"))
+    pose, conv, info = oracle.ndt_scan2map(g["scan"], g["map"], g["init"])
+    assert conv == bool(g["converged"]) and info["iterations"] == int(g["iterations"])
+    np.testing.assert_array_equal(pose, g["pose"])
+    R = pose[:3, :3]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-6
+
+
+def test_euler_parameterisation_roundtrip():
+    """p = [t; eulerAngles(0,1,2)] and Translation*Rx*Ry*Rz are inverse to each other (ndt_omp_impl.hpp:103-111,146-149)."""
+    T = np.eye(4)
+    T[:3, :3] = Rot.from_euler("XYZ", [0.01, -0.02, 2.5]).as_matrix()
+    T[:3, 3] = [1, 2, 3]
+    p6 = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_euler("XYZ")])
+    world, m = synth.make_map(3000, seed=1)
+    # zero iterations are not expressible; instead check derivative evaluation is invariant to the equivalent triple
+    alt = p6.copy(); alt[3] += np.pi; alt[4] = np.pi - alt[4]; alt[5] += np.pi
+    a = oracle.ndt_derivatives(m[:500], m, p6)["score"]
+    b = oracle.ndt_derivatives(m[:500], m, alt)["score"]
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)

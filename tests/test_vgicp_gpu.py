@@ -82,3 +82,21 @@ def test_static_target_reuse(gpu, vg_world):
     c2 = reg.align(w["scan"], p2)
     assert c1 == c2
     np.testing.assert_array_equal(p1, p2)
+
+
+def test_golden_fixture(gpu):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgicp_small.npz"))
+    reg = VgicpRegister()
+    np.testing.assert_allclose(reg.covariances(g["scan"])[::16], g["src_cov"], atol=1e-9)
+    reg.setTarget(g["map"])
+    lin = reg.linearize(g["scan"], g["init"])
+    assert lin["n"] == int(g["n_corr"])
+    np.testing.assert_allclose(lin["H"], g["H"], rtol=1e-7, atol=1e-6)
+    np.testing.assert_allclose(lin["err"], float(g["err"]), rtol=1e-8)
+    pose = g["init"].copy()
+    conv = reg.scan2Map(g["scan"], g["map"], pose)
+    assert conv == bool(g["converged"]) and reg.stats()["iterations"] == int(g["outer"])
+    dt, dr = synth.pose_error(pose, g["pose"])
+    assert dt <= 1e-4 and dr <= 1e-4
+    np.testing.assert_allclose(reg.getFitnessScore(), float(g["fitness"]), rtol=1e-5)
