@@ -127,6 +127,9 @@ int pcr_loam_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stri
 /* Per-iteration trace of the last LOAM call (params.record_trace = 1):
  * for it < *n_iters: JtJ[it*36..], JtE[it*6..], n[it], x[it*6..]. Arrays sized for loam_iters. */
 int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int64_t* n, double* x);
+/* Per linearisation of the last traced LOAM call: scan points whose neighbours came from the temporal
+ * neighbour cache (proven exact) and points that needed a full grid search. */
+int pcr_get_trace_counts(pcr_handle* h, int64_t* cache_hits, int64_t* searches);
 
 /* VGICP introspection.  Per-point covariances as fast_gicp::FastGICP::calculate_covariances forms
  * them (fast_gicp_impl.hpp:241-297; 20-NN, PLANE regularisation): cov_out[n*6] = xx xy xz yy yz zz. */

@@ -12,6 +12,7 @@ def run(mask, label, nosort=0):
     p = default_params(loam_iters=10, loam_early_exit=0)
     p.reserved[0] = mask
     p.reserved[1] = nosort
+    p.reserved[2] = 1   # temporal cache off: every iteration is a full search
     reg = LoamRegister(params=p)
     reg.setTarget(dm)
     reg.set_profile(2)
@@ -22,10 +23,7 @@ def run(mask, label, nosort=0):
         pose = T0.copy(); reg.align(ds, pose); st = reg.stats(); ks.append(st['kernel_ms'] / max(1, st['kernel_launches']))
     print(f"{label:40s} mask={mask} iterate kernel avg {1e3*np.median(ks):8.2f} us  solve_ms {st['solve_ms']:.3f}")
 run(0, 'full')
-run(0, 'full, cell-sorted scan', 1)
-run(2 | 4, 'kNN only, no prologue, sorted', 1)
-run(4, 'no prologue solve')
-run(1, 'no candidate loop (=> no QR)')
-run(2, 'kNN only (no QR)')
-run(1 | 4, 'no loop, no prologue')
 run(2 | 4, 'kNN only, no prologue')
+run(2 | 4 | 32, 'kNN: loads + distances, no insert')
+run(2 | 4 | 16, 'kNN: loads only')
+run(1 | 4, 'no candidate loop')

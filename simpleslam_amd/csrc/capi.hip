@@ -147,11 +147,7 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
     a->trace = h->prm.record_trace ? h->loam_trace.as<LoamTrace>() : nullptr;
     a->result = h->result_dev;
     a->ablate = h->prm.reserved[0];
-    if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 32) == hipSuccess &&
-        h->q_cache.reserve((n_src + 1) * sizeof(float4)) == hipSuccess) {
-        a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
-        a->q_cache = h->q_cache.as<float4>();
-    }
+    if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 128) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
     a->use_tile = h->use_tile;
     for (int d = 0; d < 3; ++d) { a->tile_lo[d] = h->tile_lo[d]; a->tile_hi[d] = h->tile_hi[d]; }
 }
@@ -1034,6 +1030,16 @@ int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int
         if (JtE) memcpy(JtE + i * 6, t.JtE, sizeof(t.JtE));
         if (x) memcpy(x + i * 6, t.x, sizeof(t.x));
         if (n) n[i] = t.n;
+    }
+    return 0;
+}
+
+int pcr_get_trace_counts(pcr_handle* h, int64_t* cache_hits, int64_t* searches) {
+    if (!h) return 1;
+    if (!h->prm.record_trace) return fail(h, "trace not recorded: set pcr_params.record_trace");
+    for (int i = 0; i < h->trace_iters && i < (int)h->trace_host.size(); ++i) {
+        if (cache_hits) cache_hits[i] = h->trace_host[i].cache_hits;
+        if (searches) searches[i] = h->trace_host[i].searches;
     }
     return 0;
 }

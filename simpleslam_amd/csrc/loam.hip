@@ -28,8 +28,8 @@ namespace pcr {
 // ------------------------------------------------------------------------------
 struct Knn5 {
     double d[5];
-    uint32_t idx[5];   // original target index: the tie-break key
-    uint32_t pos[5];   // position in the cell-sorted array
+    uint32_t idx[5];   // original target index (filled once the search is over)
+    uint32_t pos[5];   // position in the cell-sorted array; 0xffffffff = empty slot (sentinel)
 };
 
 // (d, idx) lexicographic order, branch-free: distance ties are broken on the original index
@@ -37,17 +37,20 @@ __device__ __forceinline__ bool knn_less(double d, uint32_t i, double d2, uint32
     return (d < d2) | ((d == d2) & (i < i2));
 }
 
-__device__ __forceinline__ void knn_insert(Knn5& s, double d, uint32_t idx, uint32_t pos) {
-    // caller guarantees (d,idx) < slot 4; straight-line sorted insert, selects only
-    const bool c3 = knn_less(d, idx, s.d[3], s.idx[3]);
-    const bool c2 = knn_less(d, idx, s.d[2], s.idx[2]);
-    const bool c1 = knn_less(d, idx, s.d[1], s.idx[1]);
-    const bool c0 = knn_less(d, idx, s.d[0], s.idx[0]);
-    s.d[4] = c3 ? s.d[3] : d;   s.idx[4] = c3 ? s.idx[3] : idx;   s.pos[4] = c3 ? s.pos[3] : pos;
-    s.d[3] = c3 ? (c2 ? s.d[2] : d) : s.d[3];   s.idx[3] = c3 ? (c2 ? s.idx[2] : idx) : s.idx[3];   s.pos[3] = c3 ? (c2 ? s.pos[2] : pos) : s.pos[3];
-    s.d[2] = c2 ? (c1 ? s.d[1] : d) : s.d[2];   s.idx[2] = c2 ? (c1 ? s.idx[1] : idx) : s.idx[2];   s.pos[2] = c2 ? (c1 ? s.pos[1] : pos) : s.pos[2];
-    s.d[1] = c1 ? (c0 ? s.d[0] : d) : s.d[1];   s.idx[1] = c1 ? (c0 ? s.idx[0] : idx) : s.idx[1];   s.pos[1] = c1 ? (c0 ? s.pos[0] : pos) : s.pos[1];
-    s.d[0] = c0 ? d : s.d[0];   s.idx[0] = c0 ? idx : s.idx[0];   s.pos[0] = c0 ? pos : s.pos[0];
+// Hot-path insertion: a branch-free bubble pass through the sorted list, ordered by distance alone (one
+// v_min/v_max/v_cmp and two selects per slot).  The value that falls off the end -- the candidate itself when
+// it does not belong -- is returned: it bounds the "6th neighbour" from below.  Exact distance ties, which
+// need the original-index tie-break, are detected after the search and redone by knn5_resolve_ties.
+// (Written as min/max dataflow on purpose: hipcc turns nested ?: chains here into ~16 divergent branches.)
+__device__ __forceinline__ void knn_bubble(Knn5& s, double& t, uint32_t& tpos) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const bool lt = t < s.d[k];
+        const double lo = fmin(s.d[k], t), hi = fmax(s.d[k], t);
+        const uint32_t plo = lt ? tpos : s.pos[k], phi = lt ? s.pos[k] : tpos;
+        s.d[k] = lo; s.pos[k] = plo;
+        t = hi; tpos = phi;
+    }
 }
 
 // Per-block LDS scratch of the search: the 9 row ranges of every lane.
@@ -66,6 +69,7 @@ struct KnnQuery {
     double qx, qy, qz;          // query (a float widened to double)
     double ylo, yhi, zlo, zhi;  // distance to the faces of the query's cell
     double l6;                  // lower bound of the squared distance of every point NOT in the top 5
+    int ablate;                 // profiling aid: bit4 skip candidates (loads only), bit5 skip insertion
 };
 
 __device__ __forceinline__ double row_bound(const KnnQuery& q, int r) {
@@ -79,17 +83,19 @@ __device__ __forceinline__ double row_bound(const KnnQuery& q, int r) {
 
 // One candidate.  No single-precision pre-screen: with 64 independent searches in lockstep some
 // lane nearly always needs the exact distance, so the screen would only add instructions.
-__device__ __forceinline__ void knn_consider(Knn5& s, KnnQuery& q, const float4 p, uint32_t pos) {
+__device__ __forceinline__ void knn_consider(Knn5& s, KnnQuery& q, const float4 p, uint32_t pos, bool valid) {
     const double dx = q.qx - (double)p.x, dy = q.qy - (double)p.y, dz = q.qz - (double)p.z;
     double d = dx * dx;      // nanoflann L2_Simple_Adaptor::evalMetric order (nanoflann.hpp:523-535)
     d += dy * dy;
     d += dz * dz;
-    const uint32_t idx = __float_as_uint(p.w);
-    const bool take = knn_less(d, idx, s.d[4], s.idx[4]);
-    // whatever leaves or never enters the top 5 bounds the "6th neighbour" from below
-    const double out = take ? s.d[4] : d;
-    q.l6 = out < q.l6 ? out : q.l6;
-    if (take) knn_insert(s, d, idx, pos);
+    // slots past the end of the run (and NaN distances) become +inf: the pass below is then a no-op
+    double t = (valid && d == d) ? d : __longlong_as_double(0x7ff0000000000000ll);
+    uint32_t tpos = pos;
+    if (q.ablate & 32) { q.l6 = t < q.l6 ? t : q.l6; return; }
+    knn_bubble(s, t, tpos);
+    // what fell off bounds the 6th neighbour (an evicted sentinel is not a point: it bounds nothing)
+    const double out = tpos == 0xffffffffu ? q.l6 : t;
+    q.l6 = fmin(q.l6, out);
 }
 
 struct KnnCursor { int r; uint32_t j, e; };
@@ -102,9 +108,38 @@ __device__ __forceinline__ bool knn_advance(KnnCursor& c, const KnnShared& sh, K
         c.j = sh.rs[c.r][tid];
         c.e = sh.re[c.r][tid];
         const double b = row_bound(q, c.r);
-        if (b > s.d[4]) { c.j = c.e; q.l6 = b < q.l6 ? b : q.l6; }   // skipped points are at least sqrt(b) away
+        // Skipping needs only b > d4.  The extra ~0.1 m of radius keeps the lower bound l6 of the "6th
+        // neighbour" (which a skipped row caps at b) ~0.05 m above the 5th distance so that the next
+        // iteration's temporal-coherence test to succeed once the pose update is small.
+        const float r4 = sqrtf((float)s.d[4]);
+        const double thresh = s.d[4] + (double)(0.1f * r4 + 0.0025f);   // (r + 0.05)^2 - r^2
+        if (b > thresh) { c.j = c.e; q.l6 = b < q.l6 ? b : q.l6; }   // skipped points are at least sqrt(b) away
     }
     return true;
+}
+
+// Rare path: exact distance ties.  Plain sequential scan of the 3x3x3 block with the full
+// (distance, original index) order; kept out of line so that it costs the hot path nothing.
+__device__ __noinline__ void knn5_resolve_ties(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                               double qx, double qy, double qz, double max_sq, Knn5& s) {
+    double d5[5]; uint32_t i5[5], p5[5];
+    for (int j = 0; j < 5; ++j) { d5[j] = max_sq; i5[j] = 0xffffffffu; p5[j] = 0xffffffffu; }
+    const int cx = (int)floor((qx - h.origin[0]) * h.inv_cell), cy = (int)floor((qy - h.origin[1]) * h.inv_cell),
+              cz = (int)floor((qz - h.origin[2]) * h.inv_cell);
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t key = ((uint32_t)(cz + r / 3 - 1) * (uint32_t)h.dims[1] + (uint32_t)(cy + r % 3 - 1)) * (uint32_t)h.dims[0] + (uint32_t)cx;
+        for (uint32_t j = cell_start[key - 1]; j < cell_start[key + 2]; ++j) {
+            const float4 p = pts[j];
+            const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+            double d = dx * dx; d += dy * dy; d += dz * dz;
+            const uint32_t idx = __float_as_uint(p.w);
+            if (!knn_less(d, idx, d5[4], i5[4])) continue;
+            int k = 4;
+            while (k > 0 && knn_less(d, idx, d5[k - 1], i5[k - 1])) { d5[k] = d5[k - 1]; i5[k] = i5[k - 1]; p5[k] = p5[k - 1]; --k; }
+            d5[k] = d; i5[k] = idx; p5[k] = j;
+        }
+    }
+    for (int j = 0; j < 5; ++j) { s.d[j] = d5[j]; s.idx[j] = i5[j]; s.pos[j] = p5[j]; }
 }
 
 static constexpr int kChunk = 8;   // candidates per lane per step (the sorted array is padded by kChunk)
@@ -118,11 +153,19 @@ static constexpr int kChunk = 8;   // candidates per lane per step (the sorted a
 // candidates stream in chunks of kChunk float4 loads with the next chunk already in flight.
 __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __restrict__ pts,
                                           const uint32_t* __restrict__ cell_start, double qx, double qy, double qz,
-                                          double max_sq, Knn5& s, KnnShared& sh, bool active, double* l6_out, bool keep) {
+                                          double max_sq, Knn5& s, KnnShared& sh, bool active, double* l6_out, bool keep,
+                                          double seed_bound, int ablate) {
     const int tid = threadIdx.x;
     if (!keep) {
+        // Empty slots are sentinels (index 0xffffffff) at an upper bound of the 5th distance: the gate
+        // radius, or -- when five real points are known to lie within seed_bound (the previous iteration's
+        // neighbours) -- that tighter radius, which lets the row bounds prune from the first row on.
+        // Every true neighbour has d <= bound and a smaller index than the sentinel, so it displaces one.
+        // (distance-only compares: a point exactly AT the seed radius must still enter, so the sentinels sit one
+        // ulp above it; at the gate radius itself entering or not is immaterial -- the gate d5 < max_sq fails)
+        const double b0 = seed_bound < max_sq ? __longlong_as_double(__double_as_longlong(seed_bound) + 1) : max_sq;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { s.d[j] = max_sq; s.idx[j] = 0xffffffffu; s.pos[j] = 0; }
+        for (int j = 0; j < 5; ++j) { s.d[j] = b0; s.idx[j] = 0xffffffffu; s.pos[j] = 0xffffffffu; }
     }
     // cell coordinates (exact: q is a float widened to double, origin a multiple of cell)
     const double rx = qx - h.origin[0], ry = qy - h.origin[1], rz = qz - h.origin[2];
@@ -149,6 +192,7 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
     q.ylo = ry - fy * h.cell; q.yhi = (fy + 1.0) * h.cell - ry;
     q.zlo = rz - fz * h.cell; q.zhi = (fz + 1.0) * h.cell - rz;
     q.l6 = max_sq;   // points outside the 3x3x3 block are >= one cell (>= sqrt(max_sq)) away
+    q.ablate = ablate;
     // (each lane reads back only what it wrote itself: no barrier needed)
     KnnCursor cur{-1, 0u, 0u};
     bool has = knn_advance(cur, sh, q, s, tid);
@@ -172,13 +216,29 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
         }
 #pragma unroll
         for (int i = 0; i < kChunk; ++i) {
-            if (cur.j + i < cur.e) knn_consider(s, q, c[i], cur.j + i);
+            if (q.ablate & 16) { q.l6 += (double)c[i].x; }
+            else knn_consider(s, q, c[i], cur.j + i, cur.j + i < cur.e);
         }
 #pragma unroll
         for (int i = 0; i < kChunk; ++i) c[i] = n[i];
         cur = nxt; has = has_n;
     }
     *l6_out = q.l6;
+    if (inside) {
+        // fill the original indices and detect exact distance ties (inside the list, or between its last
+        // entry and anything left out); those rare queries are redone with the index tie-break
+        bool tie = false;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) s.idx[j] = s.pos[j] == 0xffffffffu ? 0xffffffffu : __float_as_uint(pts[s.pos[j]].w);
+        if (s.pos[4] != 0xffffffffu) {
+            tie = (q.l6 == s.d[4]) | (s.d[0] == s.d[1]) | (s.d[1] == s.d[2]) | (s.d[2] == s.d[3]) | (s.d[3] == s.d[4]);
+        }
+        if (tie) {
+            Knn5 fixed;     // a separate object: only this rare path lives in scratch memory
+            knn5_resolve_ties(h, pts, cell_start, qx, qy, qz, max_sq, fixed);
+            s = fixed;
+        }
+    }
     return inside;
 }
 
@@ -191,47 +251,61 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
 // the 5 cached neighbours is strictly closer to q than that, the cached set IS the exact
 // 5-NN set of q and only its order has to be recomputed.  Otherwise the full search runs.
 // ------------------------------------------------------------------------------
-struct NnCacheEntry {          // 32 bytes
-    uint32_t pos[5];
-    float l6;                  // rounded down
-    uint32_t valid;
+struct NnCacheEntry {          // 128 bytes per scan point
+    float4 nb[5];              // the 5 neighbours in (distance, index) order: x y z | original index bits
+    double x[3];               // plane through them, A x = -1 (depends only on nb and their order)
+    float q0[3];               // query position the entry refers to
+    float l6;                  // lower bound (rounded down) of the squared distance from q0 to every OTHER target point
+    uint32_t flags;            // bit0: entry valid (5 real neighbours)  bit1: x valid  bit2: plane passed its validity gate
     uint32_t pad;
 };
+static_assert(sizeof(NnCacheEntry) == 128, "cache entry layout");
 
-__device__ __forceinline__ void knn_cswap(Knn5& s, int i, int j) {
-    const bool sw = knn_less(s.d[j], s.idx[j], s.d[i], s.idx[i]);
-    const double di = s.d[i], dj = s.d[j];
-    const uint32_t ii = s.idx[i], ij = s.idx[j], pi = s.pos[i], pj = s.pos[j];
-    s.d[i] = sw ? dj : di; s.d[j] = sw ? di : dj;
-    s.idx[i] = sw ? ij : ii; s.idx[j] = sw ? ii : ij;
-    s.pos[i] = sw ? pj : pi; s.pos[j] = sw ? pi : pj;
-}
-
-// returns true when the cached neighbours were proven to be the exact 5-NN of (qx,qy,qz)
-__device__ __forceinline__ bool knn5_from_cache(const float4* __restrict__ pts, const NnCacheEntry& ce, const float4 q0,
-                                                double qx, double qy, double qz, Knn5& s, float* l6_new) {
+// Distances from the new query to the cached neighbours; returns true when they are proven to be the exact
+// 5-NN (see above).  *ordered: they are still in (distance, index) order, so the cached plane is reusable bit for bit.
+__device__ __forceinline__ bool knn5_from_cache(const NnCacheEntry& ce, double qx, double qy, double qz, Knn5& s, double A[5][3],
+                                                float* l6_new, bool* ordered) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const float4 p = pts[ce.pos[j]];
-        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+        const float4 p = ce.nb[j];
+        A[j][0] = (double)p.x; A[j][1] = (double)p.y; A[j][2] = (double)p.z;
+        const double dx = qx - A[j][0], dy = qy - A[j][1], dz = qz - A[j][2];
         double d = dx * dx;
         d += dy * dy;
         d += dz * dz;
-        s.d[j] = d; s.idx[j] = __float_as_uint(p.w); s.pos[j] = ce.pos[j];
+        s.d[j] = d; s.idx[j] = __float_as_uint(p.w); s.pos[j] = (uint32_t)j;   // pos = slot in the entry
     }
-    // 9-comparator sorting network for 5 keys
-    knn_cswap(s, 0, 1); knn_cswap(s, 3, 4); knn_cswap(s, 2, 4); knn_cswap(s, 2, 3); knn_cswap(s, 0, 3);
-    knn_cswap(s, 0, 2); knn_cswap(s, 1, 4); knn_cswap(s, 1, 3); knn_cswap(s, 1, 2);
-    const float ex = (float)qx - q0.x, ey = (float)qy - q0.y, ez = (float)qz - q0.z;
+    bool ord = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ord = ord & !knn_less(s.d[j + 1], s.idx[j + 1], s.d[j], s.idx[j]);
+    *ordered = ord;
+    double r5sq = s.d[4];
+    if (!ord) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r5sq = fmax(r5sq, s.d[j]);
+    }
+    const float ex = (float)qx - ce.q0[0], ey = (float)qy - ce.q0[1], ez = (float)qz - ce.q0[2];
     // single precision with 1e-6 relative margins on every term (rounding is < 2e-7)
     const float delta = sqrtf(fmaf(ex, ex, fmaf(ey, ey, ez * ez))) * 1.000001f + 1e-7f;
-    const float r5 = sqrtf((float)s.d[4]) * 1.000001f;
+    const float r5 = sqrtf((float)r5sq) * 1.000001f;
     const float l6 = sqrtf(ce.l6) * 0.999999f;
     const float slack = l6 - delta;
     *l6_new = slack > 0.f ? slack * slack * 0.999999f : 0.f;
     return r5 < slack * 0.999999f;
 }
 
+// 9-comparator sorting network on (distance, index) with the neighbour coordinates as payload
+__device__ __forceinline__ void knn_sort5(Knn5& s, double A[5][3]) {
+#define CSWAP(i, j) { const bool sw = knn_less(s.d[j], s.idx[j], s.d[i], s.idx[i]); \
+        const double di = s.d[i], dj = s.d[j]; s.d[i] = sw ? dj : di; s.d[j] = sw ? di : dj; \
+        const uint32_t ii = s.idx[i], ij = s.idx[j]; s.idx[i] = sw ? ij : ii; s.idx[j] = sw ? ii : ij; \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) { const double ai = A[i][c], aj = A[j][c]; A[i][c] = sw ? aj : ai; A[j][c] = sw ? ai : aj; } }
+    CSWAP(0, 1) CSWAP(3, 4) CSWAP(2, 4) CSWAP(2, 3) CSWAP(0, 3) CSWAP(0, 2) CSWAP(1, 4) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+}
+
+// Rare path: exact distance ties.  Plain sequential scan of the 3x3x3 block with the full
+// (distance, original index) order; kept out of line so that it costs the hot path nothing.
 // ------------------------------------------------------------------------------
 // plane fit: Eigen::ColPivHouseholderQR<Matrix<double,5,3>>::solve(-1) restated
 // (LoamRegister.cpp:29-35), all indices static so everything stays in registers.
@@ -350,14 +424,106 @@ __device__ __forceinline__ void plane_qr_solve(double a[5][3], double x[3]) {
 }
 
 // ------------------------------------------------------------------------------
+// Wave-cooperative exact 5-NN of ONE query: lanes = candidates.  Used when only a handful of queries of a
+// block still need a search (late Gauss-Newton iterations): the per-lane search above is a chain of a dozen
+// dependent memory round trips whether 1 or 64 lanes are busy, this one is three (ranges, points, done).
+// Every candidate of the 3x3x3 block gets its exact (distance, index) key; a candidate's rank is the number
+// of smaller keys, counted against the wave's table in LDS -- no ordering between lanes is needed.
+// All 64 lanes call it with the same query.  tab: >= kWaveTab entries of this wave.  Returns false when the
+// block holds more candidates than the table (the caller then falls back to the per-lane search).
+// ------------------------------------------------------------------------------
+struct WaveCand { double d; uint32_t idx, pos; };
+static constexpr int kWaveTab = 280;     // 4 waves x (280 + 8 result slots) x 16 B = the 18 KB of KnnShared, which this path reuses
+
+__device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                          double qx, double qy, double qz, double max_sq, WaveCand* tab, Knn5& out, double* l6_out,
+                                          bool* inside_out) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { out.d[j] = max_sq; out.idx[j] = 0xffffffffu; out.pos[j] = 0xffffffffu; }
+    *l6_out = max_sq;
+    const double rx = qx - h.origin[0], ry = qy - h.origin[1], rz = qz - h.origin[2];
+    const double fx = floor(rx * h.inv_cell), fy = floor(ry * h.inv_cell), fz = floor(rz * h.inv_cell);
+    const bool inside = (fx >= 1.0 && fx <= (double)(h.dims[0] - 2) && fy >= 1.0 && fy <= (double)(h.dims[1] - 2) && fz >= 1.0 &&
+                         fz <= (double)(h.dims[2] - 2));
+    *inside_out = inside;
+    if (!inside) return true;
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    // lanes 0..8 fetch the 9 row ranges
+    uint32_t rs = 0, len = 0;
+    if (lane < 9) {
+        const uint32_t key = ((uint32_t)(cz + lane / 3 - 1) * (uint32_t)h.dims[1] + (uint32_t)(cy + lane % 3 - 1)) * (uint32_t)h.dims[0] + (uint32_t)cx;
+        rs = cell_start[key - 1];
+        len = cell_start[key + 2] - rs;
+    }
+    uint32_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const uint32_t total = __shfl(incl, 8, 64);
+    if (total > (uint32_t)kWaveTab) return false;
+    uint32_t r_start[9], r_excl[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { r_start[r] = __shfl(rs, r, 64); r_excl[r] = __shfl(incl - len, r, 64); }
+    // every lane computes the exact keys of its candidates
+    for (uint32_t c = lane; c < total; c += 64) {
+        uint32_t pos = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (c >= r_excl[r]) pos = r_start[r] + (c - r_excl[r]);
+        const float4 p = pts[pos];
+        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        WaveCand w; w.d = d; w.idx = __float_as_uint(p.w); w.pos = pos;
+        tab[c] = w;
+    }
+    // (same wave: its LDS operations complete in order, so the table is visible to the reads below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    for (uint32_t c = lane; c < total; c += 64) {
+        const WaveCand me = tab[c];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < total; ++j) {
+            const WaveCand o = tab[j];
+            rank += knn_less(o.d, o.idx, me.d, me.idx) ? 1u : 0u;
+        }
+        if (rank < 6) { tab[kWaveTab + rank] = me; }       // six result slots behind the table
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if ((uint32_t)j < total) { const WaveCand w = tab[kWaveTab + j]; out.d[j] = w.d; out.idx[j] = w.idx; out.pos[j] = w.pos; }
+    }
+    if (total > 5) *l6_out = fmin(max_sq, tab[kWaveTab + 5].d);
+    return true;
+}
+
+// Block-level compaction of the queries that need a full search.  After the first iterations most lanes
+// are served by the neighbour cache; the search body is straight-line code that costs a wave the same
+// whether 1 or 64 of its lanes are active, so the remaining queries are gathered into dense waves:
+// owners post their query, threads 0..count-1 search one posted query each and post the result back.
+static constexpr int kRowStride = 258;   // doubles per component row in LDS (256 + pad: conflict-free reads)
+static constexpr int kSparseMisses = 8;  // up to this many posted queries per block go the wave-cooperative way
+struct MissExchange {
+    uint32_t count, fallback;
+    uint32_t list[256];                  // owner thread of the m-th posted query (order immaterial)
+    float qx[256], qy[256], qz[256];     // query (float-valued)
+    double seed[256];                    // upper bound of the 5th distance
+    double l6[256];
+    uint32_t searched[256];
+    union {
+        struct { double d[5][256]; uint32_t pos[5][256]; uint32_t idx[5][256]; } res;   // by owner
+        double rows[8 * kRowStride];     // later: [component][point] rows of the normal equations
+    } u;
+};
+
+// ------------------------------------------------------------------------------
 // one scan point: returns status (0 accepted, 1 k-NN gate, 2 plane gate, 3 weight gate,
 // 4 outside this rank's query tile / no point);  row[0..5] = s*[n ; p x n], row[6] = s*d
+// Called by all threads of the block together (it contains barriers).
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h, const double* __restrict__ pose,
-                                          const float* __restrict__ sp, bool valid, KnnShared& sh, double row[7],
-                                          uint32_t nn_idx[5], uint32_t qi, bool use_cache) {
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    if (valid) { sx = sp[0]; sy = sp[1]; sz = sp[2]; }
+                                          float sx, float sy, float sz, bool valid, const NnCacheEntry& ce_in, bool have_entry,
+                                          KnnShared& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how) {
     const double ox = (double)sx, oy = (double)sy, oz = (double)sz;
     // LoamRegister.cpp:126-130: Isometry3d * Vector4d in f64, then cast to f32
     const float px = (float)(pose[0] * ox + pose[4] * oy + pose[8] * oz + pose[12] * 1.0);
@@ -371,54 +537,133 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         if (!in_tile) { active = false; valid = false; }
     }
     Knn5 s;
-    bool searched = false;
-    NnCacheEntry* cache = a.nn_cache ? &a.nn_cache[qi] : nullptr;
+    double A[5][3];
+    bool searched = false, ordered = false;
     float l6f = 0.f;
-    if (cache && use_cache && active) {
-        const NnCacheEntry ce = *cache;
-        if (ce.valid) searched = knn5_from_cache(a.grid.pts, ce, a.q_cache[qi], qx, qy, qz, s, &l6f);
-    }
+    const bool have_seed = have_entry && active && (ce_in.flags & 1u);
+    if (have_seed) searched = knn5_from_cache(ce_in, qx, qy, qz, s, A, &l6f, &ordered);
     const bool hit = searched;
     double l6 = 0.0;
-    // (the full search is entered by the whole wave; lanes served by the cache sit it out)
-    const bool full = knn5_grid(h, a.grid.pts, a.grid.cell_start, qx, qy, qz, a.c.knn_max_sq, s, sh,
-                                active && !hit && !(a.ablate & 1), &l6, hit);
-    searched = hit || full;
-    if (cache && active) {
+    const int tid = threadIdx.x;
+    // ---- post the queries that need a search ----
+    const bool miss = active && !hit && !(a.ablate & 1);
+    if (tid == 0) ex.count = 0;
+    __syncthreads();
+    if (miss) {
+        const uint32_t m = atomicAdd(&ex.count, 1u);
+        ex.list[m] = (uint32_t)tid;
+        ex.qx[tid] = px; ex.qy[tid] = py; ex.qz[tid] = pz;
+        // cached neighbours that could not be proven final still bound the 5th distance from above
+        double sb = a.c.knn_max_sq;
+        if (have_seed) { sb = s.d[0]; for (int j = 1; j < 5; ++j) sb = fmax(sb, s.d[j]); }
+        ex.seed[tid] = sb;
+    }
+    __syncthreads();
+    // ---- the posted queries are searched: a few -> one wave per query (lanes = candidates); many -> thread m
+    //      serves the m-th posted query (lanes = queries) ----
+    {
+        const uint32_t n_miss = ex.count;           // block-uniform
+        bool dense = n_miss > (uint32_t)kSparseMisses;
+        if (n_miss && !dense) {
+            if (tid == 0) ex.fallback = 0;
+            __syncthreads();
+            const int wave = tid >> 6;
+            WaveCand* tab = reinterpret_cast<WaveCand*>(&sh) + (size_t)wave * (kWaveTab + 8);
+            for (uint32_t m = wave; m < n_miss; m += 4) {
+                const uint32_t owner = ex.list[m];
+                Knn5 r;
+                double rl6 = 0.0;
+                bool ins = false;
+                const bool done = knn5_wave(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
+                                            a.c.knn_max_sq, tab, r, &rl6, &ins);
+                if (!done) { if ((tid & 63) == 0) ex.fallback = 1; }
+                else if ((tid & 63) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { ex.u.res.d[j][owner] = r.d[j]; ex.u.res.pos[j][owner] = r.pos[j]; ex.u.res.idx[j][owner] = r.idx[j]; }
+                    ex.l6[owner] = rl6; ex.searched[owner] = ins ? 1u : 0u;
+                }
+            }
+            __syncthreads();
+            dense = ex.fallback != 0;               // a cell block too crowded for the wave table: redo all of them densely
+            __syncthreads();
+        }
+        if (n_miss && dense) {
+            const bool worker = (uint32_t)tid < n_miss;
+            const uint32_t owner = worker ? ex.list[tid] : 0u;
+            Knn5 r;
+            double rl6 = 0.0;
+            const bool ok = knn5_grid(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
+                                      a.c.knn_max_sq, r, sh, worker, &rl6, false, worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate);
+            if (worker) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { ex.u.res.d[j][owner] = r.d[j]; ex.u.res.pos[j][owner] = r.pos[j]; ex.u.res.idx[j][owner] = r.idx[j]; }
+                ex.l6[owner] = rl6; ex.searched[owner] = ok ? 1u : 0u;
+            }
+        }
+    }
+    __syncthreads();
+    bool real5 = hit;     // five real neighbours present
+    if (miss) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { s.d[j] = ex.u.res.d[j][tid]; s.pos[j] = ex.u.res.pos[j][tid]; s.idx[j] = ex.u.res.idx[j][tid]; }
+        l6 = ex.l6[tid];
+        searched = ex.searched[tid] != 0;
+        real5 = searched && s.pos[4] != 0xffffffffu;
+        if (real5) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float4 p = a.grid.pts[s.pos[j]];
+                A[j][0] = (double)p.x; A[j][1] = (double)p.y; A[j][2] = (double)p.z;
+            }
+        }
+    } else if (hit && !ordered) {
+        knn_sort5(s, A);          // same set, new order
+    }
+    __syncthreads();   // ex.u.rows is written next
+    *how = hit ? 1 : (miss ? 2 : 0);
+
+    // ---- plane through the 5 neighbours (LoamRegister.cpp:29-45): reused from the cache when the neighbours
+    // and their order are unchanged, since it does not depend on the query ----
+    double x[3] = {0, 0, 0};
+    bool plane_ok = false;
+    const bool reuse = hit && ordered && (ce_in.flags & 2u);
+    const bool gate_knn = real5 && (s.d[4] < a.c.knn_max_sq);      // LoamRegister.cpp:59
+    if (reuse) {
+        x[0] = ce_in.x[0]; x[1] = ce_in.x[1]; x[2] = ce_in.x[2];
+        plane_ok = (ce_in.flags & 4u) != 0;
+    } else if (real5 && !(a.ablate & 2)) {
+        double Aq[5][3];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { Aq[j][0] = A[j][0]; Aq[j][1] = A[j][1]; Aq[j][2] = A[j][2]; }
+        plane_qr_solve(Aq, x);
+        const double xn0 = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        plane_ok = true;           // LoamRegister.cpp:38-43
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double dot = x[0] * A[i][0] + x[1] * A[i][1] + x[2] * A[i][2];
+            if (fabs(dot + 1.0) > a.c.plane_thresh * xn0) plane_ok = false;
+        }
+    }
+    // ---- remember everything for the next iteration ----
+    if (a.nn_cache && active) {
         NnCacheEntry ce;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) ce.pos[j] = s.pos[j];
-        // all five slots must hold real points for the entry to be reusable
-        ce.valid = searched && s.idx[4] != 0xffffffffu;
+        for (int j = 0; j < 5; ++j) ce.nb[j] = make_float4((float)A[j][0], (float)A[j][1], (float)A[j][2], __uint_as_float(s.idx[j]));
+        ce.x[0] = x[0]; ce.x[1] = x[1]; ce.x[2] = x[2];
+        ce.q0[0] = px; ce.q0[1] = py; ce.q0[2] = pz;
         ce.l6 = hit ? l6f : (float)l6 * 0.999999f;
-        ce.pad = hit;
-        *cache = ce;
-        a.q_cache[qi] = make_float4((float)qx, (float)qy, (float)qz, 0.f);
+        ce.flags = (real5 ? 1u : 0u) | ((real5 && !(a.ablate & 2)) ? 2u : 0u) | (plane_ok ? 4u : 0u);
+        ce.pad = 0;
+        a.nn_cache[qi] = ce;
     }
     if (!valid) return 4;
     if (!searched) return 1;
 #pragma unroll
     for (int j = 0; j < 5; ++j) nn_idx[j] = s.idx[j];
-    if (!(s.d[4] < a.c.knn_max_sq)) return 1;
-    double A[5][3], Aq[5][3];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const float4 p = a.grid.pts[s.pos[j]];
-        A[j][0] = (double)p.x; A[j][1] = (double)p.y; A[j][2] = (double)p.z;
-        Aq[j][0] = A[j][0]; Aq[j][1] = A[j][1]; Aq[j][2] = A[j][2];
-    }
+    if (!gate_knn) return 1;
     if (a.ablate & 2) return 2;
-    double x[3];
-    plane_qr_solve(Aq, x);
+    if (!plane_ok) return 2;
     const double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    // LoamRegister.cpp:38-43
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const double dot = x[0] * A[i][0] + x[1] * A[i][1] + x[2] * A[i][2];
-        if (fabs(dot + 1.0) > a.c.plane_thresh * xn) ok = false;
-    }
-    if (!ok) return 2;
     const double dist = (qx * x[0] + qy * x[1] + qz * x[2] + 1.0) / xn;   // LoamRegister.hpp:75-77
     const float r2 = sx * sx + sy * sy + sz * sz;                           // LoamRegister.cpp:147-148 (float)
     const float rr = sqrtf(sqrtf(r2));
@@ -538,6 +783,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
                 for (int i = 0; i < 36; ++i) tr->JtJ[i] = JtJ[i];
                 for (int i = 0; i < 6; ++i) { tr->JtE[i] = -rhs[i]; tr->x[i] = x[i]; }
                 tr->n = (int64_t)n;
+                tr->cache_hits = (int64_t)sh_sum[28]; tr->searches = (int64_t)sh_sum[29];
             }
         }
     }
@@ -548,23 +794,35 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
 // ------------------------------------------------------------------------------
 // the iteration kernel
 // ------------------------------------------------------------------------------
-static constexpr int kRowStride = 258;   // doubles per component row in LDS (256 + pad: conflict-free reads)
-
 __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, const int k) {
     __shared__ double sh_sum[8 * 32];
     __shared__ Prologue sh_pro;
     __shared__ KnnShared sh_knn;
-    __shared__ double sh_rows[8 * kRowStride];   // [component][point]: s*J row (6), s*d, accepted flag
+    __shared__ MissExchange sh_ex;               // also holds the rows: [component][point] s*J (6), s*d, accepted flag
+    double* const sh_rows = sh_ex.u.rows;
+    const int tid = threadIdx.x;
+    // XCD-aware mapping: consecutive logical blocks (adjacent lidar rings) share an XCD's L2
+    uint32_t blk = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // Everything the first round needs from memory is requested BEFORE the prologue, so that the scan point and
+    // the 128-byte neighbour-cache entry arrive while the previous iteration's normal equations are being solved.
+    float pre_x = 0.f, pre_y = 0.f, pre_z = 0.f;
+    NnCacheEntry pre_ce;
+    pre_ce.flags = 0;
+    const bool use_cache = k > 0 && a.nn_cache != nullptr;
+    {
+        const uint32_t q = blk * 256 + tid;
+        if (q < a.n_src) {
+            const float* sp = a.src + (size_t)q * a.src_stride;
+            pre_x = sp[0]; pre_y = sp[1]; pre_z = sp[2];
+            if (use_cache) pre_ce = a.nn_cache[q];
+        }
+    }
     if (loam_prologue(a, k, sh_sum, &sh_pro)) return;
     const GridHeader h = *a.grid.hdr;
     double pose[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) pose[i] = sh_pro.pose[i];
-    const int tid = threadIdx.x;
-
-    // XCD-aware mapping: consecutive logical blocks (adjacent lidar rings) share an XCD's L2
-    uint32_t blk = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 
     // This thread accumulates ONE entry of the normal equations over a 32-point chunk:
     // e < 21: JtJ(er,ec) upper triangle; 21..26: JtE(er) = sum row[er]*row[6]; 27: accepted count.
@@ -580,12 +838,24 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         if (e >= 21 && e < 27) { er = e - 21; ec = 6; }
     }
     double acc = 0.0;
+    uint32_t n_hit = 0, n_search = 0;
     for (uint32_t base = blk * 256; base < a.n_src; base += gridDim.x * 256) {
         const uint32_t q = base + tid;
         const bool valid = q < a.n_src;
         double row[7] = {0, 0, 0, 0, 0, 0, 0};
         uint32_t nn[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        const int st = loam_point(a, h, pose, a.src + (size_t)(valid ? q : 0) * a.src_stride, valid, sh_knn, row, nn, q, k > 0);
+        int how = 0;
+        float sx = pre_x, sy = pre_y, sz = pre_z;
+        NnCacheEntry ce = pre_ce;
+        if (base != blk * 256) {      // later rounds of a grid-stride launch
+            ce.flags = 0; sx = sy = sz = 0.f;
+            if (valid) {
+                const float* sp = a.src + (size_t)q * a.src_stride;
+                sx = sp[0]; sy = sp[1]; sz = sp[2];
+                if (use_cache) ce = a.nn_cache[q];
+            }
+        }
+        const int st = loam_point(a, h, pose, sx, sy, sz, valid, ce, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const float* spq = a.src + (size_t)q * a.src_stride;
             const size_t oi = a.src_indexed ? (size_t)__float_as_uint(spq[3]) : (size_t)q;   // original scan index
@@ -597,6 +867,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         for (int c = 0; c < 7; ++c) sh_rows[c * kRowStride + tid] = st == 0 ? row[c] : 0.0;
         sh_rows[7 * kRowStride + tid] = st == 0 ? 1.0 : 0.0;
         __syncthreads();
+        n_hit += how == 1; n_search += how == 2;
         if (e < 28) {
             const double* ra = sh_rows + er * kRowStride + ch * 32;
             const double* rb = sh_rows + ec * kRowStride + ch * 32;
@@ -606,11 +877,19 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         __syncthreads();
     }
     sh_sum[ch * 32 + e] = e < 28 ? acc : 0.0;
+    // statistics ride in the two spare components (exact small integers in f64)
+    __shared__ uint32_t sh_cnt[2];
+    if (tid == 0) { sh_cnt[0] = 0; sh_cnt[1] = 0; }
+    __syncthreads();
+    if (n_hit) atomicAdd(&sh_cnt[0], n_hit);
+    if (n_search) atomicAdd(&sh_cnt[1], n_search);
     __syncthreads();
     if (tid < 32) {
         double v = sh_sum[tid];
 #pragma unroll
         for (int c = 1; c < 8; ++c) v += sh_sum[c * 32 + tid];
+        if (tid == 28) v = (double)sh_cnt[0];
+        if (tid == 29) v = (double)sh_cnt[1];
         a.partials[((size_t)(k & 1) * kMaxPartials + blockIdx.x) * kAccum + tid] = v;
     }
 }

@@ -72,6 +72,7 @@ struct LoamTrace {           // per consumed linearisation
     double JtE[6];
     double x[6];
     int64_t n;
+    int64_t cache_hits, searches;   // queries served by the neighbour cache / by a full search in that linearisation
 };
 
 struct NnCacheEntry;
@@ -95,7 +96,6 @@ struct LoamArgs {
     int32_t* dbg_nn;
     // optional query tile (multi-GPU): process only queries inside [lo,hi)
     struct NnCacheEntry* nn_cache;   // [n_src] neighbours of the previous iteration (loam.hip), or null
-    float4* q_cache;         // [n_src] query positions of the previous iteration
     int32_t src_indexed;     // src is the cell-sorted float4 copy: .w = original scan index
     int32_t use_tile;
     double tile_lo[3], tile_hi[3];

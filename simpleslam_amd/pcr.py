@@ -47,7 +47,7 @@ class PcrStats(C.Structure):
 # every symbol include/pcr_hip.h declares
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
-    "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace",
+    "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
 ]
 
@@ -83,6 +83,7 @@ def load_library():
     L.pcr_fitness.restype = C.c_double
     L.pcr_loam_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, C.POINTER(C.c_int64), vp, vp, vp]
     L.pcr_get_trace.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, vp, vp]
+    L.pcr_get_trace_counts.argtypes = [vp, vp, vp]
     L.pcr_vgicp_covariances.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.pcr_vgicp_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.pcr_ndt_derivatives.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, dp]
@@ -259,7 +260,9 @@ class LoamRegister(PointCloudRegister):
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         self._check(self._lib.pcr_get_trace(self._h, C.byref(k), vp(JtJ), vp(JtE), vp(n), vp(x)))
         k = k.value
-        return dict(iters_run=k, JtJ=JtJ[:k].reshape(-1, 6, 6), JtE=JtE[:k], n=n[:k], x=x[:k])
+        hits, srch = np.zeros(it, np.int64), np.zeros(it, np.int64)
+        self._check(self._lib.pcr_get_trace_counts(self._h, vp(hits), vp(srch)))
+        return dict(iters_run=k, JtJ=JtJ[:k].reshape(-1, 6, 6), JtE=JtE[:k], n=n[:k], x=x[:k], cache_hits=hits[:k], searches=srch[:k])
 
 
 class NdtRegister(PointCloudRegister):

@@ -243,3 +243,20 @@ def test_temporal_cache_is_exact(gpu, world_100k):
     ta, tb = a.trace(), b.trace()
     np.testing.assert_array_equal(ta["n"], tb["n"])
     np.testing.assert_array_equal(ta["JtJ"], tb["JtJ"])
+
+
+def test_distance_ties_resolved_on_original_index(gpu):
+    """Duplicated target points give bitwise-equal distances; the neighbour lists must then follow the
+    documented (distance, original index) order exactly, like the oracle's."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_nanoflann.npz"))
+    pts = np.concatenate([g["points"], g["points"][:2000]])          # 2000 more exact duplicates
+    q = np.concatenate([g["queries"], g["points"][:300] + np.float32(1e-3)])
+    reg = LoamRegister()
+    reg.setTarget(pts)
+    lin = reg.linearize(q, np.eye(4), per_point=True)
+    idx, d2 = oracle.KdTree(pts).knn(q[:, :3].astype(np.float64), 5)
+    found = d2[:, 4] < 1.0
+    np.testing.assert_array_equal(lin["status"] != 1, found)
+    np.testing.assert_array_equal(lin["nn"][found], idx[found])
+    assert (d2[found][:, 1:] == d2[found][:, :-1]).any()              # the fixture really contains ties
