@@ -703,40 +703,46 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         __syncthreads();
         return false;
     }
-    if (prev->done) {
-        if (t < 16) sh->pose[t] = prev->pose[t];
+    // Request this thread's share of the previous launch's partial sums together with the state it guards
+    // (one memory round trip instead of two); they are simply unused when the loop has already finished.
+    const int comp = t & 31, slice = t >> 5;
+    double pv[32];
+    {
+        const double* part = a.partials + (size_t)((k + 1) & 1) * kMaxPartials * kAccum + comp;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const uint32_t b = (uint32_t)slice + 8u * u;
+            pv[u] = (!a.reduced && b < a.n_partials) ? part[(size_t)b * kAccum] : 0.0;
+        }
+    }
+    const int prev_done = prev->done;
+    const double prev_pose_t = t < 16 ? prev->pose[t] : 0.0;
+    if (prev_done) {
+        if (t < 16) sh->pose[t] = prev_pose_t;
         if (t == 0) sh->done = 1;
         if (blockIdx.x == 0 && t == 0) { *cur = *prev; }
         __syncthreads();
         return true;
     }
     if (a.ablate & 4) {
-        if (t < 16) sh->pose[t] = prev->pose[t];
+        if (t < 16) sh->pose[t] = prev_pose_t;
         if (t == 0) sh->done = k >= a.c.iters;
         if (blockIdx.x == 0 && t == 0) { *cur = *prev; cur->done = k >= a.c.iters; cur->iters_run = k; }
         __syncthreads();
         return k >= a.c.iters;
     }
     // fixed-order reduction of the partial sums of launch k-1
-    const int comp = t & 31, slice = t >> 5;
     double acc = 0.0;
     if (a.reduced) {
         if (slice == 0) acc = a.reduced[comp];
     } else {
-        // 8 independent loads in flight per batch; the additions keep their fixed order
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += pv[u];
         const double* part = a.partials + (size_t)((k + 1) & 1) * kMaxPartials * kAccum + comp;
-        for (uint32_t b0 = slice; b0 < a.n_partials; b0 += 64) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t b = b0 + 8 * u;
-                v[u] = b < a.n_partials ? part[(size_t)b * kAccum] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
+        for (uint32_t b = (uint32_t)slice + 256u; b < a.n_partials; b += 8) acc += part[(size_t)b * kAccum];   // > 256 blocks
     }
     sh_sum[slice * 32 + comp] = acc;
+    if (t < 16) sh->pose[t] = prev_pose_t;
     __syncthreads();
     if (t < 32) {
         double v = sh_sum[t];
@@ -745,18 +751,42 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         sh_sum[t] = v;
     }
     __syncthreads();
+    // ---- x = (JtJ)^-1 (-JtE)  (LoamRegister.cpp:198).  The reference calls Eigen's LDLT; JtJ is symmetric
+    // positive definite, so plain Gauss-Jordan elimination gives the same x to rounding.  It runs with one lane
+    // per entry of the augmented 6x7 system (42 lanes of wave 0, 6 short steps) instead of ~1.5k dependent
+    // instructions on a single lane while 255 threads of every block wait. ----
+    double* const sh_m = sh_sum + 64;      // 42 entries of the augmented matrix
+    double* const sh_x = sh_sum + 112;     // 6 entries of the solution
+    if (t < 64) {
+        const int i = t / 7, j = t - 7 * i;
+        const bool in = t < 42;
+        double v = 0.0;
+        if (in) {
+            const int r = i < j ? i : j, c = i < j ? j : i;
+            v = j < 6 ? sh_sum[r * 6 - (r * (r - 1)) / 2 + (c - r)] : -sh_sum[21 + i];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+            if (in) sh_m[t] = v;
+            __builtin_amdgcn_wave_barrier();
+            const double pk = sh_m[kk * 7 + kk], aik = in ? sh_m[i * 7 + kk] : 0.0, akj = in ? sh_m[kk * 7 + j] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            if (in) v = (i == kk) ? akj / pk : v - (aik / pk) * akj;
+        }
+        if (in && j == 6) sh_x[i] = v;
+    }
+    __syncthreads();
     if (t == 0) {
-        double JtJ[36], rhs[6], x[6] = {0, 0, 0, 0, 0, 0};
+        double JtJ[36], rhs[6], x[6];
         int q = 0;
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { JtJ[r * 6 + c] = JtJ[c * 6 + r] = sh_sum[q++]; }
-        for (int r = 0; r < 6; ++r) rhs[r] = -sh_sum[21 + r];
+        for (int r = 0; r < 6; ++r) { rhs[r] = -sh_sum[21 + r]; x[r] = sh_x[r]; }
         const double n = sh_sum[27];
         int done = 0, conv = 0, fail = 0;
         double pose[16];
-        for (int i = 0; i < 16; ++i) pose[i] = prev->pose[i];
-        if (n < 6.0) { done = 1; fail = 1; }                      // LoamRegister.cpp:173-176
+        for (int i = 0; i < 16; ++i) pose[i] = sh->pose[i];      // previous pose, staged below
+        if (n < 6.0) { done = 1; fail = 1; for (int r = 0; r < 6; ++r) x[r] = 0.0; }   // LoamRegister.cpp:173-176
         else {
-            ldlt6_solve(JtJ, rhs, x);                              // LoamRegister.cpp:198
             const double np = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
             const double nr = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
             if (a.c.early_exit && np <= a.c.pos_conv && nr <= a.c.rot_conv) { done = 1; conv = 1; }   // :202-206
