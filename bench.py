@@ -31,6 +31,19 @@ SEED = 20261003
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota when there is one (a GPU box grants a share
+    of its host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,7 +174,7 @@ def main():
         # ---- pose parity + CPU baseline: the oracle (a port) on this host's cores ----
         if not args.no_cpu_baseline and not args.shard_map:
             import oracle
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = host_cores()
             prm = oracle.loam_params(iters=args.iters, early_exit=0, threads=cores)
             n_done, t_cpu, et, er = 0, 0.0, [], []
             while n_done < args.scans and (n_done < 1 or t_cpu < args.cpu_budget_s):

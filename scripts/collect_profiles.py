@@ -1,0 +1,66 @@
+"""Condense gpurun_out/prof_r01 (scripts/profile_round.sh) into profiles/: the kernel statistics table, the
+per-kernel PMC means, and profiles/loam_iterate_pmc.json (HBM bytes per launch of the dominant kernel,
+corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KiB... see below)."""
+import csv, glob, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_r01")
+dst = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(dst, exist_ok=True)
+
+
+def newest(pattern):
+    fs = glob.glob(os.path.join(src, pattern), recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+f = newest("stats/**/*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline\n")
+        o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            o.write(",".join([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+
+
+def means(pattern):
+    f = newest(pattern)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    if f:
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in acc.items()}
+
+
+allm = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
+    for k, d in means(f"{sub}/**/*counter_collection.csv").items():
+        allm.setdefault(k, {}).update(d)
+with open(os.path.join(dst, f"{tag}_pmc_means.csv"), "w") as o:
+    o.write("# mean counter value per dispatch; one rocprofv3 --pmc pass per counter group (separate runs)\n")
+    o.write("Kernel,Counter,MeanPerDispatch,Dispatches\n")
+    for k in sorted(allm):
+        for c in sorted(allm[k]):
+            o.write(f"{k},{c},{allm[k][c][0]:.1f},{allm[k][c][1]}\n")
+
+it = allm.get("pcr::loam_iterate_kernel", {})
+if "FETCH_SIZE" in it and "WRITE_SIZE" in it:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE
+    # counts 128-B requests as 64 B for wide coalesced streams -> the guide doubles it for streaming reads.  This
+    # kernel's reads are 16-B gathers and 128-B cache entries, an uncalibrated pattern: both figures are recorded.
+    fetch_kib, write_kib = it["FETCH_SIZE"][0], it["WRITE_SIZE"][0]
+    out = {
+        "kernel": "loam_iterate_kernel",
+        "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
+        "hbm_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024,
+        "hbm_bytes_per_launch_uncorrected": (fetch_kib + write_kib) * 1024,
+        "note": "mean over all launches of the bench run (full-search and cache-hit iterations); FETCH_SIZE doubled per the gfx950 correction",
+    }
+    json.dump(out, open(os.path.join(dst, "loam_iterate_pmc.json"), "w"), indent=1)
+    print(out)
+b = os.path.join(src, "bench_under_profiler.json")
+if os.path.exists(b):
+    open(os.path.join(dst, f"{tag}_bench_under_profiler.json"), "w").write(open(b).read())
+print("profiles written to", dst)

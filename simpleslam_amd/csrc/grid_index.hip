@@ -119,15 +119,37 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
     return true;
 }
 
-// ---- 3. histogram --------------------------------------------------------------
+// ---- 3. histogram + rank of every point inside its cell -------------------------------
+// One atomic per RUN of equal keys in consecutive lanes (clouds that come out of a voxel filter or a
+// lidar driver are spatially ordered, so neighbouring lanes often share a cell): the run's first lane adds the
+// run length and hands the base to the others.  key/rank are kept so that the scatter pass needs neither the
+// f64 key arithmetic nor atomics again.
 __global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
-                                                         const GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count) {
+                                                         const GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks) {
     const GridHeader h = *hdr;
     if (h.overflow || h.empty) return;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float* p = pts + (size_t)i * stride;
-        uint32_t key;
-        if (point_key(h, p[0], p[1], p[2], &key)) atomicAdd(&cell_count[key], 1u);
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_round = (n + 255u) & ~255u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_round; i += gridDim.x * 256) {
+        uint32_t key = 0xffffffffu;
+        if (i < n) {
+            const float* p = pts + (size_t)i * stride;
+            uint32_t k;
+            if (point_key(h, p[0], p[1], p[2], &k)) key = k;
+        }
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const bool leader = lane == 0 || prev != key;
+        const unsigned long long lead = __ballot(leader);
+        // my run starts at the highest leader bit at or below my lane and ends before the next leader bit
+        const unsigned long long below = lead & (~0ull >> (63 - lane));
+        const int start = 63 - __clzll(below);
+        const unsigned long long above = lane == 63 ? 0ull : (lead >> (lane + 1)) << (lane + 1);
+        const int end = above ? __ffsll((long long)above) - 1 : 64;
+        uint32_t base = 0;
+        if (leader && key != 0xffffffffu) base = atomicAdd(&cell_count[key], (uint32_t)(end - start));
+        base = __shfl(base, start, 64);
+        if (i < n) { keys[i] = key; ranks[i] = base + (uint32_t)(lane - start); }
     }
 }
 
@@ -206,21 +228,18 @@ __global__ __launch_bounds__(kScanBlock) void grid_scan_add_kernel(uint32_t* __r
     for (int j = 0; j < kScanPerThread; ++j) if (base + j < total) cell_start[base + j] += add;
 }
 
-// ---- 5. scatter into cell order --------------------------------------------------
+// ---- 5. scatter into cell order (no atomics: position = cell start + rank) ---------------
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
-                                                           const GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count,
-                                                           const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted) {
-    const GridHeader h = *hdr;
-    if (h.overflow || h.empty) return;
+                                                           const GridHeader* __restrict__ hdr, const uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ cell_start,
+                                                           float4* __restrict__ sorted) {
+    if (hdr->overflow || hdr->empty) return;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float* p = pts + (size_t)i * stride;
-        const float x = p[0], y = p[1], z = p[2];
-        uint32_t key;
-        if (point_key(h, x, y, z, &key)) {
-            // slots of a cell are handed out from the back; the order inside a cell is
-            // immaterial (the k-NN breaks distance ties on the original index in .w)
-            const uint32_t slot = atomicSub(&cell_count[key], 1u) - 1u;
-            sorted[cell_start[key] + slot] = make_float4(x, y, z, __uint_as_float(i));
+        const uint32_t key = keys[i];
+        if (key != 0xffffffffu) {
+            const float* p = pts + (size_t)i * stride;
+            // the order inside a cell is immaterial (the searches break distance ties on the original index in .w)
+            sorted[cell_start[key] + ranks[i]] = make_float4(p[0], p[1], p[2], __uint_as_float(i));
         }
     }
 }
@@ -242,7 +261,7 @@ void DeviceBuf::release() {
 
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
-    bbox_partials.release(); header.release();
+    bbox_partials.release(); header.release(); keys.release(); ranks.release();
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -272,6 +291,8 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
     PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
     PCR_TRY(header.reserve(sizeof(GridHeader)));
+    PCR_TRY(keys.reserve((n + 1) * sizeof(uint32_t)));
+    PCR_TRY(ranks.reserve((n + 1) * sizeof(uint32_t)));
     if (cell_capacity == 0) {
         // first guess; a too-small table is detected on the device (header.overflow)
         // and the caller grows it with grow_cells() and retries
@@ -288,7 +309,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     hipLaunchKernelGGL(grid_header_clear_kernel, dim3(clear_blocks), dim3(256), 0, s, bbox_partials.as<float>(), kBBoxBlocks,
                        header.as<GridHeader>(), cell_count.as<uint32_t>(), (uint64_t)cell_capacity, cell, n32);
     hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
-                       cell_count.as<uint32_t>());
+                       cell_count.as<uint32_t>(), keys.as<uint32_t>(), ranks.as<uint32_t>());
     const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL(grid_scan_local_kernel, dim3(scan_blocks), dim3(kScanBlock), 0, s, cell_count.as<uint32_t>(),
                        cell_start.as<uint32_t>(), block_sums.as<uint32_t>(), header.as<GridHeader>());
@@ -296,7 +317,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     hipLaunchKernelGGL(grid_scan_add_kernel, dim3(scan_blocks), dim3(kScanBlock), 0, s, cell_start.as<uint32_t>(),
                        block_sums.as<uint32_t>(), header.as<GridHeader>());
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
-                       cell_count.as<uint32_t>(), cell_start.as<uint32_t>(), sorted.as<float4>());
+                       keys.as<uint32_t>(), ranks.as<uint32_t>(), cell_start.as<uint32_t>(), sorted.as<float4>());
     PCR_TRY(hipGetLastError());
     n_points = n;
     valid = true;

@@ -253,9 +253,10 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
 // ------------------------------------------------------------------------------
 struct NnCacheEntry {          // 128 bytes per scan point
     float4 nb[5];              // the 5 neighbours in (distance, index) order: x y z | original index bits
+    float q0[3];               // query position the entry refers to            } the only 16 bytes that change while
+    float l6;                  // lower bound (rounded down) of the squared     } the neighbours stay the same
+                               // distance from q0 to every OTHER target point
     double x[3];               // plane through them, A x = -1 (depends only on nb and their order)
-    float q0[3];               // query position the entry refers to
-    float l6;                  // lower bound (rounded down) of the squared distance from q0 to every OTHER target point
     uint32_t flags;            // bit0: entry valid (5 real neighbours)  bit1: x valid  bit2: plane passed its validity gate
     uint32_t pad;
 };
@@ -646,15 +647,21 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     }
     // ---- remember everything for the next iteration ----
     if (a.nn_cache && active) {
-        NnCacheEntry ce;
+        const float l6s = hit ? l6f : (float)l6 * 0.999999f;
+        if (reuse) {
+            // neighbours, order and plane unchanged: only the query position and its bound move (16 of the 128 bytes)
+            *reinterpret_cast<float4*>(&a.nn_cache[qi].q0[0]) = make_float4(px, py, pz, l6s);
+        } else {
+            NnCacheEntry ce;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) ce.nb[j] = make_float4((float)A[j][0], (float)A[j][1], (float)A[j][2], __uint_as_float(s.idx[j]));
-        ce.x[0] = x[0]; ce.x[1] = x[1]; ce.x[2] = x[2];
-        ce.q0[0] = px; ce.q0[1] = py; ce.q0[2] = pz;
-        ce.l6 = hit ? l6f : (float)l6 * 0.999999f;
-        ce.flags = (real5 ? 1u : 0u) | ((real5 && !(a.ablate & 2)) ? 2u : 0u) | (plane_ok ? 4u : 0u);
-        ce.pad = 0;
-        a.nn_cache[qi] = ce;
+            for (int j = 0; j < 5; ++j) ce.nb[j] = make_float4((float)A[j][0], (float)A[j][1], (float)A[j][2], __uint_as_float(s.idx[j]));
+            ce.x[0] = x[0]; ce.x[1] = x[1]; ce.x[2] = x[2];
+            ce.q0[0] = px; ce.q0[1] = py; ce.q0[2] = pz;
+            ce.l6 = l6s;
+            ce.flags = (real5 ? 1u : 0u) | ((real5 && !(a.ablate & 2)) ? 2u : 0u) | (plane_ok ? 4u : 0u);
+            ce.pad = 0;
+            a.nn_cache[qi] = ce;
+        }
     }
     if (!valid) return 4;
     if (!searched) return 1;
