@@ -355,15 +355,27 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a,
     }
 }
 
-// fold per-block partials (48 doubles each) into 48 doubles, fixed order
-__global__ __launch_bounds__(192) void ndt_sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
-    __shared__ double sh[4 * 48];
+// fold per-block partials (48 doubles each) into 48 doubles, fixed order; 16 slices of 48 components, each
+// slice keeps 8 independent loads in flight
+__global__ __launch_bounds__(768) void ndt_sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+    __shared__ double sh[16 * 48];
     const int t = threadIdx.x, comp = t % 48, slice = t / 48;
     double acc = 0.0;
-    for (uint32_t b = slice; b < nblocks; b += 4) acc += partials[(size_t)b * 48 + comp];
+    for (uint32_t b0 = slice; b0 < nblocks; b0 += 16 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t b = b0 + 16 * u; v[u] = b < nblocks ? partials[(size_t)b * 48 + comp] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
     sh[slice * 48 + comp] = acc;
     __syncthreads();
-    if (t < 48) out[t] = ((sh[t] + sh[48 + t]) + sh[96 + t]) + sh[144 + t];
+    if (t < 48) {
+        double v = sh[t];
+#pragma unroll
+        for (int s2 = 1; s2 < 16; ++s2) v += sh[s2 * 48 + t];
+        out[t] = v;
+    }
 }
 
 // ---- host launchers ---------------------------------------------------------------
@@ -384,14 +396,14 @@ hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* 
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s) {
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_derivatives_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang, compute_hessian);
-    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(192), 0, s, a.partials, nb, d_out48);
+    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48);
     return hipGetLastError();
 }
 
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s) {
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_hessian_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
-    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(192), 0, s, a.partials, nb, d_out48);
+    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48);
     return hipGetLastError();
 }
 

@@ -49,25 +49,40 @@ __device__ __forceinline__ void ring_scan_run(const float4* __restrict__ pts, ui
     }
 }
 
-// Searches outward ring by ring until the K-th distance is provably final.  max_sq: neighbours
-// farther than this are not needed (FLT_MAX for none).
+// Searches outward ring by ring until the K-th distance is provably final.  max_sq: neighbours farther than
+// this are not needed (FLT_MAX for none).  seed_sq: a radius^2 expected to hold at least K points (from the local
+// density); the list starts with sentinels at that radius so that, in a crowded cell, the thousands of farther
+// candidates are rejected by one compare instead of being inserted and displaced again.  The search is exact
+// either way: when fewer than K real points turn up inside the seed radius it is repeated without the seed.
 template <int K>
-__device__ __forceinline__ void ring_knn(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                         float qx, float qy, float qz, float max_sq, KeyList<K>& L) {
+__device__ __forceinline__ void ring_knn_pass(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                              float qx, float qy, float qz, float max_sq, float seed_sq, KeyList<K>& L) {
+    const unsigned long long sentinel = ((unsigned long long)__float_as_uint(seed_sq) << 32) | 0xffffffffull;
 #pragma unroll
-    for (int i = 0; i < K; ++i) L.k[i] = ~0ull;
-    if (h.empty || h.overflow) return;
+    for (int i = 0; i < K; ++i) L.k[i] = sentinel;
     const int d0 = h.dims[0], d1 = h.dims[1], d2 = h.dims[2];
     double fx = floor((double)qx / h.cell) - h.org[0], fy = floor((double)qy / h.cell) - h.org[1], fz = floor((double)qz / h.cell) - h.org[2];
     // centre cell, clamped into the grid (queries of the fitness score may lie outside)
     const int cx = (int)fmin(fmax(fx, 0.0), (double)(d0 - 1)), cy = (int)fmin(fmax(fy, 0.0), (double)(d1 - 1)),
               cz = (int)fmin(fmax(fz, 0.0), (double)(d2 - 1));
     const int rmax = max(max(max(cx, d0 - 1 - cx), max(cy, d1 - 1 - cy)), max(cz, d2 - 1 - cz));
+    const float cellf = (float)h.cell;
     for (int r = 1; r <= max(rmax, 1); ++r) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, d2 - 1), y0 = max(cy - r, 0), y1 = min(cy + r, d1 - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, d0 - 1);
+        const float worst = __uint_as_float((uint32_t)(L.k[K - 1] >> 32));
         for (int z = z0; z <= z1; ++z) {
+            // distance from the query to the slab of cells z (0 inside it); float, shaved so that it never exceeds the true gap
+            const float zlo = (float)((h.org[2] + z) * h.cell), gz = fmaxf(fmaxf(zlo - qz, qz - (zlo + cellf)), 0.f) * 0.99999f;
+            if (gz * gz > worst) continue;
+            // rows y0..y1 of one z layer are contiguous in key order: one subtraction tells whether the whole band
+            // (all x) is empty -- the common case for the far, sparse part of a lidar scan, where a ring of
+            // radius r would otherwise cost (2r+1)^2 row lookups
+            if (cell_start[((uint32_t)z * (uint32_t)d1 + (uint32_t)y0) * (uint32_t)d0] ==
+                cell_start[((uint32_t)z * (uint32_t)d1 + (uint32_t)y1 + 1u) * (uint32_t)d0]) continue;
             for (int y = y0; y <= y1; ++y) {
+                const float ylo = (float)((h.org[1] + y) * h.cell), gy = fmaxf(fmaxf(ylo - qy, qy - (ylo + cellf)), 0.f) * 0.99999f;
+                if (gy * gy + gz * gz > worst) continue;      // the whole row is farther than the current K-th distance
                 const uint32_t row = ((uint32_t)z * (uint32_t)d1 + (uint32_t)y) * (uint32_t)d0;
                 const bool shell_row = r == 1 || z == cz - r || z == cz + r || y == cy - r || y == cy + r;
                 if (shell_row) {
@@ -90,8 +105,33 @@ __device__ __forceinline__ void ring_knn(const GridHeader& h, const float4* __re
         if (bound >= 1e299) break;   // the block covers the whole grid
         const double b2 = bound > 0 ? bound * bound * (1.0 - 1e-5) : 0.0;   // margin: float distances
         if (b2 > (double)max_sq) break;
-        if (L.k[K - 1] != ~0ull && (double)__uint_as_float((uint32_t)(L.k[K - 1] >> 32)) < b2) break;
+        if ((double)__uint_as_float((uint32_t)(L.k[K - 1] >> 32)) < b2) break;
     }
+}
+
+template <int K>
+__device__ __forceinline__ void ring_knn(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                         float qx, float qy, float qz, float max_sq, KeyList<K>& L) {
+    if (h.empty || h.overflow) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) L.k[i] = ~0ull;
+        return;
+    }
+    float seed = 3.0e38f;
+    if (K > 1) {
+        // points of the query's own cell, taken as a surface patch of area cell^2: radius holding ~2K of them
+        const double fx = floor((double)qx / h.cell) - h.org[0], fy = floor((double)qy / h.cell) - h.org[1], fz = floor((double)qz / h.cell) - h.org[2];
+        if (fx >= 0 && fx < h.dims[0] && fy >= 0 && fy < h.dims[1] && fz >= 0 && fz < h.dims[2]) {
+            const uint32_t key = ((uint32_t)fz * (uint32_t)h.dims[1] + (uint32_t)fy) * (uint32_t)h.dims[0] + (uint32_t)fx;
+            const uint32_t nc = cell_start[key + 1] - cell_start[key];
+            if (nc >= 4u * (uint32_t)K) seed = (float)(h.cell * h.cell) * (2.0f * (float)K / (3.14159265f * (float)nc));
+        }
+    }
+    ring_knn_pass<K>(h, pts, cell_start, qx, qy, qz, max_sq, seed, L);
+    if (seed < 3.0e38f && (uint32_t)L.k[K - 1] == 0xffffffffu)      // the seed radius held fewer than K points: exact redo
+        ring_knn_pass<K>(h, pts, cell_start, qx, qy, qz, max_sq, 3.0e38f, L);
+#pragma unroll
+    for (int i = 0; i < K; ++i) if ((uint32_t)L.k[i] == 0xffffffffu) L.k[i] = ~0ull;   // unfilled slots
 }
 
 // ------------------------------------------------------------------------------
