@@ -77,7 +77,8 @@ struct pcr_handle {
 
     // VGICP work memory
     GridIndex src_grid;
-    DeviceBuf tgt_cov6, src_cov6, vox_slot, vox, vox_count, corr_slot, corr_M, vg_partials;
+    GridIndex cov_l1, cov_l2;        // the cloud whose covariances are being computed, indexed at 4x and 16x the cell
+    DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, vg_partials;
     double* out32_host = nullptr;        // host-mapped: 32 doubles written by sum_partials_kernel
     double* out32_dev = nullptr;
     bool vg_target_ready = false;
@@ -277,21 +278,41 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
     return fail(h, "index could not be sized");
 }
 
+// the fine index plus the two coarse ones of the covariance search, settled with one round trip
+int settle_cov_levels(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell, double shift0) {
+    GridIndex* lv[3] = {&g, &h->cov_l1, &h->cov_l2};
+    const double cells[3] = {cell, 4.0 * cell, 16.0 * cell};
+    bool todo[3] = {true, true, true};
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        GridHeader hdr[3];
+        for (int l = 0; l < 3; ++l) {
+            if (!todo[l]) continue;
+            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0) != hipSuccess) return 1;
+            H_TRY(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
+        }
+        H_TRY(hipStreamSynchronize(h->stream));
+        bool again = false;
+        for (int l = 0; l < 3; ++l) {
+            if (!todo[l]) continue;
+            if (hdr[l].overflow) { if (lv[l]->grow_cells(hdr[l].n_cells, &h->err) != hipSuccess) return 1; again = true; }
+            else todo[l] = false;
+        }
+        if (!again) return 0;
+    }
+    return fail(h, "index could not be sized");
+}
+
 int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
     h->vg_target_ready = false;
     const double res = h->prm.vgicp_resolution;
     if (!(res > 0)) return fail(h, "vgicp_resolution must be positive");
     if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
-    if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res)) return 1;
+    if (settle_cov_levels(h, h->grid, d_dst, n_dst, stride_floats, res, 0.5)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->tgt_cov6.reserve((n_dst + 1) * 6 * sizeof(double)));
-    const uint64_t slot_cap = 2 * (uint64_t)h->grid.cell_capacity + 64;
-    H_TRY(h->vox_slot.reserve(slot_cap * sizeof(uint32_t)));
     H_TRY(h->vox.reserve((n_dst + 1) * sizeof(VgicpVoxel)));
-    H_TRY(h->vox_count.reserve(16));
-    H_TRY(vgicp_launch_cov(h->grid, d_dst, stride_floats, n_dst, h->tgt_cov6.as<double>(), h->stream));
-    H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox_slot.as<uint32_t>(), slot_cap, h->vox.as<VgicpVoxel>(),
-                              h->vox_count.as<uint32_t>(), h->stream));
+    H_TRY(vgicp_launch_cov(h->grid, &h->cov_l1, &h->cov_l2, d_dst, stride_floats, n_dst, h->tgt_cov6.as<double>(), h->stream));
+    H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream));
     h->vg_target_ready = true;
     return 0;
 }
@@ -342,9 +363,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         H_TRY(hipHostGetDevicePointer((void**)&h->out32_dev, h->out32_host, 0));
     }
     // source covariances over the source's own index (fast_gicp_impl.hpp:103-108)
-    if (settle_grid(h, h->src_grid, d_src, n_src, stride_floats, h->prm.vgicp_resolution)) return 1;
+    if (settle_cov_levels(h, h->src_grid, d_src, n_src, stride_floats, h->prm.vgicp_resolution, 0.0)) return 1;
     H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
-    H_TRY(vgicp_launch_cov(h->src_grid, d_src, stride_floats, n_src, h->src_cov6.as<double>(), h->stream));
+    H_TRY(vgicp_launch_cov(h->src_grid, &h->cov_l1, &h->cov_l2, d_src, stride_floats, n_src, h->src_cov6.as<double>(), h->stream));
     H_TRY(h->corr_slot.reserve((n_src + 1) * sizeof(uint32_t)));
     H_TRY(h->corr_M.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(h->vg_partials.reserve((size_t)512 * 32 * sizeof(double)));
@@ -352,7 +373,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)stride_floats;
     a.src_cov6 = h->src_cov6.as<double>();
     a.hdr = h->grid.header.as<GridHeader>();
-    a.vox_slot = h->vox_slot.as<uint32_t>(); a.slot_capacity = 2 * (uint64_t)h->grid.cell_capacity + 64;
+    a.cell_start = h->grid.cell_start.as<uint32_t>();
     a.vox = h->vox.as<VgicpVoxel>();
     a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
     a.partials = h->vg_partials.as<double>();
@@ -809,8 +830,8 @@ void pcr_destroy(pcr_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release(); h->sorter.release();
-    h->src_grid.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox_slot.release(); h->vox.release();
-    h->vox_count.release(); h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
+    h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
+    h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
@@ -936,10 +957,10 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     const float* d_pts = (const float*)pts;
     if (!on_device && stage_host(h, &h->src_stage, pts, n, stride_bytes, &d_pts)) return 1;
-    if (settle_grid(h, h->src_grid, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution)) return 1;
+    if (settle_cov_levels(h, h->src_grid, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution, 0.0)) return 1;
     H_TRY(h->src_cov6.reserve((n + 1) * 6 * sizeof(double)));
     H_TRY(hipMemsetAsync(h->src_cov6.p, 0, (n + 1) * 6 * sizeof(double), h->stream));
-    H_TRY(vgicp_launch_cov(h->src_grid, d_pts, stride_bytes / 4, n, h->src_cov6.as<double>(), h->stream));
+    H_TRY(vgicp_launch_cov(h->src_grid, &h->cov_l1, &h->cov_l2, d_pts, stride_bytes / 4, n, h->src_cov6.as<double>(), h->stream));
     H_TRY(hipMemcpyAsync(cov_out, h->src_cov6.p, n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -967,7 +988,7 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)(stride_bytes / 4);
     a.src_cov6 = h->src_cov6.as<double>();
     a.hdr = h->grid.header.as<GridHeader>();
-    a.vox_slot = h->vox_slot.as<uint32_t>(); a.slot_capacity = 2 * (uint64_t)h->grid.cell_capacity + 64;
+    a.cell_start = h->grid.cell_start.as<uint32_t>();
     a.vox = h->vox.as<VgicpVoxel>();
     a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
     a.partials = h->vg_partials.as<double>();

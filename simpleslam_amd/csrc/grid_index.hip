@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict_
 // ---- 2. header (every block, redundantly) + clear of the cell counters -------
 __global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __restrict__ partials, int n_partials,
                                                                 GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count,
-                                                                uint64_t capacity, double cell, uint32_t n_points) {
+                                                                uint64_t capacity, double cell, double shift, uint32_t n_points) {
     __shared__ float sh[4][6];
     __shared__ uint64_t sh_ncells;
     __shared__ int sh_bad;
@@ -80,16 +80,16 @@ __global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         GridHeader h;
-        h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n_points;
+        h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n_points; h.shift = shift;
         h.empty = 0; h.overflow = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
             float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
             if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
-            double clo = floor((double)lo / cell), chi = floor((double)hi / cell);
+            double clo = floor((double)lo / cell - shift), chi = floor((double)hi / cell - shift);
             h.org[d] = clo - kPad;
-            h.origin[d] = (clo - kPad) * cell;
+            h.origin[d] = (clo - kPad + shift) * cell;
             double dim = chi - clo + 1.0 + 2.0 * kPad;
             h.dims[d] = dim < 2.0e9 ? (int32_t)dim : 0x7fffffff;
             nc *= dim;
@@ -111,9 +111,9 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
     // cell index = floor(x / cell) - org.  For a power-of-two cell (LOAM) x / cell is exact and this
     // equals floor((x - origin) / cell); for any other edge (VGICP/NDT resolutions) it is the single
     // definition every kernel uses, so a point and its queries always agree on the cell.
-    const double fx = floor((double)x / h.cell) - h.org[0];
-    const double fy = floor((double)y / h.cell) - h.org[1];
-    const double fz = floor((double)z / h.cell) - h.org[2];
+    const double fx = floor((double)x / h.cell - h.shift) - h.org[0];
+    const double fy = floor((double)y / h.cell - h.shift) - h.org[1];
+    const double fz = floor((double)z / h.cell - h.shift) - h.org[2];
     const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
     *key = (cz * (uint32_t)h.dims[1] + cy) * (uint32_t)h.dims[0] + cx;
     return true;
@@ -285,7 +285,7 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 
 #define PCR_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { if (err) *err = std::string(#x) + ": " + hipGetErrorString(_e); return _e; } } while (0)
 
-hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err) {
+hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift) {
     valid = false;
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
@@ -307,7 +307,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     hipLaunchKernelGGL(grid_bbox_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>());
     const int clear_blocks = (int)std::min<size_t>(2048, cell_capacity / 1024 + 1);
     hipLaunchKernelGGL(grid_header_clear_kernel, dim3(clear_blocks), dim3(256), 0, s, bbox_partials.as<float>(), kBBoxBlocks,
-                       header.as<GridHeader>(), cell_count.as<uint32_t>(), (uint64_t)cell_capacity, cell, n32);
+                       header.as<GridHeader>(), cell_count.as<uint32_t>(), (uint64_t)cell_capacity, cell, shift, n32);
     hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
                        cell_count.as<uint32_t>(), keys.as<uint32_t>(), ranks.as<uint32_t>());
     const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);

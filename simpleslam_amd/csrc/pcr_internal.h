@@ -29,6 +29,7 @@ struct GridHeader {
     uint64_t n_cells;        // dims[0]*dims[1]*dims[2]
     int32_t overflow;        // n_cells + 1 exceeds the allocated cell table
     int32_t empty;           // no finite point
+    double shift;            // lattice offset in cells: cell index = floor(x / cell - shift) - org (0.5 for the VGICP voxel lattice)
 };
 
 struct GridView {            // what kernels need to query the index
@@ -124,7 +125,7 @@ struct GridIndex {
     // Enqueue the build of the index over n points (device pointer, stride in floats).
     // No host synchronisation unless the cell table must grow.  cell = grid edge.
     hipError_t build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s,
-                     std::string* err);
+                     std::string* err, double shift = 0.0);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
     void release();
@@ -153,16 +154,16 @@ struct VgicpArgs {
     const float* src; uint32_t n_src, src_stride;
     const double* src_cov6;      // per source point, original order
     const GridHeader* hdr;       // target index header (voxel lattice = index grid shifted by half a cell)
-    const uint32_t* vox_slot; uint64_t slot_capacity;
+    const uint32_t* cell_start;  // of the target index: voxel = cell, stored at the position of the cell's first point
     const VgicpVoxel* vox;
     uint32_t* corr_slot;         // [n_src] voxel slot + 1 of the correspondence, 0 = none
     double* corr_M;              // [n_src][6] Mahalanobis matrix of the correspondence
     double* partials;            // [blocks][32]
 };
 
-hipError_t vgicp_launch_cov(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, double* d_cov6, hipStream_t s);
-hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, uint32_t* d_slot, uint64_t slot_capacity, VgicpVoxel* d_vox,
-                               uint32_t* d_count, hipStream_t s);
+hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
+                            size_t n, double* d_cov6, hipStream_t s);
+hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s);
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s);
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s);
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,

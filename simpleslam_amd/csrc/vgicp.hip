@@ -25,17 +25,19 @@ struct KeyList {
     unsigned long long k[K];
 };
 
-template <int K>
+template <int K, bool DEDUPE>
 __device__ __forceinline__ void keylist_insert(KeyList<K>& L, unsigned long long key) {
     bool c[K];
+    bool dup = false;
 #pragma unroll
-    for (int i = 0; i < K; ++i) c[i] = key < L.k[i];
+    for (int i = 0; i < K; ++i) { c[i] = key < L.k[i]; if (DEDUPE) dup |= key == L.k[i]; }
+    if (DEDUPE && dup) return;      // a coarser level meets the points of the finer ones again
 #pragma unroll
     for (int i = K - 1; i >= 1; --i) L.k[i] = c[i - 1] ? L.k[i - 1] : (c[i] ? key : L.k[i]);
     L.k[0] = c[0] ? key : L.k[0];
 }
 
-template <int K>
+template <int K, bool DEDUPE>
 __device__ __forceinline__ void ring_scan_run(const float4* __restrict__ pts, uint32_t s, uint32_t e, float qx, float qy, float qz,
                                               KeyList<K>& L) {
     for (uint32_t j = s; j < e; ++j) {
@@ -45,73 +47,96 @@ __device__ __forceinline__ void ring_scan_run(const float4* __restrict__ pts, ui
         d += dy * dy;
         d += dz * dz;
         const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(p.w);
-        if (key < L.k[K - 1]) keylist_insert<K>(L, key);
+        if (key < L.k[K - 1]) keylist_insert<K, DEDUPE>(L, key);
     }
 }
 
-// Searches outward ring by ring until the K-th distance is provably final.  max_sq: neighbours farther than
-// this are not needed (FLT_MAX for none).  seed_sq: a radius^2 expected to hold at least K points (from the local
-// density); the list starts with sentinels at that radius so that, in a crowded cell, the thousands of farther
-// candidates are rejected by one compare instead of being inserted and displaced again.  The search is exact
-// either way: when fewer than K real points turn up inside the seed radius it is repeated without the seed.
-template <int K>
-__device__ __forceinline__ void ring_knn_pass(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                              float qx, float qy, float qz, float max_sq, float seed_sq, KeyList<K>& L) {
-    const unsigned long long sentinel = ((unsigned long long)__float_as_uint(seed_sq) << 32) | 0xffffffffull;
-#pragma unroll
-    for (int i = 0; i < K; ++i) L.k[i] = sentinel;
+// One cloud indexed at up to three cell sizes (cell, 4 cell, 16 cell).  A lidar scan spans four orders of
+// magnitude of density; on a single grid the K-neighbourhood of a far point is dozens of rings wide and one such
+// lane holds its whole wave.  Rings 1 and 2 of each level guarantee radii of 1, 2, 4, 8, 16, 32 cells; only
+// the last level keeps growing.
+struct GridLevels {
+    const GridHeader* hdr[3];
+    const float4* pts[3];
+    const uint32_t* cell_start[3];
+    int n;
+};
+
+// Rings first..last of one level.  Returns true when the K-th distance is final (or nothing can lie beyond).
+template <int K, bool DEDUPE>
+__device__ __forceinline__ bool ring_level(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                           float qx, float qy, float qz, float max_sq, int last_ring, KeyList<K>& L) {
     const int d0 = h.dims[0], d1 = h.dims[1], d2 = h.dims[2];
-    double fx = floor((double)qx / h.cell) - h.org[0], fy = floor((double)qy / h.cell) - h.org[1], fz = floor((double)qz / h.cell) - h.org[2];
+    double fx = floor((double)qx / h.cell - h.shift) - h.org[0], fy = floor((double)qy / h.cell - h.shift) - h.org[1],
+           fz = floor((double)qz / h.cell - h.shift) - h.org[2];
     // centre cell, clamped into the grid (queries of the fitness score may lie outside)
     const int cx = (int)fmin(fmax(fx, 0.0), (double)(d0 - 1)), cy = (int)fmin(fmax(fy, 0.0), (double)(d1 - 1)),
               cz = (int)fmin(fmax(fz, 0.0), (double)(d2 - 1));
     const int rmax = max(max(max(cx, d0 - 1 - cx), max(cy, d1 - 1 - cy)), max(cz, d2 - 1 - cz));
     const float cellf = (float)h.cell;
+    const double o0 = h.org[0] + h.shift, o1 = h.org[1] + h.shift, o2 = h.org[2] + h.shift;   // cell i spans [(o + i) cell, (o + i + 1) cell)
     for (int r = 1; r <= max(rmax, 1); ++r) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, d2 - 1), y0 = max(cy - r, 0), y1 = min(cy + r, d1 - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, d0 - 1);
         const float worst = __uint_as_float((uint32_t)(L.k[K - 1] >> 32));
         for (int z = z0; z <= z1; ++z) {
             // distance from the query to the slab of cells z (0 inside it); float, shaved so that it never exceeds the true gap
-            const float zlo = (float)((h.org[2] + z) * h.cell), gz = fmaxf(fmaxf(zlo - qz, qz - (zlo + cellf)), 0.f) * 0.99999f;
+            const float zlo = (float)((o2 + z) * h.cell), gz = fmaxf(fmaxf(zlo - qz, qz - (zlo + cellf)), 0.f) * 0.99999f;
             if (gz * gz > worst) continue;
             // rows y0..y1 of one z layer are contiguous in key order: one subtraction tells whether the whole band
-            // (all x) is empty -- the common case for the far, sparse part of a lidar scan, where a ring of
-            // radius r would otherwise cost (2r+1)^2 row lookups
+            // (all x) is empty
             if (cell_start[((uint32_t)z * (uint32_t)d1 + (uint32_t)y0) * (uint32_t)d0] ==
                 cell_start[((uint32_t)z * (uint32_t)d1 + (uint32_t)y1 + 1u) * (uint32_t)d0]) continue;
             for (int y = y0; y <= y1; ++y) {
-                const float ylo = (float)((h.org[1] + y) * h.cell), gy = fmaxf(fmaxf(ylo - qy, qy - (ylo + cellf)), 0.f) * 0.99999f;
+                const float ylo = (float)((o1 + y) * h.cell), gy = fmaxf(fmaxf(ylo - qy, qy - (ylo + cellf)), 0.f) * 0.99999f;
                 if (gy * gy + gz * gz > worst) continue;      // the whole row is farther than the current K-th distance
                 const uint32_t row = ((uint32_t)z * (uint32_t)d1 + (uint32_t)y) * (uint32_t)d0;
                 const bool shell_row = r == 1 || z == cz - r || z == cz + r || y == cy - r || y == cy + r;
                 if (shell_row) {
-                    ring_scan_run<K>(pts, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, L);
+                    ring_scan_run<K, DEDUPE>(pts, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, L);
                 } else {
-                    if (cx - r >= 0) ring_scan_run<K>(pts, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, L);
-                    if (cx + r <= d0 - 1) ring_scan_run<K>(pts, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, L);
+                    if (cx - r >= 0) ring_scan_run<K, DEDUPE>(pts, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, L);
+                    if (cx + r <= d0 - 1) ring_scan_run<K, DEDUPE>(pts, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, L);
                 }
             }
         }
         // every point not yet visited lies beyond a face of the block [c-r, c+r]; faces on the
         // grid boundary have nothing behind them
         double bound = 1e300;
-        if (cx - r > 0) bound = fmin(bound, (double)qx - (h.org[0] + (double)(cx - r)) * h.cell);
-        if (cx + r < d0 - 1) bound = fmin(bound, (h.org[0] + (double)(cx + r + 1)) * h.cell - (double)qx);
-        if (cy - r > 0) bound = fmin(bound, (double)qy - (h.org[1] + (double)(cy - r)) * h.cell);
-        if (cy + r < d1 - 1) bound = fmin(bound, (h.org[1] + (double)(cy + r + 1)) * h.cell - (double)qy);
-        if (cz - r > 0) bound = fmin(bound, (double)qz - (h.org[2] + (double)(cz - r)) * h.cell);
-        if (cz + r < d2 - 1) bound = fmin(bound, (h.org[2] + (double)(cz + r + 1)) * h.cell - (double)qz);
-        if (bound >= 1e299) break;   // the block covers the whole grid
+        if (cx - r > 0) bound = fmin(bound, (double)qx - (o0 + (double)(cx - r)) * h.cell);
+        if (cx + r < d0 - 1) bound = fmin(bound, (o0 + (double)(cx + r + 1)) * h.cell - (double)qx);
+        if (cy - r > 0) bound = fmin(bound, (double)qy - (o1 + (double)(cy - r)) * h.cell);
+        if (cy + r < d1 - 1) bound = fmin(bound, (o1 + (double)(cy + r + 1)) * h.cell - (double)qy);
+        if (cz - r > 0) bound = fmin(bound, (double)qz - (o2 + (double)(cz - r)) * h.cell);
+        if (cz + r < d2 - 1) bound = fmin(bound, (o2 + (double)(cz + r + 1)) * h.cell - (double)qz);
+        if (bound >= 1e299) return true;   // the block covers the whole grid
         const double b2 = bound > 0 ? bound * bound * (1.0 - 1e-5) : 0.0;   // margin: float distances
-        if (b2 > (double)max_sq) break;
-        if ((double)__uint_as_float((uint32_t)(L.k[K - 1] >> 32)) < b2) break;
+        if (b2 > (double)max_sq) return true;
+        if ((double)__uint_as_float((uint32_t)(L.k[K - 1] >> 32)) < b2) return true;
+        if (r >= last_ring) return false;
+    }
+    return true;
+}
+
+// Exact K nearest neighbours.  max_sq: neighbours farther than this are not needed (FLT_MAX for none).
+// seed_sq: a radius^2 expected to hold at least K points (from the local density); the list starts with
+// sentinels at that radius so that, in a crowded cell, the thousands of farther candidates are rejected by one
+// compare instead of being inserted and displaced again.
+template <int K>
+__device__ __forceinline__ void ring_knn_pass(const GridLevels& lv, float qx, float qy, float qz, float max_sq, float seed_sq, KeyList<K>& L) {
+    const unsigned long long sentinel = ((unsigned long long)__float_as_uint(seed_sq) << 32) | 0xffffffffull;
+#pragma unroll
+    for (int i = 0; i < K; ++i) L.k[i] = sentinel;
+    bool done = ring_level<K, false>(*lv.hdr[0], lv.pts[0], lv.cell_start[0], qx, qy, qz, max_sq, lv.n > 1 ? 2 : 0x7fffffff, L);
+    for (int l = 1; l < lv.n; ++l) {
+        if (done) break;
+        done = ring_level<K, true>(*lv.hdr[l], lv.pts[l], lv.cell_start[l], qx, qy, qz, max_sq, l + 1 < lv.n ? 2 : 0x7fffffff, L);
     }
 }
 
 template <int K>
-__device__ __forceinline__ void ring_knn(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                         float qx, float qy, float qz, float max_sq, KeyList<K>& L) {
+__device__ __forceinline__ void ring_knn(const GridLevels& lv, float qx, float qy, float qz, float max_sq, KeyList<K>& L) {
+    const GridHeader& h = *lv.hdr[0];
     if (h.empty || h.overflow) {
 #pragma unroll
         for (int i = 0; i < K; ++i) L.k[i] = ~0ull;
@@ -120,18 +145,26 @@ __device__ __forceinline__ void ring_knn(const GridHeader& h, const float4* __re
     float seed = 3.0e38f;
     if (K > 1) {
         // points of the query's own cell, taken as a surface patch of area cell^2: radius holding ~2K of them
-        const double fx = floor((double)qx / h.cell) - h.org[0], fy = floor((double)qy / h.cell) - h.org[1], fz = floor((double)qz / h.cell) - h.org[2];
+        const double fx = floor((double)qx / h.cell - h.shift) - h.org[0], fy = floor((double)qy / h.cell - h.shift) - h.org[1],
+                     fz = floor((double)qz / h.cell - h.shift) - h.org[2];
         if (fx >= 0 && fx < h.dims[0] && fy >= 0 && fy < h.dims[1] && fz >= 0 && fz < h.dims[2]) {
             const uint32_t key = ((uint32_t)fz * (uint32_t)h.dims[1] + (uint32_t)fy) * (uint32_t)h.dims[0] + (uint32_t)fx;
-            const uint32_t nc = cell_start[key + 1] - cell_start[key];
+            const uint32_t nc = lv.cell_start[0][key + 1] - lv.cell_start[0][key];
             if (nc >= 4u * (uint32_t)K) seed = (float)(h.cell * h.cell) * (2.0f * (float)K / (3.14159265f * (float)nc));
         }
     }
-    ring_knn_pass<K>(h, pts, cell_start, qx, qy, qz, max_sq, seed, L);
+    ring_knn_pass<K>(lv, qx, qy, qz, max_sq, seed, L);
     if (seed < 3.0e38f && (uint32_t)L.k[K - 1] == 0xffffffffu)      // the seed radius held fewer than K points: exact redo
-        ring_knn_pass<K>(h, pts, cell_start, qx, qy, qz, max_sq, 3.0e38f, L);
+        ring_knn_pass<K>(lv, qx, qy, qz, max_sq, 3.0e38f, L);
 #pragma unroll
     for (int i = 0; i < K; ++i) if ((uint32_t)L.k[i] == 0xffffffffu) L.k[i] = ~0ull;   // unfilled slots
+}
+
+__device__ __forceinline__ GridLevels one_level(const GridView& g) {
+    GridLevels lv;
+    lv.hdr[0] = lv.hdr[1] = lv.hdr[2] = g.hdr; lv.pts[0] = lv.pts[1] = lv.pts[2] = g.pts;
+    lv.cell_start[0] = lv.cell_start[1] = lv.cell_start[2] = g.cell_start; lv.n = 1;
+    return lv;
 }
 
 // ------------------------------------------------------------------------------
@@ -180,15 +213,22 @@ __device__ inline void sym3_eig(const double A[6] /* xx xy xz yy yz zz */, doubl
 // ------------------------------------------------------------------------------
 static constexpr int kCovK = 20;
 
-__global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, const float* __restrict__ orig, uint32_t stride, uint32_t n_sorted_max,
-                                                        double* __restrict__ cov6) {
+__global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
+                                                        uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6) {
     const GridHeader h = *g.hdr;
     if (h.empty || h.overflow) return;
+    GridLevels lv;
+    lv.hdr[0] = g.hdr; lv.pts[0] = g.pts; lv.cell_start[0] = g.cell_start;
+    lv.hdr[1] = g1.hdr; lv.pts[1] = g1.pts; lv.cell_start[1] = g1.cell_start;
+    lv.hdr[2] = g2.hdr; lv.pts[2] = g2.pts; lv.cell_start[2] = g2.cell_start;
+    lv.n = n_levels;
+    if (n_levels > 1 && (g1.hdr->overflow || g1.hdr->empty)) lv.n = 1;
+    if (n_levels > 2 && (g2.hdr->overflow || g2.hdr->empty)) lv.n = min(lv.n, 2);
     const uint32_t n = g.cell_start[h.n_cells];   // points actually indexed (finite ones)
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n && j < n_sorted_max; j += gridDim.x * 256) {
         const float4 q = g.pts[j];
         KeyList<kCovK> L;
-        ring_knn<kCovK>(h, g.pts, g.cell_start, q.x, q.y, q.z, 3.0e38f, L);
+        ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L);
         // fast_gicp_impl.hpp:255-262: neighbours as f64, minus their mean, N N^T / k
         double mx = 0, my = 0, mz = 0;
         int found = 0;
@@ -237,65 +277,51 @@ __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, const float*
 
 // ------------------------------------------------------------------------------
 // V3: Gaussian voxel map.  Reference voxel coordinate c = floor(x/res - 0.5)
-// (fast_vgicp_voxel.hpp:158-160): the voxel lattice is the index grid shifted by half a cell,
-// so voxel v (local index c - org + 1, in [0, dims]) overlaps the 8 grid cells {v-1, v}^3.
-// One thread per voxel scans those cells and keeps the points whose coordinate is c.
+// (fast_vgicp_voxel.hpp:158-160): the target index is built on exactly that lattice
+// (GridHeader.shift = 0.5), so a voxel IS a cell and its points are one contiguous run.
+// One thread per sorted point; the thread of a cell's first point folds the run and stores the
+// voxel at that position (no slot table, no counter).
 // Sums are fixed point (2^44 per unit), hence independent of the order of the points.
 // ------------------------------------------------------------------------------
 static constexpr double kFix = 17592186044416.0;   // 2^44
 
-__global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const float* __restrict__ orig_unused, const double* __restrict__ cov6,
-                                                          uint32_t* __restrict__ vox_slot, uint64_t slot_capacity,
-                                                          VgicpVoxel* __restrict__ vox, uint32_t* __restrict__ vox_count) {
+__device__ __forceinline__ bool lattice_key(const GridHeader& h, double x, double y, double z, uint32_t* key, double c[3]) {
+    c[0] = floor(x / h.cell - h.shift); c[1] = floor(y / h.cell - h.shift); c[2] = floor(z / h.cell - h.shift);
+    const double vx = c[0] - h.org[0], vy = c[1] - h.org[1], vz = c[2] - h.org[2];
+    if (!(vx >= 0.0 && vx < (double)h.dims[0] && vy >= 0.0 && vy < (double)h.dims[1] && vz >= 0.0 && vz < (double)h.dims[2])) return false;
+    *key = ((uint32_t)vz * (uint32_t)h.dims[1] + (uint32_t)vy) * (uint32_t)h.dims[0] + (uint32_t)vx;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const double* __restrict__ cov6, VgicpVoxel* __restrict__ vox) {
     const GridHeader h = *g.hdr;
-    if (h.overflow) return;
-    const uint64_t v0 = (uint64_t)h.dims[0] + 1, v1 = (uint64_t)h.dims[1] + 1, v2 = (uint64_t)h.dims[2] + 1;
-    const uint64_t total = v0 * v1 * v2;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total && t < slot_capacity; t += (uint64_t)gridDim.x * 256) {
-        const int vx = (int)(t % v0), vy = (int)((t / v0) % v1), vz = (int)(t / (v0 * v1));
-        // reference coordinate of this voxel and its lower corner
-        const double cxr = h.org[0] + vx - 1, cyr = h.org[1] + vy - 1, czr = h.org[2] + vz - 1;
-        const double ox = (cxr + 0.5) * h.cell, oy = (cyr + 0.5) * h.cell, oz = (czr + 0.5) * h.cell;
+    if (h.overflow || h.empty) return;
+    const uint32_t n = g.cell_start[h.n_cells];
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const float4 q = g.pts[j];
+        uint32_t key;
+        double c[3];
+        if (!lattice_key(h, (double)q.x, (double)q.y, (double)q.z, &key, c)) continue;
+        if (g.cell_start[key] != j) continue;                 // not the first point of its voxel
+        const uint32_t e = g.cell_start[key + 1];
+        const double ox = (c[0] + h.shift) * h.cell, oy = (c[1] + h.shift) * h.cell, oz = (c[2] + h.shift) * h.cell;   // lower corner
         long long sm[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
-        uint32_t cnt = 0;
-        if (!h.empty) {
-            for (int dz = -1; dz <= 0; ++dz) {
-                const int z = vz + dz;
-                if (z < 0 || z >= h.dims[2]) continue;
-                for (int dy = -1; dy <= 0; ++dy) {
-                    const int y = vy + dy;
-                    if (y < 0 || y >= h.dims[1]) continue;
-                    const int xa = max(vx - 1, 0), xb = min(vx, h.dims[0] - 1);
-                    if (xa > xb) continue;
-                    const uint32_t row = ((uint32_t)z * (uint32_t)h.dims[1] + (uint32_t)y) * (uint32_t)h.dims[0];
-                    const uint32_t s = g.cell_start[row + xa], e = g.cell_start[row + xb + 1];
-                    for (uint32_t j = s; j < e; ++j) {
-                        const float4 p = g.pts[j];
-                        const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
-                        if (floor(px / h.cell - 0.5) == cxr && floor(py / h.cell - 0.5) == cyr && floor(pz / h.cell - 0.5) == czr) {
-                            ++cnt;
-                            sm[0] += llrint((px - ox) * kFix); sm[1] += llrint((py - oy) * kFix); sm[2] += llrint((pz - oz) * kFix);
-                            const double* c = cov6 + (size_t)__float_as_uint(p.w) * 6;
+        for (uint32_t i = j; i < e; ++i) {
+            const float4 p = g.pts[i];
+            sm[0] += llrint(((double)p.x - ox) * kFix); sm[1] += llrint(((double)p.y - oy) * kFix); sm[2] += llrint(((double)p.z - oz) * kFix);
+            const double* cc = cov6 + (size_t)__float_as_uint(p.w) * 6;
 #pragma unroll
-                            for (int k = 0; k < 6; ++k) sc[k] += llrint(c[k] * kFix);
-                        }
-                    }
-                }
-            }
+            for (int k = 0; k < 6; ++k) sc[k] += llrint(cc[k] * kFix);
         }
-        uint32_t slot = 0;
-        if (cnt) {
-            slot = atomicAdd(vox_count, 1u) + 1;   // placement only; the stored values do not depend on it
-            VgicpVoxel v;
-            const double inv = 1.0 / (double)cnt;
-            v.mean[0] = ox + (double)sm[0] / kFix * inv; v.mean[1] = oy + (double)sm[1] / kFix * inv; v.mean[2] = oz + (double)sm[2] / kFix * inv;
+        const uint32_t cnt = e - j;
+        VgicpVoxel v;
+        const double inv = 1.0 / (double)cnt;
+        v.mean[0] = ox + (double)sm[0] / kFix * inv; v.mean[1] = oy + (double)sm[1] / kFix * inv; v.mean[2] = oz + (double)sm[2] / kFix * inv;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v.cov[k] = (double)sc[k] / kFix * inv;
-            v.w = sqrt((double)cnt);   // fast_vgicp_impl.hpp:149
-            v.n = cnt;
-            vox[slot - 1] = v;
-        }
-        vox_slot[t] = slot;
+        for (int k = 0; k < 6; ++k) v.cov[k] = (double)sc[k] / kFix * inv;
+        v.w = sqrt((double)cnt);   // fast_vgicp_impl.hpp:149
+        v.n = cnt; v.pad = 0;
+        vox[j] = v;
     }
 }
 
@@ -311,14 +337,13 @@ __device__ __forceinline__ void inv3_sym(const double S[6], double M[6]) {
     M[3] = (a * f - c * c) * id; M[4] = (b * c - a * e) * id; M[5] = (a * d - b * b) * id;
 }
 
-__device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint32_t* __restrict__ vox_slot, uint64_t slot_capacity,
-                                                 const double tp[3]) {
+__device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint32_t* __restrict__ cell_start, const double tp[3]) {
     if (h.overflow || h.empty) return 0;
-    const double vx = floor(tp[0] / h.cell - 0.5) - h.org[0] + 1.0, vy = floor(tp[1] / h.cell - 0.5) - h.org[1] + 1.0,
-                 vz = floor(tp[2] / h.cell - 0.5) - h.org[2] + 1.0;
-    if (!(vx >= 0.0 && vx <= (double)h.dims[0] && vy >= 0.0 && vy <= (double)h.dims[1] && vz >= 0.0 && vz <= (double)h.dims[2])) return 0;
-    const uint64_t t = ((uint64_t)vz * ((uint64_t)h.dims[1] + 1) + (uint64_t)vy) * ((uint64_t)h.dims[0] + 1) + (uint64_t)vx;
-    return t < slot_capacity ? vox_slot[t] : 0;
+    uint32_t key;
+    double c[3];
+    if (!lattice_key(h, tp[0], tp[1], tp[2], &key, c)) return 0;
+    const uint32_t s = cell_start[key], e = cell_start[key + 1];
+    return e > s ? s + 1 : 0;
 }
 
 static constexpr int kLinStride = 258;
@@ -340,7 +365,7 @@ __global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a,
             double tp[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
-            const uint32_t slot = vgicp_lookup(h, a.vox_slot, a.slot_capacity, tp);
+            const uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
             a.corr_slot[i] = slot;
             if (slot) {
                 const VgicpVoxel vx = a.vox[slot - 1];
@@ -461,7 +486,6 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
                                                       const PoseF16 T, float max_range, double* __restrict__ partials) {
     __shared__ double sh[256];
     __shared__ double shc[256];
-    const GridHeader h = *g.hdr;
     double acc = 0.0, cnt = 0.0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_src; i += gridDim.x * 256) {
         const float* p = src + (size_t)i * stride;
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
         const float qy = T.m[1] * p[0] + T.m[5] * p[1] + T.m[9] * p[2] + T.m[13];
         const float qz = T.m[2] * p[0] + T.m[6] * p[1] + T.m[10] * p[2] + T.m[14];
         KeyList<1> L;
-        ring_knn<1>(h, g.pts, g.cell_start, qx, qy, qz, max_range, L);
+        ring_knn<1>(one_level(g), qx, qy, qz, max_range, L);
         if (L.k[0] != ~0ull) {
             const float d = __uint_as_float((uint32_t)(L.k[0] >> 32));
             if (d <= max_range) { acc += (double)d; cnt += 1.0; }
@@ -488,19 +512,19 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
 }
 
 // ---- host launchers ---------------------------------------------------------------
-hipError_t vgicp_launch_cov(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, double* d_cov6, hipStream_t s) {
+hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
+                            size_t n, double* d_cov6, hipStream_t s) {
     const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
-    hipLaunchKernelGGL(vgicp_cov_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6);
+    const int levels = coarse1 ? (coarse2 ? 3 : 2) : 1;
+    hipLaunchKernelGGL(vgicp_cov_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
+                       coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6);
     return hipGetLastError();
 }
 
-hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, uint32_t* d_slot, uint64_t slot_capacity, VgicpVoxel* d_vox,
-                               uint32_t* d_count, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    const int blocks = (int)std::min<uint64_t>(65535, slot_capacity / 256 + 1);
-    hipLaunchKernelGGL(vgicp_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), (const float*)nullptr, d_cov6, d_slot, slot_capacity, d_vox,
-                       d_count);
+hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s) {
+    const size_t n = grid.n_points;
+    const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
+    hipLaunchKernelGGL(vgicp_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_cov6, d_vox);
     return hipGetLastError();
 }
 
