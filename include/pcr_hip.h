@@ -140,6 +140,11 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
 int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
                         const double pose[16], double H[36], double b[6], double* error, int64_t* n_corr);
 
+/* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
+ * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
+ * accumulation done, partial sums stored.  out receives [launches][blocks][8] u64; call with out = NULL to size it. */
+int pcr_get_timeline(pcr_handle* h, uint64_t* out, size_t capacity, int* launches, int* blocks);
+
 /* NDT introspection: one computeDerivatives pass (ndt_omp_impl.hpp:180-285) at the parameter vector
  * p = [tx ty tz, roll pitch yaw] (Translation * Rx * Ry * Rz, ndt_omp_impl.hpp:146-149) against the current
  * target (pcr_set_target): score, gradient (6), Hessian (36, row-major) and, when hess_d != NULL, the

@@ -64,12 +64,13 @@ struct pcr_handle {
     const float* tgt_ptr = nullptr;   // device pointer the index was built from (for rebuild on overflow)
     size_t tgt_n = 0, tgt_stride = 0;
     bool have_target = false;
+    uint32_t last_blocks = 0;        // linearisation blocks of the last LOAM call (timeline readout)
     // source
     DeviceBuf src_stage;
     QuerySorter sorter;
 
     // LOAM work memory
-    DeviceBuf loam_state, loam_partials, loam_trace, loam_reduced, dbg_status, dbg_rows, dbg_nn, nn_cache, q_cache;
+    DeviceBuf loam_state, loam_partials, loam_trace, loam_reduced, dbg_status, dbg_rows, dbg_nn, nn_cache, q_cache, timeline;
     LoamResult* result_host = nullptr;   // host-mapped, written by the finalize kernel
     LoamResult* result_dev = nullptr;
     std::vector<LoamTrace> trace_host;
@@ -145,10 +146,13 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
     a->partials = h->loam_partials.as<double>();
     a->reduced = nullptr;
     a->n_partials = loam_grid_blocks((uint32_t)n_src);
+    h->last_blocks = a->n_partials;
     a->trace = h->prm.record_trace ? h->loam_trace.as<LoamTrace>() : nullptr;
     a->result = h->result_dev;
     a->ablate = h->prm.reserved[0];
     if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 128) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
+    if (h->prm.reserved[3] == 1 && h->timeline.reserve((size_t)(std::max(1, h->prm.loam_iters) + 1) * kMaxPartials * 8 * sizeof(unsigned long long)) == hipSuccess)
+        a->timeline = h->timeline.as<unsigned long long>();
     a->use_tile = h->use_tile;
     for (int d = 0; d < 3; ++d) { a->tile_lo[d] = h->tile_lo[d]; a->tile_hi[d] = h->tile_hi[d]; }
 }
@@ -836,7 +840,7 @@ void pcr_destroy(pcr_handle* h) {
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
-    h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->q_cache.release();
+    h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->q_cache.release(); h->timeline.release();
     if (h->result_host) (void)hipHostFree(h->result_host);
     for (hipEvent_t e : h->ev_kernel) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -1062,6 +1066,21 @@ int pcr_get_trace_counts(pcr_handle* h, int64_t* cache_hits, int64_t* searches) 
         if (cache_hits) cache_hits[i] = h->trace_host[i].cache_hits;
         if (searches) searches[i] = h->trace_host[i].searches;
     }
+    return 0;
+}
+
+int pcr_get_timeline(pcr_handle* h, uint64_t* out, size_t capacity, int* launches, int* blocks) {
+    if (!h) return 1;
+    if (h->prm.reserved[3] != 1 || !h->timeline.p) return fail(h, "timeline not recorded: set pcr_params.reserved[3] = 1");
+    const int nl = std::max(1, h->prm.loam_iters), nb = (int)h->last_blocks;
+    if (launches) *launches = nl;
+    if (blocks) *blocks = nb;
+    if (!out) return 0;
+    if (capacity < (size_t)nl * nb * 8) return fail(h, "timeline buffer too small");
+    H_TRY(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < nl; ++l)
+        H_TRY(hipMemcpy(out + (size_t)l * nb * 8, h->timeline.as<unsigned long long>() + (size_t)l * kMaxPartials * 8, (size_t)nb * 8 * sizeof(uint64_t),
+                        hipMemcpyDeviceToHost));
     return 0;
 }
 

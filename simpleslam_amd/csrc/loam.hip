@@ -253,9 +253,10 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
 // ------------------------------------------------------------------------------
 struct NnCacheEntry {          // 128 bytes per scan point
     float4 nb[5];              // the 5 neighbours in (distance, index) order: x y z | original index bits
-    float q0[3];               // query position the entry refers to            } the only 16 bytes that change while
-    float l6;                  // lower bound (rounded down) of the squared     } the neighbours stay the same
-                               // distance from q0 to every OTHER target point
+    float q0[3];               // query position of the SEARCH that produced the entry (never moved afterwards: a bound
+                               // anchored there is at least as tight as one chained through the iterations, and a
+                               // hit then writes nothing back)
+    float l6;                  // lower bound (rounded down) of the DISTANCE from q0 to every OTHER target point
     double x[3];               // plane through them, A x = -1 (depends only on nb and their order)
     uint32_t flags;            // bit0: entry valid (5 real neighbours)  bit1: x valid  bit2: plane passed its validity gate
     uint32_t pad;
@@ -265,7 +266,7 @@ static_assert(sizeof(NnCacheEntry) == 128, "cache entry layout");
 // Distances from the new query to the cached neighbours; returns true when they are proven to be the exact
 // 5-NN (see above).  *ordered: they are still in (distance, index) order, so the cached plane is reusable bit for bit.
 __device__ __forceinline__ bool knn5_from_cache(const NnCacheEntry& ce, double qx, double qy, double qz, Knn5& s, double A[5][3],
-                                                float* l6_new, bool* ordered) {
+                                                bool* ordered) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const float4 p = ce.nb[j];
@@ -285,14 +286,12 @@ __device__ __forceinline__ bool knn5_from_cache(const NnCacheEntry& ce, double q
 #pragma unroll
         for (int j = 0; j < 4; ++j) r5sq = fmax(r5sq, s.d[j]);
     }
-    const float ex = (float)qx - ce.q0[0], ey = (float)qy - ce.q0[1], ez = (float)qz - ce.q0[2];
-    // single precision with 1e-6 relative margins on every term (rounding is < 2e-7)
-    const float delta = sqrtf(fmaf(ex, ex, fmaf(ey, ey, ez * ez))) * 1.000001f + 1e-7f;
-    const float r5 = sqrtf((float)r5sq) * 1.000001f;
-    const float l6 = sqrtf(ce.l6) * 0.999999f;
-    const float slack = l6 - delta;
-    *l6_new = slack > 0.f ? slack * slack * 0.999999f : 0.f;
-    return r5 < slack * 0.999999f;
+    // |p - q| >= |p - q0| - |q - q0| >= l6 - delta for every other target point p.  Double precision: the stored bound
+    // loses at most one float ulp, so only 5th/6th-neighbour gaps below ~1e-7 m fail to be proven.
+    const double ex = qx - (double)ce.q0[0], ey = qy - (double)ce.q0[1], ez = qz - (double)ce.q0[2];
+    const double delta = sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-12) + 1e-13;
+    const double slack = (double)ce.l6 - delta;
+    return slack > 0.0 && r5sq < slack * slack * (1.0 - 1e-12);
 }
 
 // 9-comparator sorting network on (distance, index) with the neighbour coordinates as payload
@@ -524,7 +523,8 @@ struct MissExchange {
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h, const double* __restrict__ pose,
                                           float sx, float sy, float sz, bool valid, const NnCacheEntry& ce_in, bool have_entry,
-                                          KnnShared& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how) {
+                                          KnnShared& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how,
+                                          unsigned long long* tl) {
     const double ox = (double)sx, oy = (double)sy, oz = (double)sz;
     // LoamRegister.cpp:126-130: Isometry3d * Vector4d in f64, then cast to f32
     const float px = (float)(pose[0] * ox + pose[4] * oy + pose[8] * oz + pose[12] * 1.0);
@@ -540,9 +540,8 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     Knn5 s;
     double A[5][3];
     bool searched = false, ordered = false;
-    float l6f = 0.f;
     const bool have_seed = have_entry && active && (ce_in.flags & 1u);
-    if (have_seed) searched = knn5_from_cache(ce_in, qx, qy, qz, s, A, &l6f, &ordered);
+    if (have_seed) searched = knn5_from_cache(ce_in, qx, qy, qz, s, A, &ordered);
     const bool hit = searched;
     double l6 = 0.0;
     const int tid = threadIdx.x;
@@ -560,6 +559,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         ex.seed[tid] = sb;
     }
     __syncthreads();
+    if (tl) tl[2] = wall_clock64();
     // ---- the posted queries are searched: a few -> one wave per query (lanes = candidates); many -> thread m
     //      serves the m-th posted query (lanes = queries) ----
     {
@@ -603,6 +603,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         }
     }
     __syncthreads();
+    if (tl) tl[3] = wall_clock64();
     bool real5 = hit;     // five real neighbours present
     if (miss) {
 #pragma unroll
@@ -647,22 +648,22 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     }
     // ---- remember everything for the next iteration ----
     if (a.nn_cache && active) {
-        const float l6s = hit ? l6f : (float)l6 * 0.999999f;
         if (reuse) {
-            // neighbours, order and plane unchanged: only the query position and its bound move (16 of the 128 bytes)
-            *reinterpret_cast<float4*>(&a.nn_cache[qi].q0[0]) = make_float4(px, py, pz, l6s);
+            // neighbours, order and plane unchanged: the entry stays as it is
         } else {
             NnCacheEntry ce;
 #pragma unroll
             for (int j = 0; j < 5; ++j) ce.nb[j] = make_float4((float)A[j][0], (float)A[j][1], (float)A[j][2], __uint_as_float(s.idx[j]));
             ce.x[0] = x[0]; ce.x[1] = x[1]; ce.x[2] = x[2];
-            ce.q0[0] = px; ce.q0[1] = py; ce.q0[2] = pz;
-            ce.l6 = l6s;
+            // a hit whose order changed keeps the anchor of its search
+            ce.q0[0] = hit ? ce_in.q0[0] : px; ce.q0[1] = hit ? ce_in.q0[1] : py; ce.q0[2] = hit ? ce_in.q0[2] : pz;
+            ce.l6 = hit ? ce_in.l6 : __double2float_rd(sqrt(l6) * (1.0 - 1e-15));
             ce.flags = (real5 ? 1u : 0u) | ((real5 && !(a.ablate & 2)) ? 2u : 0u) | (plane_ok ? 4u : 0u);
             ce.pad = 0;
             a.nn_cache[qi] = ce;
         }
     }
+    if (tl) tl[4] = wall_clock64();
     if (!valid) return 4;
     if (!searched) return 1;
 #pragma unroll
@@ -696,7 +697,7 @@ struct Prologue {
     int done;
 };
 
-__device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 */, Prologue* sh) {
+__device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 */, Prologue* sh, unsigned long long* tl = nullptr) {
     const LoamState* prev = &a.state[(k + 1) & 1];
     LoamState* cur = &a.state[k & 1];
     const int t = threadIdx.x;
@@ -751,6 +752,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     sh_sum[slice * 32 + comp] = acc;
     if (t < 16) sh->pose[t] = prev_pose_t;
     __syncthreads();
+    if (tl) tl[7] = wall_clock64();
     if (t < 32) {
         double v = sh_sum[t];
 #pragma unroll
@@ -838,6 +840,8 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
     __shared__ MissExchange sh_ex;               // also holds the rows: [component][point] s*J (6), s*d, accepted flag
     double* const sh_rows = sh_ex.u.rows;
     const int tid = threadIdx.x;
+    unsigned long long* const tl = (a.timeline && tid == 0) ? a.timeline + ((size_t)k * kMaxPartials + blockIdx.x) * 8 : nullptr;
+    if (tl) tl[0] = wall_clock64();
     // XCD-aware mapping: consecutive logical blocks (adjacent lidar rings) share an XCD's L2
     uint32_t blk = blockIdx.x;
     if ((gridDim.x & 7u) == 0) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -855,7 +859,8 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
             if (use_cache) pre_ce = a.nn_cache[q];
         }
     }
-    if (loam_prologue(a, k, sh_sum, &sh_pro)) return;
+    if (loam_prologue(a, k, sh_sum, &sh_pro, tl)) return;
+    if (tl) tl[1] = wall_clock64();
     const GridHeader h = *a.grid.hdr;
     double pose[16];
 #pragma unroll
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
                 if (use_cache) ce = a.nn_cache[q];
             }
         }
-        const int st = loam_point(a, h, pose, sx, sy, sz, valid, ce, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how);
+        const int st = loam_point(a, h, pose, sx, sy, sz, valid, ce, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const float* spq = a.src + (size_t)q * a.src_stride;
             const size_t oi = a.src_indexed ? (size_t)__float_as_uint(spq[3]) : (size_t)q;   // original scan index
@@ -913,6 +918,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         }
         __syncthreads();
     }
+    if (tl) tl[5] = wall_clock64();
     sh_sum[ch * 32 + e] = e < 28 ? acc : 0.0;
     // statistics ride in the two spare components (exact small integers in f64)
     __shared__ uint32_t sh_cnt[2];
@@ -929,6 +935,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         if (tid == 29) v = (double)sh_cnt[1];
         a.partials[((size_t)(k & 1) * kMaxPartials + blockIdx.x) * kAccum + tid] = v;
     }
+    if (tl) tl[6] = wall_clock64();
 }
 
 // last launch: prologue only, then T2SE3 and the output pose (LoamRegister.cpp:220)

@@ -103,6 +103,8 @@ struct LoamArgs {
     // profiling aid (pcr_params.reserved[0]): skip phases to price them.  bit0: candidate loop,
     // bit1: plane fit and everything after it, bit2: prologue solve.  Results are then meaningless.
     int32_t ablate;
+    // profiling aid (pcr_params.reserved[3] = 1): [launch][block][8] s_memrealtime stamps (100 MHz) taken by thread 0
+    unsigned long long* timeline;
 };
 
 // host-side launchers (grid_index.hip / loam.hip)

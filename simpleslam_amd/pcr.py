@@ -48,7 +48,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
-    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load_library():
     L.pcr_vgicp_covariances.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.pcr_vgicp_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.pcr_ndt_derivatives.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, dp]
+    L.pcr_get_timeline.argtypes = [vp, vp, C.c_size_t, ip, ip]
     L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
     L.pcr_set_profile.argtypes = [vp, C.c_int]
     L.pcr_set_stream.argtypes = [vp, vp]
@@ -263,6 +264,16 @@ class LoamRegister(PointCloudRegister):
         hits, srch = np.zeros(it, np.int64), np.zeros(it, np.int64)
         self._check(self._lib.pcr_get_trace_counts(self._h, vp(hits), vp(srch)))
         return dict(iters_run=k, JtJ=JtJ[:k].reshape(-1, 6, 6), JtE=JtE[:k], n=n[:k], x=x[:k], cache_hits=hits[:k], searches=srch[:k])
+
+    def timeline(self):
+        """[launch][block][8] stamps in microseconds relative to each launch's earliest block entry
+        (needs pcr_params.reserved[3] = 1).  Columns: entry, prologue, posted, searched, plane, accumulated, stored, partial sums folded (inside the prologue)."""
+        nl, nb = C.c_int(0), C.c_int(0)
+        self._check(self._lib.pcr_get_timeline(self._h, None, 0, C.byref(nl), C.byref(nb)))
+        raw = np.zeros((nl.value, nb.value, 8), np.uint64)
+        self._check(self._lib.pcr_get_timeline(self._h, raw.ctypes.data_as(C.c_void_p), raw.size, C.byref(nl), C.byref(nb)))
+        t = raw.astype(np.int64)
+        return (t - t[:, :, :1].min(axis=1, keepdims=True)) / 100.0
 
 
 class NdtRegister(PointCloudRegister):
