@@ -120,14 +120,16 @@ __device__ __forceinline__ bool knn_advance(KnnCursor& c, const KnnShared& sh, K
 
 // Rare path: exact distance ties.  Plain sequential scan of the 3x3x3 block with the full
 // (distance, original index) order; kept out of line so that it costs the hot path nothing.
-__device__ __noinline__ void knn5_resolve_ties(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+// (The grid geometry is passed by value: handing over a reference to the kernel's GridHeader would force that copy
+// into scratch memory -- seven vector loads, seven scratch stores and a memory round trip in EVERY launch.)
+__device__ __noinline__ void knn5_resolve_ties(double org_x, double org_y, double org_z, double inv_cell, uint32_t dim0, uint32_t dim1,
+                                               const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
                                                double qx, double qy, double qz, double max_sq, Knn5& s) {
     double d5[5]; uint32_t i5[5], p5[5];
     for (int j = 0; j < 5; ++j) { d5[j] = max_sq; i5[j] = 0xffffffffu; p5[j] = 0xffffffffu; }
-    const int cx = (int)floor((qx - h.origin[0]) * h.inv_cell), cy = (int)floor((qy - h.origin[1]) * h.inv_cell),
-              cz = (int)floor((qz - h.origin[2]) * h.inv_cell);
+    const int cx = (int)floor((qx - org_x) * inv_cell), cy = (int)floor((qy - org_y) * inv_cell), cz = (int)floor((qz - org_z) * inv_cell);
     for (int r = 0; r < 9; ++r) {
-        const uint32_t key = ((uint32_t)(cz + r / 3 - 1) * (uint32_t)h.dims[1] + (uint32_t)(cy + r % 3 - 1)) * (uint32_t)h.dims[0] + (uint32_t)cx;
+        const uint32_t key = ((uint32_t)(cz + r / 3 - 1) * dim1 + (uint32_t)(cy + r % 3 - 1)) * dim0 + (uint32_t)cx;
         for (uint32_t j = cell_start[key - 1]; j < cell_start[key + 2]; ++j) {
             const float4 p = pts[j];
             const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
@@ -235,7 +237,8 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
         }
         if (tie) {
             Knn5 fixed;     // a separate object: only this rare path lives in scratch memory
-            knn5_resolve_ties(h, pts, cell_start, qx, qy, qz, max_sq, fixed);
+            knn5_resolve_ties(h.origin[0], h.origin[1], h.origin[2], h.inv_cell, (uint32_t)h.dims[0], (uint32_t)h.dims[1], pts, cell_start, qx, qy, qz,
+                              max_sq, fixed);
             s = fixed;
         }
     }
@@ -697,7 +700,16 @@ struct Prologue {
     int done;
 };
 
-__device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 */, Prologue* sh, unsigned long long* tl = nullptr) {
+// 16 bytes per lane from global memory straight into LDS (lane i lands at lds_wave_base + 16 i); completion is
+// signalled on vmcnt like any load.
+__device__ __forceinline__ void lds_dma16(const float4* src, float4* lds_wave_base) {
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "m0", "memory");
+}
+
+// pre_src / pre_dst: this lane's 128-byte neighbour-cache entry and the wave's slice of the LDS staging area.
+__device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 */, Prologue* sh, unsigned long long* tl = nullptr,
+                              const float4* pre_src = nullptr, float4* pre_dst = nullptr) {
     const LoamState* prev = &a.state[(k + 1) & 1];
     LoamState* cur = &a.state[k & 1];
     const int t = threadIdx.x;
@@ -714,45 +726,54 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     // Request this thread's share of the previous launch's partial sums together with the state it guards
     // (one memory round trip instead of two); they are simply unused when the loop has already finished.
     const int comp = t & 31, slice = t >> 5;
+    // the state first: loads complete in issue order, so testing `done` then waits for nothing younger
+    const int prev_done = prev->done;
+    const double prev_pose_t = t < 16 ? prev->pose[t] : 0.0;
     double pv[32];
     {
         const double* part = a.partials + (size_t)((k + 1) & 1) * kMaxPartials * kAccum + comp;
+        const uint32_t last = a.n_partials ? a.n_partials - 1u : 0u;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             const uint32_t b = (uint32_t)slice + 8u * u;
-            pv[u] = (!a.reduced && b < a.n_partials) ? part[(size_t)b * kAccum] : 0.0;
+            pv[u] = part[(size_t)(b < last ? b : last) * kAccum];      // unconditional: rows past the end are masked in the fold
         }
     }
-    const int prev_done = prev->done;
-    const double prev_pose_t = t < 16 ? prev->pose[t] : 0.0;
+    // fixed-order reduction of the partial sums of launch k-1.  Straight-line code (selects, no branches): every
+    // conditional region here made the compiler either sink the loads below it or wait for all of them at its join.
+    const double* const part0 = a.partials + (size_t)((k + 1) & 1) * kMaxPartials * kAccum + comp;
+    const double red = *(a.reduced ? a.reduced + comp : part0);       // sharded mode: sums already all-reduced
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc += ((uint32_t)slice + 8u * u < a.n_partials) ? pv[u] : 0.0;
+    for (uint32_t b = (uint32_t)slice + 256u; b < a.n_partials; b += 8) acc += part0[(size_t)b * kAccum];   // > 256 blocks
+    if (a.reduced) acc = slice == 0 ? red : 0.0;
+    sh_sum[slice * 32 + comp] = acc;
+    if (t < 16) sh->pose[t] = prev_pose_t;
+    __syncthreads();
+    if (tl) tl[7] = wall_clock64();
+    // The partial sums have arrived: now fetch this lane's neighbour-cache entry, straight into LDS, while the normal
+    // equations are solved.  Issued from inline asm on purpose: the compiler's wait-count bookkeeping treats an LDS-DMA
+    // in flight as "wait for everything" at every barrier and at every use of any other load; the consumer waits by hand.
+    if (pre_dst) {
+        const float4* src = pre_src ? pre_src : reinterpret_cast<const float4*>(a.partials) + (size_t)t * 8;   // harmless address
+#pragma unroll
+        for (int f = 0; f < 8; ++f) lds_dma16(src + f, pre_dst + f * 256);
+    }
+    // (the tests of the previous state come only now: placed before the loads above they made the compiler sink the
+    // partial-sum loads below the branch, i.e. two dependent round trips instead of one)
     if (prev_done) {
-        if (t < 16) sh->pose[t] = prev_pose_t;
         if (t == 0) sh->done = 1;
         if (blockIdx.x == 0 && t == 0) { *cur = *prev; }
         __syncthreads();
         return true;
     }
     if (a.ablate & 4) {
-        if (t < 16) sh->pose[t] = prev_pose_t;
         if (t == 0) sh->done = k >= a.c.iters;
         if (blockIdx.x == 0 && t == 0) { *cur = *prev; cur->done = k >= a.c.iters; cur->iters_run = k; }
         __syncthreads();
         return k >= a.c.iters;
     }
-    // fixed-order reduction of the partial sums of launch k-1
-    double acc = 0.0;
-    if (a.reduced) {
-        if (slice == 0) acc = a.reduced[comp];
-    } else {
-#pragma unroll
-        for (int u = 0; u < 32; ++u) acc += pv[u];
-        const double* part = a.partials + (size_t)((k + 1) & 1) * kMaxPartials * kAccum + comp;
-        for (uint32_t b = (uint32_t)slice + 256u; b < a.n_partials; b += 8) acc += part[(size_t)b * kAccum];   // > 256 blocks
-    }
-    sh_sum[slice * 32 + comp] = acc;
-    if (t < 16) sh->pose[t] = prev_pose_t;
-    __syncthreads();
-    if (tl) tl[7] = wall_clock64();
     if (t < 32) {
         double v = sh_sum[t];
 #pragma unroll
@@ -845,23 +866,28 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
     // XCD-aware mapping: consecutive logical blocks (adjacent lidar rings) share an XCD's L2
     uint32_t blk = blockIdx.x;
     if ((gridDim.x & 7u) == 0) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    // Everything the first round needs from memory is requested BEFORE the prologue, so that the scan point and
+    // Everything the first round needs from memory is requested before/inside the prologue, so that the scan point and
     // the 128-byte neighbour-cache entry arrive while the previous iteration's normal equations are being solved.
+    // The entry goes straight to LDS ([field][thread], 32 KB): held in registers it was spilled to AGPRs, which made
+    // the wave wait for it before the prologue had even started.
+    __shared__ float4 sh_pre[8 * 256];
+    const GridHeader h = *a.grid.hdr;      // uniform: scalar loads, in flight during the prologue
     float pre_x = 0.f, pre_y = 0.f, pre_z = 0.f;
-    NnCacheEntry pre_ce;
-    pre_ce.flags = 0;
     const bool use_cache = k > 0 && a.nn_cache != nullptr;
+    const float4* pre_src = nullptr;
     {
         const uint32_t q = blk * 256 + tid;
-        if (q < a.n_src) {
-            const float* sp = a.src + (size_t)q * a.src_stride;
-            pre_x = sp[0]; pre_y = sp[1]; pre_z = sp[2];
-            if (use_cache) pre_ce = a.nn_cache[q];
-        }
+        // unconditional load of a clamped index: a conditional one makes the wave wait for it at the join
+        const float* sp = a.n_src ? a.src + (size_t)(q < a.n_src ? q : a.n_src - 1u) * a.src_stride
+                                  : reinterpret_cast<const float*>(a.partials);      // empty scan: any readable address
+        pre_x = sp[0]; pre_y = sp[1]; pre_z = sp[2];
+        pre_src = (use_cache && q < a.n_src) ? reinterpret_cast<const float4*>(a.nn_cache + q) : nullptr;
     }
-    if (loam_prologue(a, k, sh_sum, &sh_pro, tl)) return;
+    if (loam_prologue(a, k, sh_sum, &sh_pro, tl, pre_src, use_cache ? sh_pre + (tid & ~63) : nullptr)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // never leave with an LDS-DMA in flight
+        return;
+    }
     if (tl) tl[1] = wall_clock64();
-    const GridHeader h = *a.grid.hdr;
     double pose[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) pose[i] = sh_pro.pose[i];
@@ -888,16 +914,23 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         uint32_t nn[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         int how = 0;
         float sx = pre_x, sy = pre_y, sz = pre_z;
-        NnCacheEntry ce = pre_ce;
-        if (base != blk * 256) {      // later rounds of a grid-stride launch
-            ce.flags = 0; sx = sy = sz = 0.f;
+        union { NnCacheEntry e; float4 v[8]; } ce;
+        ce.e.flags = 0;
+        if (base == blk * 256) {
+            if (use_cache && valid) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own LDS-DMA writes
+#pragma unroll
+                for (int f = 0; f < 8; ++f) ce.v[f] = sh_pre[f * 256 + tid];
+            }
+        } else {                      // later rounds of a grid-stride launch
+            sx = sy = sz = 0.f;
             if (valid) {
                 const float* sp = a.src + (size_t)q * a.src_stride;
                 sx = sp[0]; sy = sp[1]; sz = sp[2];
-                if (use_cache) ce = a.nn_cache[q];
+                if (use_cache) ce.e = a.nn_cache[q];
             }
         }
-        const int st = loam_point(a, h, pose, sx, sy, sz, valid, ce, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
+        const int st = loam_point(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const float* spq = a.src + (size_t)q * a.src_stride;
             const size_t oi = a.src_indexed ? (size_t)__float_as_uint(spq[3]) : (size_t)q;   // original scan index
@@ -909,7 +942,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
         for (int c = 0; c < 7; ++c) sh_rows[c * kRowStride + tid] = st == 0 ? row[c] : 0.0;
         sh_rows[7 * kRowStride + tid] = st == 0 ? 1.0 : 0.0;
         __syncthreads();
-        n_hit += how == 1; n_search += how == 2;
+        n_hit += (uint32_t)__popcll(__ballot(how == 1)); n_search += (uint32_t)__popcll(__ballot(how == 2));   // per wave
         if (e < 28) {
             const double* ra = sh_rows + er * kRowStride + ch * 32;
             const double* rb = sh_rows + ec * kRowStride + ch * 32;
@@ -921,18 +954,15 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
     if (tl) tl[5] = wall_clock64();
     sh_sum[ch * 32 + e] = e < 28 ? acc : 0.0;
     // statistics ride in the two spare components (exact small integers in f64)
-    __shared__ uint32_t sh_cnt[2];
-    if (tid == 0) { sh_cnt[0] = 0; sh_cnt[1] = 0; }
-    __syncthreads();
-    if (n_hit) atomicAdd(&sh_cnt[0], n_hit);
-    if (n_search) atomicAdd(&sh_cnt[1], n_search);
+    __shared__ uint32_t sh_cnt[8];
+    if ((tid & 63) == 0) { sh_cnt[(tid >> 6) * 2] = n_hit; sh_cnt[(tid >> 6) * 2 + 1] = n_search; }
     __syncthreads();
     if (tid < 32) {
         double v = sh_sum[tid];
 #pragma unroll
         for (int c = 1; c < 8; ++c) v += sh_sum[c * 32 + tid];
-        if (tid == 28) v = (double)sh_cnt[0];
-        if (tid == 29) v = (double)sh_cnt[1];
+        if (tid == 28) v = (double)(sh_cnt[0] + sh_cnt[2] + sh_cnt[4] + sh_cnt[6]);
+        if (tid == 29) v = (double)(sh_cnt[1] + sh_cnt[3] + sh_cnt[5] + sh_cnt[7]);
         a.partials[((size_t)(k & 1) * kMaxPartials + blockIdx.x) * kAccum + tid] = v;
     }
     if (tl) tl[6] = wall_clock64();
