@@ -3,8 +3,9 @@
 // Replaces the reference's per-call kd-tree build, Kdtree::setInputCloud ->
 // nanoflann buildIndex (reference PCR/src/LoamRegister.cpp:110,
 // third_parties/nanoflann/include/nanoflann/nanoflann.hpp:1542-1564): a serial
-// O(N log N) recursive split there, five streaming passes here:
-//   bbox partials -> header + clear -> histogram -> 3-step exclusive scan -> scatter.
+// O(N log N) recursive split there, five launches here:
+//   bbox partials (+ header, by the last block to finish) -> histogram with ranks -> exclusive scan of the cell
+//   counters in two launches (the first also re-zeroes the counters for the next build) -> scatter.
 // Algorithmic traffic: 16 B read + 16 B written per target point.
 // Everything is enqueued on one stream with no host synchronisation; the grid
 // geometry lives in a device-side GridHeader that the later kernels read.
@@ -28,9 +29,11 @@ __device__ inline float wave_max(float v) {
     return v;
 }
 
-// ---- 1. per-block bounding boxes -------------------------------------------
-__global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
-                                                        float* __restrict__ partials) {
+// ---- 1. per-block bounding boxes; the last block to finish turns them into the header ----------------
+// (one launch instead of two; the cell counters are NOT cleared here: every build leaves them zeroed, see the scan)
+__global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
+                                                               float* __restrict__ partials, uint32_t* __restrict__ ticket,
+                                                               GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float* p = pts + (size_t)i * stride;
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict_
         }
     }
     __shared__ float sh[4][6];
+    __shared__ uint32_t sh_last;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -52,35 +56,36 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict_
     if (threadIdx.x < 6) {
         float v = sh[0][threadIdx.x];
         for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
-        partials[blockIdx.x * 6 + threadIdx.x] = v;
+        __hip_atomic_store(&partials[blockIdx.x * 6 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// ---- 2. header (every block, redundantly) + clear of the cell counters -------
-__global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __restrict__ partials, int n_partials,
-                                                                GridHeader* __restrict__ hdr, uint32_t* __restrict__ cell_count,
-                                                                uint64_t capacity, double cell, double shift, uint32_t n_points) {
-    __shared__ float sh[4][6];
-    __shared__ uint64_t sh_ncells;
-    __shared__ int sh_bad;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int b = threadIdx.x; b < n_partials; b += 256) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                       // partials visible device-wide before the ticket
+        sh_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __threadfence();
+    // ---- last block: fold the partial boxes (read past this XCD's L2) and write the header ----
+    float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            mn[d] = fminf(mn[d], partials[b * 6 + d]);
-            mx[d] = fmaxf(mx[d], partials[b * 6 + 3 + d]);
+            fmn[d] = fminf(fmn[d], __hip_atomic_load(&partials[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            fmx[d] = fmaxf(fmx[d], __hip_atomic_load(&partials[b * 6 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();     // sh is reused
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float a = wave_min(mn[d]), b = wave_max(mx[d]);
+        float a = wave_min(fmn[d]), b = wave_max(fmx[d]);
         if (lane == 0) { sh[wave][d] = a; sh[wave][3 + d] = b; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        *ticket = 0;                                           // ready for the next build
         GridHeader h;
-        h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n_points; h.shift = shift;
+        h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n; h.shift = shift;
         h.empty = 0; h.overflow = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
@@ -97,13 +102,8 @@ __global__ __launch_bounds__(256) void grid_header_clear_kernel(const float* __r
         // keys are uint32 and the table holds n_cells + 1 starts
         if (nc + 1.0 > (double)capacity || nc > 4.0e9) { h.overflow = 1; h.n_cells = nc < 1.8e19 ? (uint64_t)nc : ~0ull; }
         else h.n_cells = (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2];
-        if (blockIdx.x == 0) *hdr = h;
-        sh_ncells = h.n_cells; sh_bad = h.overflow;
+        *hdr = h;
     }
-    __syncthreads();
-    if (sh_bad) return;
-    const uint64_t total = sh_ncells + 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) cell_count[i] = 0;
 }
 
 __device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key) {
@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict
     }
 }
 
-// ---- 4. exclusive scan of the counters (three steps) ------------------------------
+// ---- 4. exclusive scan of the counters (two launches) -----------------------------------------
+// Tile = 2048 cells per block: thread t owns cells 4t..4t+3 of each 1024-cell half (one 16-byte access per half,
+// fully coalesced).  Launch A: tile-local exclusive scan -> cell_start, tile total -> block_sums, and the counters
+// are written back as ZERO, which is the state the next build's histogram expects (no separate clear pass).
+// Launch B: every block sums the totals of the tiles before it (a few thousand at most) and adds that offset.
 __device__ inline uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* sh /* >= 4 */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = v;
@@ -171,61 +175,46 @@ __device__ inline uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total,
     return off + inc - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void grid_scan_local_kernel(const uint32_t* __restrict__ cell_count,
+__global__ __launch_bounds__(kScanBlock) void grid_scan_local_kernel(uint32_t* __restrict__ cell_count,
                                                                     uint32_t* __restrict__ cell_start,
                                                                     uint32_t* __restrict__ block_sums,
                                                                     const GridHeader* __restrict__ hdr) {
-    __shared__ uint32_t sh[4];
+    __shared__ uint32_t sh[8];
     if (hdr->overflow) return;
     const uint64_t total = hdr->n_cells + 1;
-    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
-    if ((uint64_t)blockIdx.x * kScanTile >= total) return;
-    uint32_t v[kScanPerThread], s = 0;
-#pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) { v[j] = (base + j < total) ? cell_count[base + j] : 0u; s += v[j]; }
-    uint32_t tot;
-    uint32_t off = block_exclusive_scan_256(s, &tot, sh);
-#pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) { if (base + j < total) cell_start[base + j] = off; off += v[j]; }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(1024) void grid_scan_sums_kernel(uint32_t* __restrict__ block_sums,
-                                                              const GridHeader* __restrict__ hdr) {
-    __shared__ uint32_t sh_w[16];
-    if (hdr->overflow) return;
-    const uint64_t total = hdr->n_cells + 1;
-    const uint32_t nb = (uint32_t)((total + kScanTile - 1) / kScanTile);
-    const uint32_t per = (nb + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nb);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += block_sums[i];
-    // block-wide exclusive scan of s over 1024 threads (16 waves)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) sh_w[wave] = inc;
-    __syncthreads();
-    uint32_t off = 0;
-    for (int w = 0; w < wave; ++w) off += sh_w[w];
-    uint32_t run = off + inc - s;
-    for (uint32_t i = lo; i < hi; ++i) { uint32_t t = block_sums[i]; block_sums[i] = run; run += t; }
+    const uint64_t tile = (uint64_t)blockIdx.x * kScanTile;
+    if (tile >= total) return;
+    const uint64_t i0 = tile + (uint64_t)threadIdx.x * 4, i1 = i0 + kScanTile / 2;
+    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+    // (the tables are padded to a whole tile, so the 16-byte accesses never leave the allocation)
+    if (i0 < total) { a = *reinterpret_cast<const uint4*>(cell_count + i0); *reinterpret_cast<uint4*>(cell_count + i0) = make_uint4(0, 0, 0, 0); }
+    if (i1 < total) { b = *reinterpret_cast<const uint4*>(cell_count + i1); *reinterpret_cast<uint4*>(cell_count + i1) = make_uint4(0, 0, 0, 0); }
+    uint32_t ta, tb;
+    const uint32_t oa = block_exclusive_scan_256(a.x + a.y + a.z + a.w, &ta, sh);
+    const uint32_t ob = block_exclusive_scan_256(b.x + b.y + b.z + b.w, &tb, sh + 4) + ta;
+    if (i0 < total) *reinterpret_cast<uint4*>(cell_start + i0) = make_uint4(oa, oa + a.x, oa + a.x + a.y, oa + a.x + a.y + a.z);
+    if (i1 < total) *reinterpret_cast<uint4*>(cell_start + i1) = make_uint4(ob, ob + b.x, ob + b.x + b.y, ob + b.x + b.y + b.z);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ta + tb;
 }
 
 __global__ __launch_bounds__(kScanBlock) void grid_scan_add_kernel(uint32_t* __restrict__ cell_start,
                                                                   const uint32_t* __restrict__ block_sums,
                                                                   const GridHeader* __restrict__ hdr) {
+    __shared__ uint32_t sh[4];
     if (hdr->overflow) return;
     const uint64_t total = hdr->n_cells + 1;
-    if ((uint64_t)blockIdx.x * kScanTile >= total) return;
-    const uint32_t add = block_sums[blockIdx.x];
-    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
+    const uint64_t tile = (uint64_t)blockIdx.x * kScanTile;
+    if (tile >= total) return;
+    uint32_t part = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kScanBlock) part += block_sums[t];
 #pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) if (base + j < total) cell_start[base + j] += add;
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const uint32_t add = sh[0] + sh[1] + sh[2] + sh[3];
+    const uint64_t i0 = tile + (uint64_t)threadIdx.x * 4, i1 = i0 + kScanTile / 2;
+    if (i0 < total) { uint4 v = *reinterpret_cast<uint4*>(cell_start + i0); v.x += add; v.y += add; v.z += add; v.w += add; *reinterpret_cast<uint4*>(cell_start + i0) = v; }
+    if (i1 < total) { uint4 v = *reinterpret_cast<uint4*>(cell_start + i1); v.x += add; v.y += add; v.z += add; v.w += add; *reinterpret_cast<uint4*>(cell_start + i1) = v; }
 }
 
 // ---- 5. scatter into cell order (no atomics: position = cell start + rank) ---------------
@@ -261,7 +250,7 @@ void DeviceBuf::release() {
 
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
-    bbox_partials.release(); header.release(); keys.release(); ranks.release();
+    bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -273,8 +262,11 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
     const size_t want = (size_t)need_cells + need_cells / 2 + 4096;
     cell_count.release(); cell_start.release(); block_sums.release();
     hipError_t e;
-    if ((e = cell_count.reserve(want * sizeof(uint32_t))) != hipSuccess || (e = cell_start.reserve(want * sizeof(uint32_t))) != hipSuccess ||
-        (e = block_sums.reserve((want / kScanTile + 2) * sizeof(uint32_t))) != hipSuccess) {
+    // (+ one tile: the scan works on whole 16-byte groups)
+    if ((e = cell_count.reserve((want + kScanTile) * sizeof(uint32_t))) != hipSuccess ||
+        (e = cell_start.reserve((want + kScanTile) * sizeof(uint32_t))) != hipSuccess ||
+        (e = block_sums.reserve((want / kScanTile + 2) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(cell_count.p, 0, cell_count.cap)) != hipSuccess) {      // builds expect and leave the counters zeroed
         if (err) *err = std::string("hipMalloc of the cell table failed: ") + hipGetErrorString(e);
         cell_capacity = 0;
         return e;
@@ -293,27 +285,29 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     PCR_TRY(header.reserve(sizeof(GridHeader)));
     PCR_TRY(keys.reserve((n + 1) * sizeof(uint32_t)));
     PCR_TRY(ranks.reserve((n + 1) * sizeof(uint32_t)));
+    if (!ticket.p) {
+        PCR_TRY(ticket.reserve(256));
+        PCR_TRY(hipMemsetAsync(ticket.p, 0, 256, s));
+    }
     if (cell_capacity == 0) {
         // first guess; a too-small table is detected on the device (header.overflow)
         // and the caller grows it with grow_cells() and retries
         size_t guess = 1u << 20;
-        PCR_TRY(cell_count.reserve(guess * sizeof(uint32_t)));
-        PCR_TRY(cell_start.reserve(guess * sizeof(uint32_t)));
+        PCR_TRY(cell_count.reserve((guess + kScanTile) * sizeof(uint32_t)));
+        PCR_TRY(cell_start.reserve((guess + kScanTile) * sizeof(uint32_t)));
+        PCR_TRY(hipMemsetAsync(cell_count.p, 0, cell_count.cap, s));      // builds expect and leave the counters zeroed
         cell_capacity = guess;
         PCR_TRY(block_sums.reserve((guess / kScanTile + 2) * sizeof(uint32_t)));
     }
     const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
     const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>());
-    const int clear_blocks = (int)std::min<size_t>(2048, cell_capacity / 1024 + 1);
-    hipLaunchKernelGGL(grid_header_clear_kernel, dim3(clear_blocks), dim3(256), 0, s, bbox_partials.as<float>(), kBBoxBlocks,
-                       header.as<GridHeader>(), cell_count.as<uint32_t>(), (uint64_t)cell_capacity, cell, shift, n32);
+    hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
+                       ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift);
     hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
                        cell_count.as<uint32_t>(), keys.as<uint32_t>(), ranks.as<uint32_t>());
     const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL(grid_scan_local_kernel, dim3(scan_blocks), dim3(kScanBlock), 0, s, cell_count.as<uint32_t>(),
                        cell_start.as<uint32_t>(), block_sums.as<uint32_t>(), header.as<GridHeader>());
-    hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums.as<uint32_t>(), header.as<GridHeader>());
     hipLaunchKernelGGL(grid_scan_add_kernel, dim3(scan_blocks), dim3(kScanBlock), 0, s, cell_start.as<uint32_t>(),
                        block_sums.as<uint32_t>(), header.as<GridHeader>());
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),

@@ -117,7 +117,7 @@ struct DeviceBuf {
 };
 
 struct GridIndex {
-    DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header, keys, ranks;
+    DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header, keys, ranks, ticket;
     size_t cell_capacity = 0;   // entries available in cell_count / cell_start
     size_t n_points = 0;
     bool valid = false;
