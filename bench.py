@@ -53,13 +53,100 @@ def parse():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
     ap.add_argument("--shard-map", action="store_true", help="shard map tiles across ranks + RCCL all-reduce (config 4)")
+    ap.add_argument("--method", choices=["loam", "vgicp", "ndt"], default="loam",
+                    help="loam = the headline line (BASELINE configs[1]); vgicp / ndt = configs[2] / configs[4], extra lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0)
     return ap.parse_args()
 
 
+def secondary(args):
+    """configs[2] (pcr=vgicp, 0.5 m voxels, 65 536 x 1 M) and configs[4] (pcr=ndt, 1 m cells, 131 072 x 5 M) on one GPU:
+    same timing contract, target rebuilt on every call like the reference (fast_vgicp_impl.hpp:66-67; ndt_omp.h:276-283)."""
+    import torch
+    import oracle
+    from simpleslam_amd import VgicpRegister, NdtRegister, synth
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    dev = torch.device("cuda", 0)
+    if args.method == "vgicp":
+        cfg, n_map, kw, mk = 3, 1_000_000, {}, {}
+        reg = VgicpRegister(vgicp_resolution=0.5)
+        pert = {}
+        cores = host_cores()
+        ref = lambda s, m, T: oracle.vgicp_scan2map(s, m, T, oracle.vgicp_params(resolution=0.5, threads=cores))[0]
+        # SURVEY 8(d): one-off per target >= N_m (16 + 20*16 + 128) for the covariances + N_m (16 + 128) for the voxel map
+        alg = lambda n_s, n_m: 608 * n_m
+        what = "target preparation (3-level index + covariance + voxel kernels), 608 B per map point"
+        workload = "pcr=vgicp, 0.5 m voxels, 65536-pt scan vs 1000000-pt submap, target rebuilt per call, inputs in HBM"
+    else:
+        cfg, n_map, kw, mk = 5, 5_000_000, dict(beams=128, azimuths=1024), dict(spacing=0.22)
+        reg = NdtRegister()
+        pert = dict(trans=0.1, rot_deg=0.5)
+        ref = lambda s, m, T: oracle.ndt_scan2map(s, m, T, oracle.ndt_params())[0]      # the NDT oracle is serial
+        cores = 1
+        alg = lambda n_s, n_m: 16 * n_m          # voxel build reads every map point once (+104 B per voxel written)
+        what = "target preparation (index + voxel Gaussians), 16 B per map point"
+        workload = "pcr=ndt, 1.0 m cells, 131072-pt 128-beam scan vs 5000000-pt submap, target rebuilt per call, inputs in HBM"
+    world, map_np = synth.make_map(n_map, seed=SEED + cfg, **mk)
+    scans, inits = [], []
+    for j in range(args.scans):
+        s, T = synth.make_scan(world, j, seed=SEED + cfg, **kw)
+        scans.append(s); inits.append(synth.perturb(T, SEED + cfg + j, **pert))
+    d_map = torch.from_numpy(map_np).to(dev)
+    d_scans = [torch.from_numpy(s).to(dev) for s in scans]
+
+    def step(i):
+        pose = inits[i % args.scans].copy()
+        reg.scan2Map(d_scans[i % args.scans], d_map, pose)
+        return pose
+
+    reg.set_profile(0)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": args.steps / elapsed, "unit": "scans/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.method == "vgicp" else "f32",
+           "data": "synthetic", "config": {"workload": workload, "scans_cycled": args.scans}}
+    reg.set_profile(1)
+    idx_ms = sol_ms = 0.0
+    for i in range(8):
+        step(i); st = reg.stats(); idx_ms += st["index_ms"] / 8; sol_ms += st["solve_ms"] / 8
+    reg.set_profile(0)
+    ach = alg(scans[0].shape[0], n_map) / (idx_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                       "kernel": what, "target_prep_ms": idx_ms, "align_ms": sol_ms}
+    if not args.no_cpu_baseline:
+        n_done, t_cpu, et, er, nan_both, nan_one = 0, 0.0, [], [], 0, 0
+        while n_done < 2 or (t_cpu < args.cpu_budget_s and n_done < args.scans):
+            j = n_done % args.scans
+            c0 = time.perf_counter(); pref = ref(scans[j], map_np, inits[j]); t_cpu += time.perf_counter() - c0
+            pg = step(j)
+            n_done += 1
+            if not (np.isfinite(pg).all() and np.isfinite(pref).all()):
+                nan_both += int(not np.isfinite(pg).all() and not np.isfinite(pref).all())
+                nan_one += int(np.isfinite(pg).all() != np.isfinite(pref).all())
+                continue
+            dt, dr = synth.pose_error(pg, pref)
+            et.append(dt); er.append(dr)
+        out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port",
+                               "sample": f"{n_done} of the same scans through the oracle, {t_cpu:.1f} s wall, threads = {cores}"}
+        out["pose_rmse_vs_cpu"] = {"trans_m": float(np.sqrt(np.mean(np.square(et)))) if et else None,
+                                   "rot_rad": float(np.sqrt(np.mean(np.square(er)))) if er else None, "scans": len(et),
+                                   # pclomp's line search can return NaN (ndt_omp_impl.hpp:773-932); both sides then agree on it
+                                   "non_finite_on_both_sides": nan_both, "non_finite_on_one_side": nan_one}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.method != "loam":
+        return secondary(args)
     import torch
     import torch.distributed as dist
     from simpleslam_amd import LoamRegister, synth

@@ -367,6 +367,8 @@ def _nd():
         L.oracle_ndt_leaf_at.restype = C.c_int
         L.oracle_ndt_leaf_at.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(NdtParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_svd6_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_ndt_trial_value.restype = C.c_double
+        L.oracle_ndt_trial_value.argtypes = [C.c_double] * 9
         L._nd_ready = True
     return L
 
@@ -379,6 +381,11 @@ def ndt_params(**kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def ndt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t):
+    """trialValueSelectionMT (ndt_omp_impl.hpp:690-769)."""
+    return float(_nd().oracle_ndt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t))
 
 
 def svd6_solve(A, b):

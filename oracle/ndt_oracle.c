@@ -439,10 +439,18 @@ static double trial_value(double a_l, double f_l, double g_l, double a_u, double
         double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
         double nx = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
         double lim = a_t + 0.66 * (a_u - a_t);
-        return a_t > a_l ? (lim < nx ? lim : nx) : (lim > nx ? lim : nx);
+        /* std::min(lim, nx) / std::max(lim, nx) exactly as the STL evaluates them (:758-761): a NaN second argument is
+         * dropped, which is how the reference survives a collapsed interval (a_t == a_l gives nx = NaN) */
+        return a_t > a_l ? (nx < lim ? nx : lim) : (lim < nx ? nx : lim);
     }
     double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = sqrt(z * z - g_t * g_u);
     return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+/* test hook: trialValueSelectionMT (:690-769) */
+double oracle_ndt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
+{
+    return trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t);
 }
 
 typedef struct { const ndt_grid *g; const float *src; size_t n, stride; float *trans; gauss_t gc; ang_t ang; float R[9], t[3]; long n_deriv, n_hess; } ndt_ctx;

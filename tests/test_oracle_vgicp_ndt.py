@@ -166,3 +166,16 @@ def test_euler_parameterisation_roundtrip():
     a = oracle.ndt_derivatives(m[:500], m, p6)["score"]
     b = oracle.ndt_derivatives(m[:500], m, alt)["score"]
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_ndt_trial_value_drops_nan_like_std_min_max():
+    """Case 3 of trialValueSelectionMT with a collapsed interval (a_t == a_l): the cubic and secant minimisers are 0/0,
+    and the reference's std::min(lim, a_t_next) / std::max(lim, a_t_next) return their FIRST argument when the second
+    is NaN (ndt_omp_impl.hpp:758-761) -- the search continues from lim instead of poisoning the pose."""
+    # f_t <= f_l, g_t * g_l >= 0, |g_t| <= |g_l|  -> case 3;  a_t == a_l -> a_c, a_s are NaN
+    v = oracle.ndt_trial_value(0.05, -1.0, -2.0, 0.1, 0.0, -2.0, 0.05, -1.0, -1.0)
+    assert np.isfinite(v)
+    assert v == 0.05 + 0.66 * (0.1 - 0.05)
+    # regular case 3 values are untouched: a_t > a_l picks min(lim, a_t_next)
+    v = oracle.ndt_trial_value(0.0, 0.0, -2.0, 1.0, 0.0, -2.0, 0.1, -0.15, -1.0)
+    assert np.isfinite(v) and 0.1 < v <= 0.1 + 0.66 * 0.9
