@@ -140,6 +140,17 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
 int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device,
                         const double pose[16], double H[36], double b[6], double* error, int64_t* n_corr);
 
+/* pcl::VoxelGrid<PointXYZI>::filter (leaf, leaf, leaf) -- the step before the path: every scan at
+ * frontend/src/LidarOdometry.cpp:36,170-171, every rebuilt sub-map at frontend/src/MapManager.cpp:78,192 through
+ * common/pcp/pcp.hpp:14-28.  One centroid per occupied voxel of PCL's lattice (idx = floor(p / leaf) - min_b, float
+ * arithmetic as in PCL), all fields averaged, output in ascending voxel index.  Points keep the input stride; with the
+ * 32-byte pcl::PointXYZI layout data[3] = 1 and the intensity (float 4) is averaged, with a 16-byte layout float 3 is.
+ * Non-finite points are skipped.  *n_out = number of voxels (also when out_capacity was too small, so that the caller
+ * can retry).  A leaf so small that PCL's integer voxel index would overflow returns the input unfiltered, like PCL.
+ * Works on any handle (the method is irrelevant). */
+int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double leaf, void* out,
+                     size_t out_capacity, int out_on_device, size_t* n_out);
+
 /* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
  * accumulation done, partial sums stored.  out receives [launches][blocks][8] u64; call with out = NULL to size it. */

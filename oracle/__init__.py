@@ -429,3 +429,19 @@ def ndt_leaf_at(dst, p, params=None):
     mean, cov, icov = np.zeros(3), np.zeros(9), np.zeros(9)
     n = _nd().oracle_ndt_leaf_at(_p(dst), dst.shape[0], dst.shape[1], C.byref(params), _p(pp), _p(mean), _p(cov), _p(icov))
     return n, mean, cov.reshape(3, 3), icov.reshape(3, 3)
+
+
+# ---------------------------------------------------------------------------
+# pcl::VoxelGrid restatement (oracle/voxel_oracle.c)
+# ---------------------------------------------------------------------------
+def voxel_filter(pts, leaf):
+    """-> (centroids in ascending voxel index, unfiltered flag)."""
+    pts = _f32(pts)
+    L = lib()
+    L.oracle_voxel_filter.restype = C.c_int
+    L.oracle_voxel_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    out = np.zeros((max(pts.shape[0], 1), pts.shape[1]), np.float32)
+    cnt = C.c_size_t(0)
+    rc = L.oracle_voxel_filter(_p(pts), pts.shape[0], pts.shape[1], float(leaf), _p(out), pts.shape[0], C.byref(cnt))
+    assert rc in (0, 1), rc
+    return out[:cnt.value].copy(), rc == 1

@@ -67,6 +67,8 @@ struct pcr_handle {
     uint32_t last_blocks = 0;        // linearisation blocks of the last LOAM call (timeline readout)
     // source
     DeviceBuf src_stage;
+    GridIndex vf_grid;               // pcl::VoxelGrid lattice of the cloud being down-sampled (pcr_voxel_filter)
+    DeviceBuf vf_in, vf_out, vf_head, vf_sums, vf_count;
     QuerySorter sorter;
 
     // LOAM work memory
@@ -834,6 +836,7 @@ void pcr_destroy(pcr_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release(); h->sorter.release();
+    h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
     h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
     if (h->out32_host) (void)hipHostFree(h->out32_host);
@@ -905,6 +908,61 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
 int pcr_invalidate_target(pcr_handle* h) {
     if (!h) return 1;
     h->have_target = false; h->grid.valid = false; h->vg_target_ready = false; h->nd_target_ready = false;
+    return 0;
+}
+
+int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double leaf, void* out,
+                     size_t out_capacity, int out_on_device, size_t* n_out) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!n_out) return fail(h, "n_out is NULL");
+    *n_out = 0;
+    if (n && !pts) return fail(h, "NULL cloud with nonzero size");
+    if (out_capacity && !out) return fail(h, "NULL output with nonzero capacity");
+    if (!(leaf > 0)) return fail(h, "leaf size must be positive");
+    if (n > 0xfffffff0ull) return fail(h, "cloud too large");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (n == 0) return 0;
+    const size_t sf = stride_bytes / 4;
+    const float* d_pts = static_cast<const float*>(pts);
+    if (!on_device && stage_host(h, &h->vf_in, pts, n, stride_bytes, &d_pts)) return 1;
+    GridHeader hdr;
+    bool settled = false;
+    for (int attempt = 0; attempt < 3 && !settled; ++attempt) {
+        if (h->vf_grid.build(d_pts, n, sf, leaf, h->stream, &h->err, 0.0, 1) != hipSuccess) return 1;
+        H_TRY(hipMemcpyAsync(&hdr, h->vf_grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        if (!hdr.overflow) settled = true;
+        else if (h->vf_grid.grow_cells(hdr.n_cells, &h->err) != hipSuccess) return 1;
+    }
+    if (!settled) return fail(h, "voxel table could not be sized");
+    if (hdr.too_fine) {
+        // pcl::VoxelGrid: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+        *n_out = n;
+        if (out_capacity < n) return fail(h, "output capacity too small (leaf too small for the data: the input is returned unfiltered)");
+        H_TRY(hipMemcpyAsync(out, d_pts, n * stride_bytes, out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        h->err = "leaf size too small for the input: integer voxel indices would overflow; input returned unfiltered";
+        return 0;
+    }
+    H_TRY(h->vf_head.reserve((n + 4096) * sizeof(uint32_t)));
+    H_TRY(h->vf_sums.reserve((n / 2048 + 2) * sizeof(uint32_t)));
+    H_TRY(h->vf_count.reserve(16));
+    float* d_out = static_cast<float*>(out);
+    size_t cap = out_capacity;
+    if (!out_on_device) {
+        cap = std::min(out_capacity, n);
+        H_TRY(h->vf_out.reserve((cap ? cap : 1) * stride_bytes));
+        d_out = h->vf_out.as<float>();
+    }
+    H_TRY(voxel_filter_launch(h->vf_grid, d_pts, sf, n, h->vf_head.as<uint32_t>(), h->vf_sums.as<uint32_t>(), d_out, cap,
+                              h->vf_count.as<uint32_t>(), h->stream));
+    uint32_t count = 0;
+    H_TRY(hipMemcpyAsync(&count, h->vf_count.p, sizeof(count), hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    *n_out = count;
+    if (count > out_capacity) return fail(h, "output capacity too small: " + std::to_string(count) + " voxels are occupied");
+    if (!out_on_device && count) H_TRY(hipMemcpy(out, d_out, (size_t)count * stride_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

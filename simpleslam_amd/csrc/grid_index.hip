@@ -33,7 +33,7 @@ __device__ inline float wave_max(float v) {
 // (one launch instead of two; the cell counters are NOT cleared here: every build leaves them zeroed, see the scan)
 __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
                                                                float* __restrict__ partials, uint32_t* __restrict__ ticket,
-                                                               GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift) {
+                                                               GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     // four independent loads in flight per lane (a 1 M-point cloud is 16-32 MB: this pass should run at HBM speed)
     const uint32_t step = gridDim.x * 256;
@@ -98,11 +98,23 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         GridHeader h;
         h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n; h.shift = shift;
         h.empty = 0; h.overflow = 0;
+        h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0;
+        h.min_b[0] = h.min_b[1] = h.min_b[2] = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
             float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
             if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
+            if (pcl_mode) {
+                // pcl::VoxelGrid::applyFilter: min_b = floor(min_p * inverse_leaf_size), float arithmetic throughout
+                const float flo = floorf(lo * h.inv_leaf_f), fhi = floorf(hi * h.inv_leaf_f);
+                const double dim = (double)fhi - (double)flo + 1.0;
+                h.min_b[d] = fabsf(flo) < 2.0e9f ? (int32_t)flo : 0;
+                h.org[d] = (double)flo; h.origin[d] = (double)flo * cell;
+                h.dims[d] = dim < 2.0e9 ? (int32_t)dim : 0x7fffffff;
+                nc *= dim;
+                continue;
+            }
             double clo = floor((double)lo / cell - shift), chi = floor((double)hi / cell - shift);
             h.org[d] = clo - kPad;
             h.origin[d] = (clo - kPad + shift) * cell;
@@ -110,8 +122,10 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
             h.dims[d] = dim < 2.0e9 ? (int32_t)dim : 0x7fffffff;
             nc *= dim;
         }
+        if (pcl_mode && nc > 2147483647.0) h.too_fine = 1;      // (dx*dy*dz) > INT_MAX
         // keys are uint32 and the table holds n_cells + 1 starts
-        if (nc + 1.0 > (double)capacity || nc > 4.0e9) { h.overflow = 1; h.n_cells = nc < 1.8e19 ? (uint64_t)nc : ~0ull; }
+        if (h.too_fine) { h.overflow = 0; h.empty = 1; h.n_cells = 1; }      // nothing is indexed; the caller copies its input
+        else if (nc + 1.0 > (double)capacity || nc > 4.0e9) { h.overflow = 1; h.n_cells = nc < 1.8e19 ? (uint64_t)nc : ~0ull; }
         else h.n_cells = (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2];
         *hdr = h;
     }
@@ -119,6 +133,13 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
 
 __device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key) {
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) return false;
+    if (h.pcl_mode) {
+        // ijk = static_cast<int>(std::floor(p * inverse_leaf_size) - static_cast<float>(min_b))   (voxel_grid.hpp)
+        const int ix = (int)(floorf(x * h.inv_leaf_f) - (float)h.min_b[0]), iy = (int)(floorf(y * h.inv_leaf_f) - (float)h.min_b[1]),
+                  iz = (int)(floorf(z * h.inv_leaf_f) - (float)h.min_b[2]);
+        *key = ((uint32_t)iz * (uint32_t)h.dims[1] + (uint32_t)iy) * (uint32_t)h.dims[0] + (uint32_t)ix;
+        return true;
+    }
     // cell index = floor(x / cell) - org.  For a power-of-two cell (LOAM) x / cell is exact and this
     // equals floor((x - origin) / cell); for any other edge (VGICP/NDT resolutions) it is the single
     // definition every kernel uses, so a point and its queries always agree on the cell.
@@ -277,7 +298,8 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
     if ((e = cell_count.reserve((want + kScanTile) * sizeof(uint32_t))) != hipSuccess ||
         (e = cell_start.reserve((want + kScanTile) * sizeof(uint32_t))) != hipSuccess ||
         (e = block_sums.reserve((want / kScanTile + 2) * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMemset(cell_count.p, 0, cell_count.cap)) != hipSuccess) {      // builds expect and leave the counters zeroed
+        (e = hipMemset(cell_count.p, 0, cell_count.cap)) != hipSuccess ||      // builds expect and leave the counters zeroed
+        (e = hipDeviceSynchronize()) != hipSuccess) {      // (a device memset is not ordered against the handle's non-blocking stream)
         if (err) *err = std::string("hipMalloc of the cell table failed: ") + hipGetErrorString(e);
         cell_capacity = 0;
         return e;
@@ -288,7 +310,8 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 
 #define PCR_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { if (err) *err = std::string(#x) + ": " + hipGetErrorString(_e); return _e; } } while (0)
 
-hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift) {
+hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift,
+                            int pcl_mode) {
     valid = false;
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
@@ -313,7 +336,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
     const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);
     hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
-                       ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift);
+                       ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode);
     hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
                        cell_count.as<uint32_t>(), keys.as<uint32_t>(), ranks.as<uint32_t>());
     const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);

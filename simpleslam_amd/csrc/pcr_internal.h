@@ -30,6 +30,12 @@ struct GridHeader {
     int32_t overflow;        // n_cells + 1 exceeds the allocated cell table
     int32_t empty;           // no finite point
     double shift;            // lattice offset in cells: cell index = floor(x / cell - shift) - org (0.5 for the VGICP voxel lattice)
+    // pcl::VoxelGrid lattice (voxel_filter.hip): cell index = (int)(floorf(x * inv_leaf_f) - (float)min_b), all in float,
+    // dims = max_b - min_b + 1 without pad cells.  pcl_mode = 0 everywhere else.
+    int32_t pcl_mode;
+    float inv_leaf_f;
+    int32_t min_b[3];
+    int32_t too_fine;        // pcl_mode: more than INT_MAX voxels ("Leaf size is too small", voxel_grid.hpp)
 };
 
 struct GridView {            // what kernels need to query the index
@@ -127,7 +133,7 @@ struct GridIndex {
     // Enqueue the build of the index over n points (device pointer, stride in floats).
     // No host synchronisation unless the cell table must grow.  cell = grid edge.
     hipError_t build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s,
-                     std::string* err, double shift = 0.0);
+                     std::string* err, double shift = 0.0, int pcl_mode = 0);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
     void release();
@@ -171,6 +177,10 @@ hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
                           double* d_partials, double* d_out32, hipStream_t s);
 uint32_t vgicp_blocks(uint32_t n_src);
+
+// pcl::VoxelGrid on the device (voxel_filter.hip); grid must have been built with pcl_mode = 1
+hipError_t voxel_filter_launch(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, uint32_t* d_head, uint32_t* d_sums,
+                               float* d_out, size_t out_capacity, uint32_t* d_n_out, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // NDT (ndt.hip)

@@ -120,3 +120,25 @@ inline PointCloudRegister::Ptr makeRegister(const std::string& pcr_type) {
 }
 
 }  // namespace PCR
+
+// common/pcp/pcp.hpp:14-28 (pcl::VoxelGrid with leaf = grid_size on all axes), on the device
+namespace pcp {
+inline void voxelDownSample(const PCR::PC_cPtr& cloudIn, PCR::PointCloud& cloudOut, float grid_size) {
+    pcr_handle* h = pcr_create("loam", nullptr);       // any method: the filter only needs a device context
+    if (!h) throw std::runtime_error(pcr_last_error(nullptr));
+    const size_t n = cloudIn->size();
+    std::vector<PCR::PointXYZI> tmp(n ? n : 1);
+    size_t n_out = 0;
+    const int rc = pcr_voxel_filter(h, cloudIn->points.data(), n, sizeof(PCR::PointXYZI), 0, grid_size, tmp.data(), n, 0, &n_out);
+    const std::string msg = rc ? pcr_last_error(h) : "";
+    pcr_destroy(h);
+    if (rc) throw std::runtime_error(msg);
+    tmp.resize(n_out);
+    cloudOut.points.swap(tmp);
+}
+inline void voxelDownSample(PCR::PC_Ptr& cloud, float grid_size) {      // in place, like pcp.hpp:14-20
+    PCR::PointCloud out;
+    voxelDownSample(PCR::PC_cPtr(cloud), out, grid_size);
+    cloud->points.swap(out.points);
+}
+}  // namespace pcp

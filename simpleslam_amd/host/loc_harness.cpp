@@ -2,7 +2,8 @@
 // LidarOdometry::generateOdom (frontend/src/LidarOdometry.cpp:170-184): load a map and a scan
 // (raw float32 x y z intensity records), read the initial pose, call scan2Map through the C++ mirror
 // of the plugin interface, print the refined pose.
-//   loc_harness <method> <map.f32> <scan.f32> <init_pose.txt (4x4 row-major, test/align.cpp:85-93)>
+//   loc_harness <method> <map.f32> <scan.f32> <init_pose.txt (4x4 row-major, test/align.cpp:85-93)> [downSampleVoxelGridSize]
+// With the optional grid size the scan is voxel-filtered first, as LidarOdometry does (LidarOdometry.cpp:36,170-171).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -31,6 +32,11 @@ int main(int argc, char** argv) {
         PCR::pose_t pose;
         std::ifstream pf(argv[4]);
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (!(pf >> pose(r, c))) throw std::runtime_error("bad pose file");
+        if (argc > 5) {
+            const size_t before = scan->size();
+            pcp::voxelDownSample(scan, std::stof(argv[5]));
+            std::printf("voxel ds %zu -> %zu\n", before, scan->size());
+        }
         const auto t0 = std::chrono::steady_clock::now();
         const bool conv = reg->scan2Map(scan, map, pose);
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -48,7 +48,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
-    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
 ]
 
 _lib = None
@@ -88,6 +88,7 @@ def load_library():
     L.pcr_vgicp_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.pcr_ndt_derivatives.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, dp]
     L.pcr_get_timeline.argtypes = [vp, vp, C.c_size_t, ip, ip]
+    L.pcr_voxel_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, vp, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
     L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
     L.pcr_set_profile.argtypes = [vp, C.c_int]
     L.pcr_set_stream.argtypes = [vp, vp]
@@ -191,6 +192,21 @@ class PointCloudRegister:
 
     def invalidateTarget(self):
         self._check(self._lib.pcr_invalidate_target(self._h))
+
+    # -- the step before the path ------------------------------------------------
+    def voxelDownSample(self, cloud, grid_size):
+        """pcp::voxelDownSample / pcl::VoxelGrid (reference common/pcp/pcp.hpp:14-28): centroid per occupied voxel, ascending
+        voxel index.  Host array in -> numpy array out; CUDA tensor in -> CUDA tensor out (nothing leaves HBM)."""
+        p, n, s, dev, keep = _cloud(cloud)
+        cnt = C.c_size_t(0)
+        if dev:
+            import torch
+            out = torch.empty((max(n, 1), s // 4), dtype=torch.float32, device=keep.device)
+            self._check(self._lib.pcr_voxel_filter(self._h, p, n, s, 1, float(grid_size), C.c_void_p(out.data_ptr()), n, 1, C.byref(cnt)))
+            return out[:cnt.value]
+        out = np.zeros((max(n, 1), s // 4), np.float32)
+        self._check(self._lib.pcr_voxel_filter(self._h, p, n, s, 0, float(grid_size), out.ctypes.data_as(C.c_void_p), n, 0, C.byref(cnt)))
+        return out[:cnt.value].copy()
 
     # -- introspection ---------------------------------------------------------
     def stats(self):

@@ -30,3 +30,24 @@ def test_cpp_harness_matches_python(gpu, world_small, tmp_path):
     np.testing.assert_array_equal(pose_cpp, pose_py)
     bad = subprocess.run([exe, "icp", "a", "b", "c"], capture_output=True, text=True)
     assert bad.returncode == 1 and "is not exist" in bad.stderr
+
+
+def test_cpp_harness_with_voxel_downsampling(gpu, world_small, tmp_path):
+    """LidarOdometry's flow, scan -> VoxelGrid(downSampleVoxelGridSize) -> scan2Map (LidarOdometry.cpp:36,170-184),
+    through the C++ mirror: same pose as the Python mirror fed with the same down-sampled scan."""
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    w = world_small
+    w["map"].astype(np.float32).tofile(tmp_path / "map.f32")
+    w["scan"].astype(np.float32).tofile(tmp_path / "scan.f32")
+    np.savetxt(tmp_path / "init.txt", w["init"], fmt="%.17g")
+    out = subprocess.run([exe, "loam", str(tmp_path / "map.f32"), str(tmp_path / "scan.f32"), str(tmp_path / "init.txt"), "0.4"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    reg = LoamRegister()
+    ds = reg.voxelDownSample(w["scan"], 0.4)
+    assert lines[0] == f"voxel ds {w['scan'].shape[0]} -> {ds.shape[0]}"
+    pose_py = w["init"].copy()
+    reg.scan2Map(ds, w["map"], pose_py)
+    pose_cpp = np.array([[float(v) for v in ln.split()] for ln in lines[-4:]])
+    np.testing.assert_array_equal(pose_cpp, pose_py)

@@ -172,6 +172,22 @@ def test_edge_cases(gpu, world_small):
     assert reg.scan2Map(far, w["map"], p) is False
 
 
+def test_first_call_after_cell_table_growth(gpu, world_100k):
+    """A gate radius of 0.25 m makes the 0.25 m grid overflow the initial cell table: the very first call has to grow it
+    and rebuild.  Its result must be the one every later call gives (the counters of a fresh table must be zero before
+    the rebuild's histogram runs)."""
+    w = world_100k
+    reg = LoamRegister(loam_knn_max_sq=0.0625)
+    p1, p2 = w["init"].copy(), w["init"].copy()
+    c1 = reg.scan2Map(w["scan"], w["map"], p1)
+    c2 = reg.scan2Map(w["scan"], w["map"], p2)
+    assert c1 == c2
+    np.testing.assert_array_equal(p1, p2)
+    po, co, _ = oracle.loam_scan2map(w["scan"], w["map"], w["init"], oracle.loam_params(knn_max_sq=0.0625))
+    dt, dr = synth.pose_error(p1, po)
+    assert dt < 1e-9 and dr < 1e-9
+
+
 def test_unknown_method_raises():
     from simpleslam_amd import make_register
     with pytest.raises(RuntimeError):

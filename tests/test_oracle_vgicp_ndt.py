@@ -179,3 +179,28 @@ def test_ndt_trial_value_drops_nan_like_std_min_max():
     # regular case 3 values are untouched: a_t > a_l picks min(lim, a_t_next)
     v = oracle.ndt_trial_value(0.0, 0.0, -2.0, 1.0, 0.0, -2.0, 0.1, -0.15, -1.0)
     assert np.isfinite(v) and 0.1 < v <= 0.1 + 0.66 * 0.9
+
+
+def test_voxel_filter_oracle_against_numpy():
+    """oracle/voxel_oracle.c (pcl::VoxelGrid restated) against an independent numpy grouping on PCL's float lattice."""
+    rng = np.random.default_rng(5)
+    pts = (rng.uniform(-30, 30, (20000, 4))).astype(np.float32)
+    pts[::17, 2] = np.nan
+    leaf = 0.7
+    out, unfiltered = oracle.voxel_filter(pts, leaf)
+    assert not unfiltered
+    fin = np.isfinite(pts[:, :3]).all(1)
+    P = pts[fin]
+    inv = np.float32(1.0) / np.float32(leaf)
+    min_b = np.floor(P[:, :3].min(0) * inv).astype(np.int64)
+    div_b = np.floor(P[:, :3].max(0) * inv).astype(np.int64) - min_b + 1
+    ijk = (np.floor(P[:, :3] * inv) - min_b.astype(np.float32)).astype(np.int64)
+    ids = ijk[:, 0] + ijk[:, 1] * div_b[0] + ijk[:, 2] * div_b[0] * div_b[1]
+    order = np.argsort(ids, kind="stable")
+    uniq, start, cnt = np.unique(ids[order], return_index=True, return_counts=True)
+    assert out.shape[0] == len(uniq)
+    mean = np.add.reduceat(P[order].astype(np.float64), start, axis=0) / cnt[:, None]
+    np.testing.assert_allclose(out, mean, rtol=0, atol=2e-4)        # float accumulation in the oracle, as in PCL
+    # leaf too small: input back
+    o2, unf = oracle.voxel_filter(pts[:100], 1e-6)
+    assert unf and o2.shape == (100, 4)
