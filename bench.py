@@ -260,7 +260,7 @@ def main():
                            "device_ms_per_scan": tot_ms / reps}
 
         # ---- pose parity + CPU baseline: the oracle (a port) on this host's cores ----
-        if not args.no_cpu_baseline and not args.shard_map:
+        if not args.no_cpu_baseline and not args.shard_map and world_size == 1:      # the CPU leg is timed at N = 1 only
             import oracle
             cores = host_cores()
             prm = oracle.loam_params(iters=args.iters, early_exit=0, threads=cores)
