@@ -227,11 +227,13 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
     }
     *l6_out = q.l6;
     if (inside) {
-        // fill the original indices and detect exact distance ties (inside the list, or between its last
-        // entry and anything left out); those rare queries are redone with the index tie-break
+        // detect exact distance ties (inside the list, or between its last entry and anything left out); those rare
+        // queries are redone with the index tie-break.  The original indices are NOT fetched here: the owner of the
+        // query reads the five points anyway (coordinates for the plane fit) and takes the index from the same 16 bytes
+        // -- one memory round trip instead of two.
         bool tie = false;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) s.idx[j] = s.pos[j] == 0xffffffffu ? 0xffffffffu : __float_as_uint(pts[s.pos[j]].w);
+        for (int j = 0; j < 5; ++j) s.idx[j] = 0xffffffffu;
         if (s.pos[4] != 0xffffffffu) {
             tie = (q.l6 == s.d[4]) | (s.d[0] == s.d[1]) | (s.d[1] == s.d[2]) | (s.d[2] == s.d[3]) | (s.d[3] == s.d[4]);
         }
@@ -614,11 +616,12 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         l6 = ex.l6[tid];
         searched = ex.searched[tid] != 0;
         real5 = searched && s.pos[4] != 0xffffffffu;
-        if (real5) {
+        if (searched) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const float4 p = a.grid.pts[s.pos[j]];
+                const float4 p = a.grid.pts[s.pos[j] != 0xffffffffu ? s.pos[j] : 0u];
                 A[j][0] = (double)p.x; A[j][1] = (double)p.y; A[j][2] = (double)p.z;
+                s.idx[j] = s.pos[j] != 0xffffffffu ? __float_as_uint(p.w) : 0xffffffffu;
             }
         }
     } else if (hit && !ordered) {
