@@ -860,8 +860,14 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
 __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, const int k) {
     __shared__ double sh_sum[8 * 32];
     __shared__ Prologue sh_pro;
-    __shared__ KnnShared sh_knn;
-    __shared__ MissExchange sh_ex;               // also holds the rows: [component][point] s*J (6), s*d, accepted flag
+    // The staging area of the prefetched cache entries (32 KB, dead once every lane has read its entry) shares its
+    // LDS with the search scratch and the miss exchange (48 KB, first written after that): 51 KB per block instead of
+    // 83 KB, so that two blocks -- e.g. of two scans on two streams -- fit on a CU.
+    struct SearchLds { KnnShared knn; MissExchange ex; };
+    static_assert(sizeof(SearchLds) >= 8 * 256 * sizeof(float4), "the staging area must fit into the search scratch");
+    __shared__ __attribute__((aligned(16))) unsigned char sh_ov[sizeof(SearchLds)];
+    KnnShared& sh_knn = reinterpret_cast<SearchLds*>(sh_ov)->knn;
+    MissExchange& sh_ex = reinterpret_cast<SearchLds*>(sh_ov)->ex;   // also holds the rows: [component][point] s*J (6), s*d, accepted flag
     double* const sh_rows = sh_ex.u.rows;
     const int tid = threadIdx.x;
     unsigned long long* const tl = (a.timeline && tid == 0) ? a.timeline + ((size_t)k * kMaxPartials + blockIdx.x) * 8 : nullptr;
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
     // the 128-byte neighbour-cache entry arrive while the previous iteration's normal equations are being solved.
     // The entry goes straight to LDS ([field][thread], 32 KB): held in registers it was spilled to AGPRs, which made
     // the wave wait for it before the prologue had even started.
-    __shared__ float4 sh_pre[8 * 256];
+    float4* const sh_pre = reinterpret_cast<float4*>(sh_ov);
     const GridHeader h = *a.grid.hdr;      // uniform: scalar loads, in flight during the prologue
     float pre_x = 0.f, pre_y = 0.f, pre_z = 0.f;
     const bool use_cache = k > 0 && a.nn_cache != nullptr;
@@ -925,6 +931,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
 #pragma unroll
                 for (int f = 0; f < 8; ++f) ce.v[f] = sh_pre[f * 256 + tid];
             }
+            __syncthreads();          // the staging area is about to be reused by the search scratch and the exchange
         } else {                      // later rounds of a grid-stride launch
             sx = sy = sz = 0.f;
             if (valid) {
