@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--shard-map", action="store_true", help="shard map tiles across ranks + RCCL all-reduce (config 4)")
     ap.add_argument("--method", choices=["loam", "vgicp", "ndt"], default="loam",
                     help="loam = the headline line (BASELINE configs[1]); vgicp / ndt = configs[2] / configs[4], extra lines")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="> 1: additionally time S independent handles (one HIP stream and one host thread each) registering "
+                         "scans concurrently on the same GPU; reported as \"concurrent\", never as \"value\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0)
     return ap.parse_args()
@@ -231,6 +234,35 @@ def main():
                    "parallelism": parallelism, "scans_cycled": args.scans},
     }
 
+    if rank == 0 and args.streams > 1 and not args.shard_map:
+        # ---- S independent registrations in flight (multi-robot / loop-closure candidates): handles are independent
+        #      objects with their own stream ("distinct handles are concurrent-safe") ----
+        import threading
+        from simpleslam_amd import pcr as _pcr
+        prm = _pcr.default_params(device=local_rank, loam_iters=args.iters, loam_early_exit=0)
+        prm.reserved[4] = 1          # the two-waves-per-SIMD variant of the iterate kernel: blocks of different handles share the CUs
+        regs = [LoamRegister(params=prm) for _ in range(args.streams)]
+        per = max(1, args.steps // args.streams)
+        for r in regs:
+            for i in range(3):
+                p = inits[i % args.scans].copy(); r.scan2Map(d_scans[i % args.scans], d_map, p)
+        start = threading.Barrier(args.streams + 1)
+
+        def worker(r, off):
+            start.wait()
+            for i in range(per):
+                p = inits[(i + off) % args.scans].copy()
+                r.scan2Map(d_scans[(i + off) % args.scans], d_map, p)
+
+        th = [threading.Thread(target=worker, args=(r, j)) for j, r in enumerate(regs)]
+        for t in th: t.start()
+        torch.cuda.synchronize()
+        start.wait(); c0 = time.perf_counter()
+        for t in th: t.join()
+        torch.cuda.synchronize()
+        ct = time.perf_counter() - c0
+        out["concurrent"] = {"streams": args.streams, "value": per * args.streams / ct, "unit": "scans/s",
+                             "scans": per * args.streams, "note": "independent handles (pcr_params.reserved[4] = 1), one stream and one host thread each, same GPU"}
     if rank == 0:
         # ---- roofline of the dominant kernel (loam_iterate_kernel), live, HIP events on its stream ----
         reg.set_profile(2)

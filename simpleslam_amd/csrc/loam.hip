@@ -144,7 +144,8 @@ __device__ __noinline__ void knn5_resolve_ties(double org_x, double org_y, doubl
     for (int j = 0; j < 5; ++j) { s.d[j] = d5[j]; s.idx[j] = i5[j]; s.pos[j] = p5[j]; }
 }
 
-static constexpr int kChunk = 8;   // candidates per lane per step (the sorted array is padded by kChunk)
+// kChunk, a template parameter below = candidates per lane per step: 8 in the default kernel, 4 in the two-waves-per-SIMD
+// variant (the sorted array is padded by 16 entries, GridIndex::build)
 
 // Exact 5 nearest target points with squared distance <= max_sq (ties on the original
 // index), searching the 3x3x3 cell block as 9 contiguous x-runs.  Returns false when the
@@ -153,6 +154,7 @@ static constexpr int kChunk = 8;   // candidates per lane per step (the sorted a
 //
 // Memory-level parallelism is explicit: the 18 range loads of a query are issued together, and
 // candidates stream in chunks of kChunk float4 loads with the next chunk already in flight.
+template <int kChunk>
 __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __restrict__ pts,
                                           const uint32_t* __restrict__ cell_start, double qx, double qy, double qz,
                                           double max_sq, Knn5& s, KnnShared& sh, bool active, double* l6_out, bool keep,
@@ -526,6 +528,7 @@ struct MissExchange {
 // 4 outside this rank's query tile / no point);  row[0..5] = s*[n ; p x n], row[6] = s*d
 // Called by all threads of the block together (it contains barriers).
 // ------------------------------------------------------------------------------
+template <int kChunk>
 __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h, const double* __restrict__ pose,
                                           float sx, float sy, float sz, bool valid, const NnCacheEntry& ce_in, bool have_entry,
                                           KnnShared& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how,
@@ -598,7 +601,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             const uint32_t owner = worker ? ex.list[tid] : 0u;
             Knn5 r;
             double rl6 = 0.0;
-            const bool ok = knn5_grid(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
+            const bool ok = knn5_grid<kChunk>(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
                                       a.c.knn_max_sq, r, sh, worker, &rl6, false, worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate);
             if (worker) {
 #pragma unroll
@@ -857,7 +860,12 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
 // ------------------------------------------------------------------------------
 // the iteration kernel
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, const int k) {
+// kChunk / kWavesPerSimd: <8, 1> is the default (fastest for one scan at a time: 255 VGPRs + AGPRs, one wave per SIMD --
+// which is all that 65 536 queries give anyway); <4, 2> fits two waves per SIMD (245 VGPRs, 50 KB LDS) so that the blocks
+// of ANOTHER handle's launch can share the CUs: ~3 % slower alone, ~25 % more scans/s with several handles in flight
+// (pcr_params.reserved[4] = 1).
+template <int kChunk, int kWavesPerSimd>
+__global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const LoamArgs a, const int k) {
     __shared__ double sh_sum[8 * 32];
     __shared__ Prologue sh_pro;
     // The staging area of the prefetched cache entries (32 KB, dead once every lane has read its entry) shares its
@@ -940,7 +948,7 @@ __global__ __launch_bounds__(256) void loam_iterate_kernel(const LoamArgs a, con
                 if (use_cache) ce.e = a.nn_cache[q];
             }
         }
-        const int st = loam_point(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
+        const int st = loam_point<kChunk>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const float* spq = a.src + (size_t)q * a.src_stride;
             const size_t oi = a.src_indexed ? (size_t)__float_as_uint(spq[3]) : (size_t)q;   // original scan index
@@ -1025,7 +1033,8 @@ uint32_t loam_grid_blocks(uint32_t n_src) {
 }
 
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s) {
-    hipLaunchKernelGGL(loam_iterate_kernel, dim3(a.n_partials), dim3(256), 0, s, a, k);
+    if (a.coresident) hipLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(a.n_partials), dim3(256), 0, s, a, k);
+    else hipLaunchKernelGGL((loam_iterate_kernel<8, 1>), dim3(a.n_partials), dim3(256), 0, s, a, k);
     return hipGetLastError();
 }
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s) {

@@ -109,6 +109,7 @@ struct LoamArgs {
     // profiling aid (pcr_params.reserved[0]): skip phases to price them.  bit0: candidate loop,
     // bit1: plane fit and everything after it, bit2: prologue solve.  Results are then meaningless.
     int32_t ablate;
+    int32_t coresident;      // pcr_params.reserved[4] = 1: the two-waves-per-SIMD variant of the iterate kernel (loam.hip)
     // profiling aid (pcr_params.reserved[3] = 1): [launch][block][8] s_memrealtime stamps (100 MHz) taken by thread 0
     unsigned long long* timeline;
 };

@@ -318,3 +318,28 @@ def test_rccl_allreduce_path_single_rank(gpu, world_small):
     assert ca == cb
     dt, dr = synth.pose_error(pa, pb)
     assert dt < 1e-10 and dr < 1e-10
+
+
+def test_coresident_kernel_variant_and_concurrent_handles(gpu, world_100k):
+    """pcr_params.reserved[4] = 1 selects the two-waves-per-SIMD build of the iterate kernel: same result bit for bit;
+    and independent handles may register scans from different host threads at the same time."""
+    import threading
+    from simpleslam_amd import pcr
+    w = world_100k
+    base = w["init"].copy()
+    LoamRegister(loam_iters=10, loam_early_exit=0).scan2Map(w["scan"], w["map"], base)
+    prm = pcr.default_params(loam_iters=10, loam_early_exit=0)
+    prm.reserved[4] = 1
+    regs = [LoamRegister(params=prm) for _ in range(3)]
+    poses = [w["init"].copy() for _ in regs]
+
+    def run(i):
+        for _ in range(4):
+            poses[i][:] = w["init"]
+            regs[i].scan2Map(w["scan"], w["map"], poses[i])
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(regs))]
+    for t in th: t.start()
+    for t in th: t.join()
+    for p in poses:
+        np.testing.assert_array_equal(p, base)
