@@ -68,7 +68,7 @@ typedef struct pcr_params {
 
     int32_t record_trace;      /* 1: keep per-iteration normal equations for pcr_get_trace */
     /* reserved[]: all zero by default.  Development switches of the LOAM path (results are unchanged except where noted):
-     *   [0] ablation mask for profiling (results become meaningless)   [1] = 1: sort the scan by target cell first
+     *   [0] ablation mask for profiling (results become meaningless)   [1] unused
      *   [2] = 1: disable the temporal-coherence neighbour cache          [3] = 1: record the in-kernel timeline (pcr_get_timeline)
      *   [4] = 1: two-waves-per-SIMD variant of the iterate kernel -- ~3 % slower for one handle, ~25 % more scans/s when
      *            several handles register scans concurrently on one GPU (their blocks can then share the CUs) */

@@ -11,7 +11,6 @@ def run(mask, label, nosort=0):
     from simpleslam_amd.pcr import default_params
     p = default_params(loam_iters=10, loam_early_exit=0)
     p.reserved[0] = mask
-    p.reserved[1] = nosort
     p.reserved[2] = 1   # temporal cache off: every iteration is a full search
     reg = LoamRegister(params=p)
     reg.setTarget(dm)

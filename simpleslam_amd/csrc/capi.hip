@@ -69,10 +69,9 @@ struct pcr_handle {
     DeviceBuf src_stage;
     GridIndex vf_grid;               // pcl::VoxelGrid lattice of the cloud being down-sampled (pcr_voxel_filter)
     DeviceBuf vf_in, vf_out, vf_head, vf_sums, vf_count;
-    QuerySorter sorter;
 
     // LOAM work memory
-    DeviceBuf loam_state, loam_partials, loam_trace, loam_reduced, dbg_status, dbg_rows, dbg_nn, nn_cache, q_cache, timeline;
+    DeviceBuf loam_state, loam_partials, loam_trace, loam_reduced, dbg_status, dbg_rows, dbg_nn, nn_cache, timeline;
     LoamResult* result_host = nullptr;   // host-mapped, written by the finalize kernel
     LoamResult* result_dev = nullptr;
     std::vector<LoamTrace> trace_host;
@@ -138,7 +137,6 @@ int ensure_loam_buffers(pcr_handle* h) {
 void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16]) {
     memset(a, 0, sizeof(*a));
     a->src = d_src; a->n_src = (uint32_t)n_src; a->src_stride = (uint32_t)stride_floats;
-    a->src_indexed = 0;
     a->grid = h->grid.view();
     a->c.knn_max_sq = h->prm.loam_knn_max_sq; a->c.plane_thresh = h->prm.loam_plane_thresh;
     a->c.point_thresh = h->prm.loam_point_thresh; a->c.pos_conv = h->prm.loam_pos_conv; a->c.rot_conv = h->prm.loam_rot_conv;
@@ -178,10 +176,6 @@ int check_grid_overflow(pcr_handle* h, int overflow, uint64_t need_cells) {
     return 2;
 }
 
-// Cell-sorting the scan (query_sort.hip) is OFF by default: measured on MI355X (65 k scan, 1 M map)
-// it costs ~130 us per call and changes the iteration kernel by < 1 us -- the search is bound by
-// per-wave instruction issue, not by gather coalescing (profiles/r01_notes.md).  reserved[1] = 1 enables it.
-bool use_sort(const pcr_handle* h, size_t n_src) { return n_src >= 2048 && h->prm.reserved[1] == 1; }
 
 int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged,
              bool index_timed) {
@@ -194,12 +188,6 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         if (h->comm) a.reduced = h->loam_reduced.as<double>();
         h->result_host->pad = 0;
         if (h->profile >= 1 && !index_timed) { H_TRY(hipEventRecord(h->ev_start, h->stream)); H_TRY(hipEventRecord(h->ev_index, h->stream)); }
-        if (use_sort(h, n_src)) {
-            Pose16 p16;
-            memcpy(p16.m, pose, sizeof(p16.m));
-            if (h->sorter.sort(d_src, n_src, stride_floats, p16, h->grid, h->stream, &h->err) != hipSuccess) return 1;
-            a.src = h->sorter.sorted_points(); a.src_stride = 4; a.src_indexed = 1;
-        }
         const bool per_kernel = h->profile >= 2;
         if (per_kernel) {
             while ((int)h->ev_kernel.size() < 2 * iters) { hipEvent_t e; H_TRY(hipEventCreate(&e)); h->ev_kernel.push_back(e); }
@@ -836,7 +824,7 @@ void pcr_destroy(pcr_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
-    h->grid.release(); h->tgt_stage.release(); h->src_stage.release(); h->sorter.release();
+    h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
     h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
@@ -844,7 +832,7 @@ void pcr_destroy(pcr_handle* h) {
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
-    h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->q_cache.release(); h->timeline.release();
+    h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->timeline.release();
     if (h->result_host) (void)hipHostFree(h->result_host);
     for (hipEvent_t e : h->ev_kernel) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -989,12 +977,6 @@ int pcr_loam_linearize(pcr_handle* h, const void* src, size_t n_src, size_t stri
     LoamArgs a;
     fill_loam_args(h, &a, d_src, n_src, stride_bytes / 4, pose);
     a.trace = nullptr;
-    if (use_sort(h, n_src)) {
-        Pose16 p16;
-        memcpy(p16.m, pose, sizeof(p16.m));
-        if (h->sorter.sort(d_src, n_src, stride_bytes / 4, p16, h->grid, h->stream, &h->err) != hipSuccess) return 1;
-        a.src = h->sorter.sorted_points(); a.src_stride = 4; a.src_indexed = 1;
-    }
     if (status) { H_TRY(h->dbg_status.reserve(n_src + 16)); a.dbg_status = h->dbg_status.as<int8_t>(); }
     if (rows) { H_TRY(h->dbg_rows.reserve(n_src * 7 * sizeof(double) + 16)); a.dbg_rows = h->dbg_rows.as<double>(); }
     if (nn) { H_TRY(h->dbg_nn.reserve(n_src * 5 * sizeof(int32_t) + 16)); a.dbg_nn = h->dbg_nn.as<int32_t>(); }

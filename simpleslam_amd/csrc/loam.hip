@@ -950,8 +950,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         }
         const int st = loam_point<kChunk>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
-            const float* spq = a.src + (size_t)q * a.src_stride;
-            const size_t oi = a.src_indexed ? (size_t)__float_as_uint(spq[3]) : (size_t)q;   // original scan index
+            const size_t oi = (size_t)q;
             if (a.dbg_status) a.dbg_status[oi] = (int8_t)st;
             if (a.dbg_nn) { for (int j = 0; j < 5; ++j) a.dbg_nn[oi * 5 + j] = (int32_t)nn[j]; }
             if (a.dbg_rows) { for (int j = 0; j < 7; ++j) a.dbg_rows[oi * 7 + j] = st == 0 ? row[j] : 0.0; }

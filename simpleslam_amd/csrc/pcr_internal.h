@@ -103,7 +103,6 @@ struct LoamArgs {
     int32_t* dbg_nn;
     // optional query tile (multi-GPU): process only queries inside [lo,hi)
     struct NnCacheEntry* nn_cache;   // [n_src] neighbours of the previous iteration (loam.hip), or null
-    int32_t src_indexed;     // src is the cell-sorted float4 copy: .w = original scan index
     int32_t use_tile;
     double tile_lo[3], tile_hi[3];
     // profiling aid (pcr_params.reserved[0]): skip phases to price them.  bit0: candidate loop,
@@ -137,15 +136,6 @@ struct GridIndex {
                      std::string* err, double shift = 0.0, int pcl_mode = 0);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
-    void release();
-};
-
-// Stable sort of the scan by target-grid cell of the initially transformed point (query_sort.hip).
-struct QuerySorter {
-    DeviceBuf keys[2], vals[2], counts, sorted;
-    hipError_t sort(const float* d_src, size_t n, size_t stride_floats, const Pose16& pose, const GridIndex& grid,
-                    hipStream_t s, std::string* err);
-    const float* sorted_points() const { return sorted.as<float>(); }
     void release();
 };
 
