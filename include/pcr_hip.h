@@ -156,6 +156,25 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
 int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double leaf, void* out,
                      size_t out_capacity, int out_on_device, size_t* n_out);
 
+/* ---- the producer of `dst`: MapManager's key-frame store and sub-map assembly, on the device ----
+ * MapManager::updateMap (frontend/src/MapManager.cpp:151-201): key frames whose position lies within `radius`
+ * (mSurroundingKeyframeSearchRadius = 8 m, MapManager.hpp:68; squared L2 in double, strict '<' like
+ * KeyFramesKdtree::radiusSearch, kfs_adaptor.hpp:57-75) are transformed by their pose cast to float
+ * (pcp::transformPointCloud, common/pcp/pcp.hpp:38-62), concatenated and voxel-filtered with grid_size
+ * (pcp::voxelDownSample, pcp.hpp:14-20).  Key frames are copied into HBM when added; the assembled sub-map stays in
+ * HBM and is handed to pcr_scan2map_device / pcr_set_target as `dst` (pcr_map_submap: pointer valid until the next
+ * pcr_map_update or pcr_map_destroy).  pcr_map_submap_indices = mSubmapIdx (ascending key-frame index). */
+typedef struct pcr_map pcr_map;
+pcr_map* pcr_map_create(int device);                    /* device ordinal, -1 = current; NULL on failure (pcr_map_last_error(NULL)) */
+void pcr_map_destroy(pcr_map* m);
+const char* pcr_map_last_error(const pcr_map* m);
+/* KeyFrame{pc, pose} (common/types/basic.hpp:33-40); pose = 16 doubles column-major.  Index of the new key frame = count - 1. */
+int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_bytes, int on_device, const double pose[16]);
+int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes);
+int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap);
+const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes);
+int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size_t* n);
+
 /* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
  * accumulation done, partial sums stored.  out receives [launches][blocks][8] u64; call with out = NULL to size it. */

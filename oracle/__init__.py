@@ -445,3 +445,26 @@ def voxel_filter(pts, leaf):
     rc = L.oracle_voxel_filter(_p(pts), pts.shape[0], pts.shape[1], float(leaf), _p(out), pts.shape[0], C.byref(cnt))
     assert rc in (0, 1), rc
     return out[:cnt.value].copy(), rc == 1
+
+
+# ---------------------------------------------------------------------------
+# MapManager::updateMap sub-map assembly (oracle/submap_oracle.c)
+# ---------------------------------------------------------------------------
+def submap_assemble(clouds, poses, position, radius, grid):
+    """clouds: list of (n_k, stride) arrays; poses: list of 4x4 -> (sub-map, indices of the key frames used)."""
+    L = lib()
+    L.oracle_submap_assemble.restype = C.c_int
+    L.oracle_submap_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double, C.c_float,
+                                         C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    stride = clouds[0].shape[1]
+    cat = np.ascontiguousarray(np.concatenate([_f32(c) for c in clouds], 0), np.float32) if clouds else np.zeros((0, 4), np.float32)
+    counts = np.array([c.shape[0] for c in clouds], np.uint64)
+    P = np.ascontiguousarray(np.stack([np.asarray(T, np.float64).T.reshape(16) for T in poses]), np.float64)
+    pos = np.ascontiguousarray(position, np.float64).reshape(3)
+    sel = np.zeros(len(clouds), np.int64)
+    nsel, nout = C.c_size_t(0), C.c_size_t(0)
+    out = np.zeros((max(cat.shape[0], 1), stride), np.float32)
+    rc = L.oracle_submap_assemble(_p(cat), _p(counts), _p(P), len(clouds), stride, _p(pos), float(radius), float(grid),
+                                  _p(sel), C.byref(nsel), _p(out), cat.shape[0], C.byref(nout))
+    assert rc in (0, 1), rc
+    return out[:nout.value].copy(), sel[:nsel.value].copy()

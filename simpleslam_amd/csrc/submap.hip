@@ -1,0 +1,196 @@
+// submap.hip -- MapManager's key-frame store and sub-map assembly on the device (gfx950).
+//
+// The producer of `dst` for every scan2Map call:
+//   MapManager::updateMap            frontend/src/MapManager.cpp:151-201
+//     key frames within mSurroundingKeyframeSearchRadius (8 m, MapManager.hpp:68) of the current position:
+//     KeyFramesKdtree::radiusSearch  third_parties/nanoflann/include/nanoflann/kfs_adaptor.hpp:57-75  (squared L2 in
+//     double, strict '<' as nanoflann's RadiusResultSet accepts)
+//     per key frame pcp::transformPointCloud(pose cast to float)   common/pcp/pcp.hpp:38-62   -> concatenate
+//     pcp::voxelDownSample(mSubmap, mGridSize)                     common/pcp/pcp.hpp:14-20   (pcl::VoxelGrid)
+// Key frames stay in HBM; an update is one transform+concatenate launch plus pcr_voxel_filter, and the sub-map it
+// leaves in HBM is what pcr_scan2map_device takes as `dst` -- no host copy of the map on the registration path.
+// The result does not depend on the order in which the key frames are concatenated (centroids are summed in f64).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pcr_hip.h"
+
+namespace {
+
+struct KfDesc {              // one selected key frame in the concatenation
+    unsigned long long src_off;   // first float of its points in the store
+    unsigned int first_out;       // first output point
+    unsigned int n;
+    float R[9], t[3];             // pose_t cast to float (pcp.hpp:41-46), row-major rotation
+};
+
+// One thread per output point.  pto = tr * pfrom in float: ((r0 x + r1 y) + r2 z) + t per row -- Eigen's coefficient-based
+// 3x3 * 3x1 product followed by the translation; compiled without FMA contraction so that the voxel a point falls
+// into is the one the CPU computes.
+__global__ __launch_bounds__(256) void submap_transform_kernel(const float* __restrict__ store, const KfDesc* __restrict__ kf, int n_kf,
+                                                               unsigned int n_total, unsigned int stride, float* __restrict__ out) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    int lo = 0, hi = n_kf - 1;                    // last key frame whose first_out <= i
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (kf[mid].first_out <= i) lo = mid; else hi = mid - 1; }
+    const KfDesc d = kf[lo];
+    const float* p = store + d.src_off + (size_t)(i - d.first_out) * stride;
+    float* o = out + (size_t)i * stride;
+    const float x = p[0], y = p[1], z = p[2];
+    o[0] = ((d.R[0] * x + d.R[1] * y) + d.R[2] * z) + d.t[0];
+    o[1] = ((d.R[3] * x + d.R[4] * y) + d.R[5] * z) + d.t[1];
+    o[2] = ((d.R[6] * x + d.R[7] * y) + d.R[8] * z) + d.t[2];
+    for (unsigned int c = 3; c < stride; ++c) o[c] = p[c];          // data[3] = 1 and the intensity travel unchanged
+}
+
+struct Buf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        void* q = nullptr;
+        const size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) return e;
+        if (p) { e = hipMemcpy(q, p, cap, hipMemcpyDeviceToDevice); (void)hipFree(p); if (e != hipSuccess) { (void)hipFree(q); p = nullptr; cap = 0; return e; } }
+        p = q; cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct pcr_map {
+    int device = 0;
+    pcr_handle* filter = nullptr;     // device context of the voxel filter
+    size_t stride = 0;                // bytes per point, fixed by the first key frame
+    Buf store, concat, submap, desc;
+    size_t store_floats = 0;
+    struct Kf { size_t off_floats, n; double pose[16]; };
+    std::vector<Kf> kfs;
+    std::vector<long long> selected;  // mSubmapIdx
+    size_t n_submap = 0;
+    std::string err;
+};
+
+static thread_local std::string g_map_err;
+static int mfail(pcr_map* m, const std::string& s) { if (m) m->err = s; else g_map_err = s; return 1; }
+#define M_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return mfail(m, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+extern "C" {
+
+pcr_map* pcr_map_create(int device) {
+    pcr_params p;
+    pcr_default_params(&p);
+    p.device = device;
+    pcr_handle* h = pcr_create("loam", &p);
+    if (!h) { g_map_err = pcr_last_error(nullptr); return nullptr; }
+    pcr_map* m = new pcr_map;
+    m->filter = h;
+    if (device >= 0) m->device = device; else (void)hipGetDevice(&m->device);
+    return m;
+}
+
+void pcr_map_destroy(pcr_map* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    m->store.release(); m->concat.release(); m->submap.release(); m->desc.release();
+    pcr_destroy(m->filter);
+    delete m;
+}
+
+const char* pcr_map_last_error(const pcr_map* m) { return m ? m->err.c_str() : g_map_err.c_str(); }
+
+int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_bytes, int on_device, const double pose[16]) {
+    if (!m) return 1;
+    m->err.clear();
+    if (n && !pts) return mfail(m, "NULL cloud with nonzero size");
+    if (!pose) return mfail(m, "NULL pose");
+    if (stride_bytes < 12 || stride_bytes % 4) return mfail(m, "stride_bytes must be a multiple of 4 and >= 12");
+    if (m->stride == 0) m->stride = stride_bytes;
+    else if (m->stride != stride_bytes) return mfail(m, "all key frames of a map must share one point layout");
+    M_TRY(hipSetDevice(m->device));
+    const size_t nf = n * (stride_bytes / 4);
+    M_TRY(m->store.reserve((m->store_floats + nf + 4) * sizeof(float)));
+    if (nf) M_TRY(hipMemcpy(static_cast<float*>(m->store.p) + m->store_floats, pts, nf * sizeof(float),
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    pcr_map::Kf k;
+    k.off_floats = m->store_floats; k.n = n;
+    for (int i = 0; i < 16; ++i) k.pose[i] = pose[i];
+    m->kfs.push_back(k);
+    m->store_floats += nf;
+    return 0;
+}
+
+int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes) {
+    if (!m || !n_keyframes) return 1;
+    *n_keyframes = m->kfs.size();
+    return 0;
+}
+
+int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap) {
+    if (!m) return 1;
+    m->err.clear();
+    if (!position) return mfail(m, "NULL position");
+    if (!(grid_size > 0)) return mfail(m, "grid_size must be positive");
+    M_TRY(hipSetDevice(m->device));
+    m->selected.clear();
+    m->n_submap = 0;
+    if (n_submap) *n_submap = 0;
+    if (m->kfs.empty()) return 0;                          // "no any keyframes to update!!" (MapManager.cpp:166-169)
+    // radius search over the key-frame positions: squared distance in double, accumulated x, y, z; strict '<'
+    std::vector<KfDesc> desc;
+    size_t total = 0;
+    const double r2 = radius * radius;
+    for (size_t i = 0; i < m->kfs.size(); ++i) {
+        const pcr_map::Kf& k = m->kfs[i];
+        double d = 0;
+        for (int c = 0; c < 3; ++c) { const double e = position[c] - k.pose[12 + c]; d += e * e; }
+        if (!(d < r2)) continue;
+        m->selected.push_back((long long)i);
+        if (k.n == 0) continue;
+        if (total + k.n > 0xfffffff0ull) return mfail(m, "sub-map too large");
+        KfDesc e;
+        e.src_off = k.off_floats; e.first_out = (unsigned int)total; e.n = (unsigned int)k.n;
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) e.R[r * 3 + c] = (float)k.pose[c * 4 + r]; e.t[r] = (float)k.pose[12 + r]; }
+        desc.push_back(e);
+        total += k.n;
+    }
+    if (total == 0) return 0;
+    const size_t sf = m->stride / 4;
+    M_TRY(m->concat.reserve(total * m->stride));
+    M_TRY(m->submap.reserve(total * m->stride));
+    M_TRY(m->desc.reserve(desc.size() * sizeof(KfDesc)));
+    M_TRY(hipMemcpy(m->desc.p, desc.data(), desc.size() * sizeof(KfDesc), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(submap_transform_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, 0, static_cast<const float*>(m->store.p),
+                       static_cast<const KfDesc*>(m->desc.p), (int)desc.size(), (unsigned int)total, (unsigned int)sf, static_cast<float*>(m->concat.p));
+    M_TRY(hipGetLastError());
+    M_TRY(hipDeviceSynchronize());                         // the filter runs on its own (non-blocking) stream
+    size_t n_out = 0;
+    if (pcr_voxel_filter(m->filter, m->concat.p, total, m->stride, 1, grid_size, m->submap.p, total, 1, &n_out))
+        return mfail(m, std::string("voxel filter: ") + pcr_last_error(m->filter));
+    m->n_submap = n_out;
+    if (n_submap) *n_submap = n_out;
+    return 0;
+}
+
+const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes) {
+    if (!m) return nullptr;
+    if (n) *n = m->n_submap;
+    if (stride_bytes) *stride_bytes = m->stride;
+    return m->n_submap ? m->submap.p : nullptr;
+}
+
+int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size_t* n) {
+    if (!m || !n) return 1;
+    *n = m->selected.size();
+    if (!idx) return 0;
+    if (capacity < m->selected.size()) return 1;
+    for (size_t i = 0; i < m->selected.size(); ++i) idx[i] = m->selected[i];
+    return 0;
+}
+
+}  // extern "C"

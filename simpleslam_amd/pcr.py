@@ -49,6 +49,8 @@ ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+    "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_submap",
+    "pcr_map_submap_indices",
 ]
 
 _lib = None
@@ -95,6 +97,18 @@ def load_library():
     L.pcr_set_query_tile.argtypes = [vp, dp, dp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.pcr_map_create.argtypes = [C.c_int]
+    L.pcr_map_create.restype = vp
+    L.pcr_map_destroy.argtypes = [vp]
+    L.pcr_map_destroy.restype = None
+    L.pcr_map_last_error.argtypes = [vp]
+    L.pcr_map_last_error.restype = C.c_char_p
+    L.pcr_map_add_keyframe.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp]
+    L.pcr_map_keyframes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.pcr_map_update.argtypes = [vp, dp, C.c_double, C.c_double, C.POINTER(C.c_size_t)]
+    L.pcr_map_submap.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.pcr_map_submap.restype = vp
+    L.pcr_map_submap_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -192,6 +206,23 @@ class PointCloudRegister:
 
     def invalidateTarget(self):
         self._check(self._lib.pcr_invalidate_target(self._h))
+
+    def scan2MapSubmap(self, src, submap, pose):
+        """scan2Map with the device-resident sub-map of a SubMap as `dst` (no host copy of the map)."""
+        p, n, s, dev, _k = _cloud(src)
+        dp, dn, ds = submap.pointer()
+        if ds != s:
+            raise ValueError("scan and sub-map must share one point layout")
+        if not dev:
+            import torch
+            t = torch.from_numpy(np.ascontiguousarray(src, np.float32)).cuda()
+            p, _k = C.c_void_p(t.data_ptr()), t
+        pc = _pose_in(pose)
+        conv = C.c_int(0)
+        self._check(self._lib.pcr_scan2map_device(self._h, p, n, C.c_void_p(dp), dn, s, pc.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
+        np.asarray(pose)[...] = _pose_out(pc)
+        self.isConverge = bool(conv.value)
+        return self.isConverge
 
     # -- the step before the path ------------------------------------------------
     def voxelDownSample(self, cloud, grid_size):
@@ -356,3 +387,72 @@ def comm_unique_id():
     if load_library().pcr_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
         raise PcrError(load_library().pcr_last_error(None).decode())
     return bytes(buf)
+
+
+class SubMap:
+    """The key-frame store and sub-map of the reference's MapManager (frontend/src/MapManager.cpp:151-201), kept in HBM.
+
+    addKeyFrame(points, pose); updateMap(position) selects the key frames within `radius` (8 m, MapManager.hpp:68), transforms
+    and concatenates them and voxel-filters the result; `pointer()` is the device-resident sub-map that
+    PointCloudRegister.scan2MapSubmap registers against without a host copy."""
+
+    def __init__(self, device=-1):
+        self._lib = load_library()
+        self._m = self._lib.pcr_map_create(int(device))
+        if not self._m:
+            raise PcrError(self._lib.pcr_map_last_error(None).decode())
+
+    def __del__(self):
+        try:
+            if self._m:
+                self._lib.pcr_map_destroy(self._m)
+                self._m = None
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise PcrError(self._lib.pcr_map_last_error(self._m).decode())
+
+    def addKeyFrame(self, cloud, pose):
+        p, n, s, dev, _keep = _cloud(cloud)
+        pc = _pose_in(pose)
+        self._check(self._lib.pcr_map_add_keyframe(self._m, p, n, s, dev, pc.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def keyframes(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.pcr_map_keyframes(self._m, C.byref(n)))
+        return n.value
+
+    def updateMap(self, position, radius=8.0, grid_size=0.4):
+        pos = np.ascontiguousarray(position, np.float64).reshape(3)
+        n = C.c_size_t(0)
+        self._check(self._lib.pcr_map_update(self._m, pos.ctypes.data_as(C.POINTER(C.c_double)), float(radius), float(grid_size), C.byref(n)))
+        return n.value
+
+    def pointer(self):
+        """-> (device pointer, number of points, stride in bytes) of the assembled sub-map."""
+        n, s = C.c_size_t(0), C.c_size_t(0)
+        p = self._lib.pcr_map_submap(self._m, C.byref(n), C.byref(s))
+        return p, n.value, s.value
+
+    def submapIdx(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.pcr_map_submap_indices(self._m, None, 0, C.byref(n)))
+        idx = np.zeros(n.value, np.int64)
+        if n.value:
+            self._check(self._lib.pcr_map_submap_indices(self._m, idx.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return idx
+
+    def download(self):
+        """The sub-map as a host array (tests, visualisation)."""
+        import torch
+        p, n, s = self.pointer()
+        out = torch.empty((n, s // 4), dtype=torch.float32, device="cuda")
+        if n:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(p), n * s, 3)      # hipMemcpyDeviceToDevice
+            if rc:
+                raise PcrError(f"hipMemcpy failed: {rc}")
+        return out.cpu().numpy()

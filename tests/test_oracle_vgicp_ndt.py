@@ -204,3 +204,20 @@ def test_voxel_filter_oracle_against_numpy():
     # leaf too small: input back
     o2, unf = oracle.voxel_filter(pts[:100], 1e-6)
     assert unf and o2.shape == (100, 4)
+
+
+def test_submap_oracle_selection_and_transform():
+    """oracle/submap_oracle.c: strict double-precision radius test, float transform, voxel filter of the union."""
+    rng = np.random.default_rng(9)
+    clouds = [rng.uniform(-5, 5, (200, 4)).astype(np.float32) for _ in range(4)]
+    poses = []
+    for x in (0.0, 4.0, 8.0, 20.0):
+        T = np.eye(4); T[0, 3] = x; T[:3, :3] = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+        poses.append(T)
+    sub, sel = oracle.submap_assemble(clouds, poses, np.zeros(3), 8.0, 0.5)
+    np.testing.assert_array_equal(sel, [0, 1])                  # 8.0 is not < 8.0
+    cat = np.concatenate([np.concatenate([(c[:, :3] @ T[:3, :3].T.astype(np.float32) + T[:3, 3].astype(np.float32)), c[:, 3:]], 1)
+                          for c, T in zip(clouds[:2], poses[:2])], 0).astype(np.float32)
+    ref, _ = oracle.voxel_filter(cat, 0.5)
+    assert sub.shape == ref.shape
+    np.testing.assert_allclose(sub, ref, rtol=0, atol=1e-5)

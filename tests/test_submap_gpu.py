@@ -1,0 +1,84 @@
+"""MapManager::updateMap on the device (pcr_map_*) vs the CPU oracle: which key frames are used and which voxel every
+transformed point falls into are exact; centroids agree to PCL's float-accumulation rounding.  The assembled sub-map
+then serves as `dst` of scan2Map without leaving HBM."""
+import numpy as np
+import pytest
+
+import oracle
+from simpleslam_amd import LoamRegister, SubMap, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def keyframes():
+    """A short trajectory through the synthetic world: every key frame is a down-sampled scan in ITS lidar frame plus its pose."""
+    world, _ = synth.make_map(20_000, seed=91)
+    kfs = []
+    for j in range(14):
+        scan, T = synth.make_scan(world, j, seed=91, beams=32, azimuths=512)
+        ds, _ = oracle.voxel_filter(scan, 0.4)            # LidarOdometry keeps the down-sampled scan as the key frame's cloud
+        kfs.append((ds, T))
+    return world, kfs
+
+
+def test_assembly_matches_oracle(gpu, keyframes):
+    world, kfs = keyframes
+    sm = SubMap()
+    for c, T in kfs:
+        sm.addKeyFrame(c, T)
+    assert sm.keyframes() == len(kfs)
+    for center, radius in ((kfs[3][1][:3, 3], 8.0), (kfs[10][1][:3, 3], 3.0), (kfs[0][1][:3, 3] + 100.0, 8.0)):
+        n = sm.updateMap(center, radius=radius, grid_size=0.4)
+        ref, sel = oracle.submap_assemble([c for c, _ in kfs], [T for _, T in kfs], center, radius, 0.4)
+        np.testing.assert_array_equal(sm.submapIdx(), sel)                  # mSubmapIdx
+        got = sm.download()
+        assert n == got.shape[0] == ref.shape[0]                            # same occupied voxels
+        if n:
+            np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=5e-4)
+            np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=1e-5, atol=1e-3)
+    # the far-away centre selects nothing: empty sub-map
+    assert sm.updateMap(kfs[0][1][:3, 3] + 100.0) == 0 and sm.pointer()[1] == 0
+
+
+def test_radius_is_strict_and_in_double(gpu):
+    sm = SubMap()
+    pts = np.array([[1.0, 0.0, 0.0, 5.0]], np.float32)
+    for x in (0.0, 3.0, 8.0, np.nextafter(8.0, 0.0)):
+        T = np.eye(4); T[0, 3] = x
+        sm.addKeyFrame(pts, T)
+    sm.updateMap(np.zeros(3), radius=8.0, grid_size=0.5)
+    np.testing.assert_array_equal(sm.submapIdx(), [0, 1, 3])               # the key frame at exactly 8 m is out (dist < radius)
+
+
+def test_submap_feeds_scan2map_without_leaving_hbm(gpu, keyframes):
+    world, kfs = keyframes
+    sm = SubMap()
+    for c, T in kfs[:10]:
+        sm.addKeyFrame(c, T)
+    scan, T_true = synth.make_scan(world, 10, seed=91, beams=32, azimuths=512)
+    sm.updateMap(T_true[:3, 3], radius=8.0, grid_size=0.4)
+    init = synth.perturb(T_true, 91, trans=0.1, rot_deg=0.5)
+    reg = LoamRegister()
+    scan_ds = reg.voxelDownSample(scan, 0.4)
+    pose = init.copy()
+    reg.scan2MapSubmap(scan_ds, sm, pose)
+    # the same registration against the downloaded sub-map through the ordinary entry point
+    host = sm.download()
+    pose2 = init.copy()
+    reg.scan2Map(scan_ds, host, pose2)
+    np.testing.assert_array_equal(pose, pose2)
+    et, er = synth.pose_error(pose, T_true)
+    assert et < 0.1 and er < 0.01                                           # and it localises the new scan in the map of the old ones
+    # and against the oracle's LOAM on the oracle's sub-map: same pose to the usual bar
+    ref_map, _ = oracle.submap_assemble([c for c, _ in kfs[:10]], [T for _, T in kfs[:10]], T_true[:3, 3], 8.0, 0.4)
+    po, _, _ = oracle.loam_scan2map(scan_ds, ref_map, init)
+    dt, dr = synth.pose_error(pose, po)
+    assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_mixed_layouts_rejected(gpu):
+    sm = SubMap()
+    sm.addKeyFrame(np.zeros((3, 4), np.float32), np.eye(4))
+    with pytest.raises(Exception):
+        sm.addKeyFrame(np.zeros((3, 8), np.float32), np.eye(4))
