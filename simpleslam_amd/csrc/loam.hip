@@ -934,8 +934,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         union { NnCacheEntry e; float4 v[8]; } ce;
         ce.e.flags = 0;
         if (base == blk * 256) {
+            // EVERY wave waits for its own LDS-DMA, also one without a single valid query (its lanes fetched a dummy address):
+            // the staging area is reused right after the barrier, and a transfer still in flight would land in the search
+            // scratch of the other waves.
+            if (use_cache) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (use_cache && valid) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own LDS-DMA writes
 #pragma unroll
                 for (int f = 0; f < 8; ++f) ce.v[f] = sh_pre[f * 256 + tid];
             }

@@ -188,6 +188,24 @@ def test_first_call_after_cell_table_growth(gpu, world_100k):
     assert dt < 1e-9 and dr < 1e-9
 
 
+@pytest.mark.parametrize("n_src", [1, 63, 100, 257, 1000, 4097])
+def test_ragged_scan_sizes(gpu, world_small, n_src):
+    """Scan sizes that leave lanes, whole waves and whole blocks without a query (the cache prefetch of such waves must
+    still be complete before its LDS staging area is reused)."""
+    w = world_small
+    scan = w["scan"][:: max(1, w["scan"].shape[0] // n_src)][:n_src]
+    assert scan.shape[0] == n_src
+    reg = LoamRegister(loam_iters=6, loam_early_exit=0)
+    for _ in range(2):
+        pose = w["init"].copy()
+        conv = reg.scan2Map(scan, w["map"], pose)
+    po, co, _ = oracle.loam_scan2map(scan, w["map"], w["init"], oracle.loam_params(iters=6, early_exit=0))
+    assert conv == co
+    if np.isfinite(po).all():
+        dt, dr = synth.pose_error(pose, po)
+        assert dt < 1e-9 and dr < 1e-9
+
+
 def test_unknown_method_raises():
     from simpleslam_amd import make_register
     with pytest.raises(RuntimeError):
