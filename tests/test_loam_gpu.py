@@ -206,6 +206,29 @@ def test_ragged_scan_sizes(gpu, world_small, n_src):
         assert dt < 1e-9 and dr < 1e-9
 
 
+def test_randomised_configurations(gpu):
+    """Twelve seeded draws of world size, scan shape, initial error and gate/iteration parameters: the device path and the
+    oracle must agree on convergence, on the number of iterations consumed and on the pose (discrete gates included)."""
+    rng = np.random.default_rng(424242)
+    for case in range(12):
+        n_map = int(rng.integers(4_000, 60_000))
+        beams, az = int(rng.choice([8, 16, 32])), int(rng.choice([128, 256, 512]))
+        world, m = synth.make_map(n_map, seed=1000 + case)
+        scan, T = synth.make_scan(world, int(rng.integers(0, 5)), seed=1000 + case, beams=beams, azimuths=az)
+        init = synth.perturb(T, 2000 + case, trans=float(rng.uniform(0.02, 0.4)), rot_deg=float(rng.uniform(0.1, 3.0)))
+        kw = dict(iters=int(rng.integers(2, 12)), early_exit=int(rng.integers(0, 2)), knn_max_sq=float(rng.choice([0.5, 1.0, 2.0, 4.0])),
+                  plane_thresh=float(rng.uniform(0.1, 0.3)), point_thresh=float(rng.uniform(0.05, 0.3)))
+        reg = LoamRegister(loam_iters=kw["iters"], loam_early_exit=kw["early_exit"], loam_knn_max_sq=kw["knn_max_sq"],
+                           loam_plane_thresh=kw["plane_thresh"], loam_point_thresh=kw["point_thresh"], record_trace=1)
+        pose = init.copy()
+        conv = reg.scan2Map(scan, m, pose)
+        po, co, info = oracle.loam_scan2map(scan, m, init, oracle.loam_params(**kw))
+        assert conv == co, (case, kw)
+        assert reg.trace()["iters_run"] == info["iters_run"], (case, kw)
+        dt, dr = synth.pose_error(pose, po)
+        assert dt < 1e-9 and dr < 1e-9, (case, kw, dt, dr)
+
+
 def test_unknown_method_raises():
     from simpleslam_amd import make_register
     with pytest.raises(RuntimeError):
