@@ -84,3 +84,23 @@ def test_golden_fixture(gpu):
     assert conv == bool(g["converged"]) and reg.stats()["iterations"] == int(g["iterations"])
     dt, dr = synth.pose_error(pose, g["pose"])
     assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_randomised_configurations(gpu):
+    """Seeded draws of world, scan, initial error and resolution: same convergence flag, iteration count and pose as the
+    oracle (float inner math on both sides; the device sums in a different order, hence the 1e-4 bar and not equality)."""
+    rng = np.random.default_rng(555)
+    for case in range(5):
+        world, m = synth.make_map(int(rng.integers(100_000, 250_000)), seed=5000 + case, spacing=0.2)
+        scan, T = synth.make_scan(world, int(rng.integers(0, 4)), seed=5000 + case, beams=int(rng.choice([16, 32])), azimuths=256)
+        init = synth.perturb(T, 6000 + case, trans=float(rng.uniform(0.03, 0.2)), rot_deg=float(rng.uniform(0.1, 1.0)))
+        res = float(rng.choice([1.0, 1.5, 2.0]))
+        reg = NdtRegister(ndt_resolution=res)
+        pose = init.copy()
+        conv = reg.scan2Map(scan, m, pose)
+        po, co, info = oracle.ndt_scan2map(scan, m, init, oracle.ndt_params(resolution=res))
+        assert np.isfinite(po).all() and np.isfinite(pose).all(), case
+        assert conv == co, (case, res)
+        assert reg.stats()["iterations"] == info["iterations"], (case, res)
+        dt, dr = synth.pose_error(pose, po)
+        assert dt <= 1e-4 and dr <= 1e-4, (case, res, dt, dr)

@@ -100,3 +100,22 @@ def test_golden_fixture(gpu):
     dt, dr = synth.pose_error(pose, g["pose"])
     assert dt <= 1e-4 and dr <= 1e-4
     np.testing.assert_allclose(reg.getFitnessScore(), float(g["fitness"]), rtol=1e-5)
+
+
+def test_randomised_configurations(gpu):
+    """Seeded draws of world, scan, initial error and voxel resolution: same convergence flag, same number of outer
+    iterations, same pose (both end in a Matrix4f) as the oracle."""
+    rng = np.random.default_rng(777)
+    for case in range(5):
+        world, m = synth.make_map(int(rng.integers(15_000, 50_000)), seed=3000 + case)
+        scan, T = synth.make_scan(world, int(rng.integers(0, 4)), seed=3000 + case, beams=int(rng.choice([16, 32])), azimuths=256)
+        init = synth.perturb(T, 4000 + case, trans=float(rng.uniform(0.05, 0.3)), rot_deg=float(rng.uniform(0.2, 2.0)))
+        res = float(rng.choice([0.5, 1.0, 1.5]))
+        reg = VgicpRegister(vgicp_resolution=res)
+        pose = init.copy()
+        conv = reg.scan2Map(scan, m, pose)
+        po, co, info = oracle.vgicp_scan2map(scan, m, init, oracle.vgicp_params(resolution=res, threads=8))
+        assert conv == co, (case, res)
+        assert reg.stats()["iterations"] == info["outer"], (case, res)
+        dt, dr = synth.pose_error(pose, po)
+        assert dt <= 1e-4 and dr <= 1e-4, (case, res, dt, dr)
