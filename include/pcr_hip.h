@@ -68,7 +68,7 @@ typedef struct pcr_params {
 
     int32_t record_trace;      /* 1: keep per-iteration normal equations for pcr_get_trace */
     /* reserved[]: all zero by default.  Development switches of the LOAM path (results are unchanged except where noted):
-     *   [0] ablation mask for profiling (results become meaningless)   [1] unused
+     *   [0] ablation mask for profiling (only in a -DPCR_ABLATION build; results become meaningless)   [1] unused
      *   [2] = 1: disable the temporal-coherence neighbour cache          [3] = 1: record the in-kernel timeline (pcr_get_timeline)
      *   [4] = 1: two-waves-per-SIMD variant of the iterate kernel -- ~3 % slower for one handle, ~25 % more scans/s when
      *            several handles register scans concurrently on one GPU (their blocks can then share the CUs) */
@@ -177,7 +177,8 @@ int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size
 
 /* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
- * accumulation done, partial sums stored.  out receives [launches][blocks][8] u64; call with out = NULL to size it. */
+ * accumulation done, partial sums stored (+ the fold inside the prologue and three stamps of the dense search).  out receives
+ * [launches][blocks][16] u64; call with out = NULL to size it. */
 int pcr_get_timeline(pcr_handle* h, uint64_t* out, size_t capacity, int* launches, int* blocks);
 
 /* NDT introspection: one computeDerivatives pass (ndt_omp_impl.hpp:180-285) at the parameter vector

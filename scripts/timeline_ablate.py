@@ -1,4 +1,5 @@
-"""searched-stage duration of the first (full-search) launch under the ablation masks of pcr_params.reserved[0]."""
+"""searched-stage duration of the first (full-search) launch under the ablation masks of pcr_params.reserved[0].
+Needs a library built with the switches compiled in:  make -C simpleslam_amd/csrc clean all EXTRA=-DPCR_ABLATION"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import torch

@@ -31,3 +31,8 @@ t = tl[6]; d = np.diff(t[:, :7], axis=1)
 for b in np.argsort(-t[:, 6])[:12]:
     print(b, f'entry={t[b,0]:5.2f} stored={t[b,6]:6.2f}', ' '.join(f'{names[i + 1]}:{d[b, i]:6.2f}' for i in range(6)))
 print('launch 6 stored-time percentiles', np.percentile(t[:, 6], [0, 10, 50, 90, 99, 100]))
+print('dense search of launch 0 (thread 0 of each block): posted -> ranges in LDS -> first chunk -> stream done -> searched')
+t = tl[0]
+ok = t[:, 10] > 0
+for a, b, n in ((2, 8, 'ranges'), (8, 9, 'first chunk'), (9, 10, 'stream'), (10, 3, 'ties + exchange')):
+    print(f'  {n:16s} {np.mean(t[ok, b] - t[ok, a]):6.2f} us')

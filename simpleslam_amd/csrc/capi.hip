@@ -152,7 +152,7 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
     a->ablate = h->prm.reserved[0];
     a->coresident = h->prm.reserved[4] == 1;
     if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 128) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
-    if (h->prm.reserved[3] == 1 && h->timeline.reserve((size_t)(std::max(1, h->prm.loam_iters) + 1) * kMaxPartials * 8 * sizeof(unsigned long long)) == hipSuccess)
+    if (h->prm.reserved[3] == 1 && h->timeline.reserve((size_t)(std::max(1, h->prm.loam_iters) + 1) * kMaxPartials * kTimelineSlots * sizeof(unsigned long long)) == hipSuccess)
         a->timeline = h->timeline.as<unsigned long long>();
     a->use_tile = h->use_tile;
     for (int d = 0; d < 3; ++d) { a->tile_lo[d] = h->tile_lo[d]; a->tile_hi[d] = h->tile_hi[d]; }
@@ -1117,10 +1117,11 @@ int pcr_get_timeline(pcr_handle* h, uint64_t* out, size_t capacity, int* launche
     if (launches) *launches = nl;
     if (blocks) *blocks = nb;
     if (!out) return 0;
-    if (capacity < (size_t)nl * nb * 8) return fail(h, "timeline buffer too small");
+    if (capacity < (size_t)nl * nb * kTimelineSlots) return fail(h, "timeline buffer too small");
     H_TRY(hipStreamSynchronize(h->stream));
     for (int l = 0; l < nl; ++l)
-        H_TRY(hipMemcpy(out + (size_t)l * nb * 8, h->timeline.as<unsigned long long>() + (size_t)l * kMaxPartials * 8, (size_t)nb * 8 * sizeof(uint64_t),
+        H_TRY(hipMemcpy(out + (size_t)l * nb * kTimelineSlots, h->timeline.as<unsigned long long>() + (size_t)l * kMaxPartials * kTimelineSlots,
+                        (size_t)nb * kTimelineSlots * sizeof(uint64_t),
                         hipMemcpyDeviceToHost));
     return 0;
 }

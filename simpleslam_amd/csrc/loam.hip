@@ -23,6 +23,15 @@
 
 namespace pcr {
 
+// The phase-skipping switches of pcr_params.reserved[0] (scripts/timeline_ablate.py) exist only in a build with
+// -DPCR_ABLATION: in the candidate loop their tests alone were two scalar branches per slot.
+#ifdef PCR_ABLATION
+static constexpr bool kAblation = true;
+#else
+static constexpr bool kAblation = false;
+#endif
+
+
 // ------------------------------------------------------------------------------
 // per-lane exact 5-NN on the grid
 // ------------------------------------------------------------------------------
@@ -91,7 +100,7 @@ __device__ __forceinline__ void knn_consider(Knn5& s, KnnQuery& q, const float4 
     // slots past the end of the run (and NaN distances) become +inf: the pass below is then a no-op
     double t = (valid && d == d) ? d : __longlong_as_double(0x7ff0000000000000ll);
     uint32_t tpos = pos;
-    if (q.ablate & 32) { q.l6 = t < q.l6 ? t : q.l6; return; }
+    if (kAblation && (q.ablate & 32)) { q.l6 = t < q.l6 ? t : q.l6; return; }
     knn_bubble(s, t, tpos);
     // what fell off bounds the 6th neighbour (an evicted sentinel is not a point: it bounds nothing)
     const double out = tpos == 0xffffffffu ? q.l6 : t;
@@ -104,7 +113,7 @@ struct KnnCursor { int r; uint32_t j, e; };
 // exceeds the current 5th distance are skipped; the bound only shrinks, so this is safe ahead of time)
 __device__ __forceinline__ bool knn_advance(KnnCursor& c, const KnnShared& sh, KnnQuery& q, const Knn5& s, int tid) {
     while (c.j >= c.e) {
-        if (++c.r > 8) return false;
+        if (++c.r > 8) { c.r = 9; c.j = c.e = 0u; return false; }
         c.j = sh.rs[c.r][tid];
         c.e = sh.re[c.r][tid];
         const double b = row_bound(q, c.r);
@@ -114,6 +123,31 @@ __device__ __forceinline__ bool knn_advance(KnnCursor& c, const KnnShared& sh, K
         const float r4 = sqrtf((float)s.d[4]);
         const double thresh = s.d[4] + (double)(0.1f * r4 + 0.0025f);   // (r + 0.05)^2 - r^2
         if (b > thresh) { c.j = c.e; q.l6 = b < q.l6 ? b : q.l6; }   // skipped points are at least sqrt(b) away
+    }
+    return true;
+}
+
+// Up to kChunk consecutive candidates of a lane's stream: [a, a + an) from the current run, then [b, b + bn) from the
+// next eligible one.
+struct KnnPair { uint32_t a, an, b, bn; };
+
+__device__ __forceinline__ uint32_t knn_pair_pos(const KnnPair& p, int i) {
+    const uint32_t o = (uint32_t)i - p.an;                      // wraps for i < an
+    return (uint32_t)i < p.an ? p.a + (uint32_t)i : (o < p.bn ? p.b + o : p.a);     // slots past the end re-read a valid point
+}
+
+template <int kChunk>
+__device__ __forceinline__ bool knn_next(KnnCursor& c, const KnnShared& sh, KnnQuery& q, const Knn5& s, int tid, KnnPair& out) {
+    out.a = 0u; out.an = 0u; out.b = 0u; out.bn = 0u;
+    if (c.r > 8) return false;
+    if (c.j >= c.e && !knn_advance(c, sh, q, s, tid)) return false;
+    out.a = c.j;
+    out.an = min(c.e - c.j, (uint32_t)kChunk);
+    c.j += out.an;
+    if (out.an < (uint32_t)kChunk && knn_advance(c, sh, q, s, tid)) {      // the run ended inside the chunk: continue in the next one
+        out.b = c.j;
+        out.bn = min(c.e - c.j, (uint32_t)kChunk - out.an);
+        c.j += out.bn;
     }
     return true;
 }
@@ -158,7 +192,7 @@ template <int kChunk>
 __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __restrict__ pts,
                                           const uint32_t* __restrict__ cell_start, double qx, double qy, double qz,
                                           double max_sq, Knn5& s, KnnShared& sh, bool active, double* l6_out, bool keep,
-                                          double seed_bound, int ablate) {
+                                          double seed_bound, int ablate, unsigned long long* tl = nullptr) {
     const int tid = threadIdx.x;
     if (!keep) {
         // Empty slots are sentinels (index 0xffffffff) at an upper bound of the 5th distance: the gate
@@ -197,37 +231,43 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
     q.zlo = rz - fz * h.cell; q.zhi = (fz + 1.0) * h.cell - rz;
     q.l6 = max_sq;   // points outside the 3x3x3 block are >= one cell (>= sqrt(max_sq)) away
     q.ablate = ablate;
+    if (tl) tl[8] = wall_clock64();       // row ranges in LDS
     // (each lane reads back only what it wrote itself: no barrier needed)
+    // A chunk = the next kChunk candidates of this lane's stream, taken from the rest of the current row run and, when
+    // that is shorter, from the head of the next eligible row (a run holds ~5 points on average: chunks cut at every run
+    // end were ~45 % empty slots, and an empty slot costs as much as a real candidate).  Slot i reads a + i or
+    // b + (i - an): straight-line code, no per-slot cursor logic.
     KnnCursor cur{-1, 0u, 0u};
-    bool has = knn_advance(cur, sh, q, s, tid);
+    KnnPair pc, pn;
+    bool has = knn_next<kChunk>(cur, sh, q, s, tid, pc);
     float4 c[kChunk];
 #pragma unroll
     for (int i = 0; i < kChunk; ++i) c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (has) {
 #pragma unroll
-        for (int i = 0; i < kChunk; ++i) c[i] = pts[cur.j + i];
+        for (int i = 0; i < kChunk; ++i) c[i] = pts[knn_pair_pos(pc, i)];
     }
+    if (tl) { float t_ = 0.f; for (int i = 0; i < kChunk; ++i) t_ += c[i].x; if (t_ == 1.2345e38f) q.l6 = 0; tl[9] = wall_clock64(); }   // first chunk arrived
     while (has) {
-        KnnCursor nxt = cur;
-        nxt.j += kChunk;
-        const bool has_n = knn_advance(nxt, sh, q, s, tid);
+        const bool has_n = knn_next<kChunk>(cur, sh, q, s, tid, pn);     // sees the list before this chunk's insertions: bounds only shrink
         float4 n[kChunk];
 #pragma unroll
         for (int i = 0; i < kChunk; ++i) n[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_n) {
 #pragma unroll
-            for (int i = 0; i < kChunk; ++i) n[i] = pts[nxt.j + i];
+            for (int i = 0; i < kChunk; ++i) n[i] = pts[knn_pair_pos(pn, i)];
         }
 #pragma unroll
         for (int i = 0; i < kChunk; ++i) {
-            if (q.ablate & 16) { q.l6 += (double)c[i].x; }
-            else knn_consider(s, q, c[i], cur.j + i, cur.j + i < cur.e);
+            if (kAblation && (q.ablate & 16)) { q.l6 += (double)c[i].x; }
+            else knn_consider(s, q, c[i], knn_pair_pos(pc, i), (uint32_t)i < pc.an + pc.bn);
         }
 #pragma unroll
         for (int i = 0; i < kChunk; ++i) c[i] = n[i];
-        cur = nxt; has = has_n;
+        pc = pn; has = has_n;
     }
     *l6_out = q.l6;
+    if (tl) tl[10] = wall_clock64();      // candidate stream done
     if (inside) {
         // detect exact distance ties (inside the list, or between its last entry and anything left out); those rare
         // queries are redone with the index tie-break.  The original indices are NOT fetched here: the owner of the
@@ -554,7 +594,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     double l6 = 0.0;
     const int tid = threadIdx.x;
     // ---- post the queries that need a search ----
-    const bool miss = active && !hit && !(a.ablate & 1);
+    const bool miss = active && !hit && !(kAblation && (a.ablate & 1));
     if (tid == 0) ex.count = 0;
     __syncthreads();
     if (miss) {
@@ -602,7 +642,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             Knn5 r;
             double rl6 = 0.0;
             const bool ok = knn5_grid<kChunk>(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
-                                      a.c.knn_max_sq, r, sh, worker, &rl6, false, worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate);
+                                      a.c.knn_max_sq, r, sh, worker, &rl6, false, worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate, tl);
             if (worker) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) { ex.u.res.d[j][owner] = r.d[j]; ex.u.res.pos[j][owner] = r.pos[j]; ex.u.res.idx[j][owner] = r.idx[j]; }
@@ -642,7 +682,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     if (reuse) {
         x[0] = ce_in.x[0]; x[1] = ce_in.x[1]; x[2] = ce_in.x[2];
         plane_ok = (ce_in.flags & 4u) != 0;
-    } else if (real5 && !(a.ablate & 2)) {
+    } else if (real5 && !(kAblation && (a.ablate & 2))) {
         double Aq[5][3];
 #pragma unroll
         for (int j = 0; j < 5; ++j) { Aq[j][0] = A[j][0]; Aq[j][1] = A[j][1]; Aq[j][2] = A[j][2]; }
@@ -667,7 +707,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             // a hit whose order changed keeps the anchor of its search
             ce.q0[0] = hit ? ce_in.q0[0] : px; ce.q0[1] = hit ? ce_in.q0[1] : py; ce.q0[2] = hit ? ce_in.q0[2] : pz;
             ce.l6 = hit ? ce_in.l6 : __double2float_rd(sqrt(l6) * (1.0 - 1e-15));
-            ce.flags = (real5 ? 1u : 0u) | ((real5 && !(a.ablate & 2)) ? 2u : 0u) | (plane_ok ? 4u : 0u);
+            ce.flags = (real5 ? 1u : 0u) | ((real5 && !(kAblation && (a.ablate & 2))) ? 2u : 0u) | (plane_ok ? 4u : 0u);
             ce.pad = 0;
             a.nn_cache[qi] = ce;
         }
@@ -678,7 +718,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
 #pragma unroll
     for (int j = 0; j < 5; ++j) nn_idx[j] = s.idx[j];
     if (!gate_knn) return 1;
-    if (a.ablate & 2) return 2;
+    if (kAblation && (a.ablate & 2)) return 2;
     if (!plane_ok) return 2;
     const double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     const double dist = (qx * x[0] + qy * x[1] + qz * x[2] + 1.0) / xn;   // LoamRegister.hpp:75-77
@@ -774,7 +814,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         __syncthreads();
         return true;
     }
-    if (a.ablate & 4) {
+    if (kAblation && (a.ablate & 4)) {
         if (t == 0) sh->done = k >= a.c.iters;
         if (blockIdx.x == 0 && t == 0) { *cur = *prev; cur->done = k >= a.c.iters; cur->iters_run = k; }
         __syncthreads();
@@ -878,7 +918,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
     MissExchange& sh_ex = reinterpret_cast<SearchLds*>(sh_ov)->ex;   // also holds the rows: [component][point] s*J (6), s*d, accepted flag
     double* const sh_rows = sh_ex.u.rows;
     const int tid = threadIdx.x;
-    unsigned long long* const tl = (a.timeline && tid == 0) ? a.timeline + ((size_t)k * kMaxPartials + blockIdx.x) * 8 : nullptr;
+    unsigned long long* const tl = (a.timeline && tid == 0) ? a.timeline + ((size_t)k * kMaxPartials + blockIdx.x) * kTimelineSlots : nullptr;
     if (tl) tl[0] = wall_clock64();
     // XCD-aware mapping: consecutive logical blocks (adjacent lidar rings) share an XCD's L2
     uint32_t blk = blockIdx.x;

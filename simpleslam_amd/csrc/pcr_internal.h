@@ -62,6 +62,7 @@ struct LoamState {
 
 static constexpr int kAccum = 32;        // 21 JtJ (upper) + 6 JtE + 1 count, padded
 static constexpr int kMaxPartials = 512; // linearisation blocks
+static constexpr int kTimelineSlots = 16; // s_memrealtime stamps per block and launch (pcr_get_timeline)
 
 struct LoamConsts {
     double knn_max_sq, plane_thresh, point_thresh, pos_conv, rot_conv;
@@ -109,7 +110,7 @@ struct LoamArgs {
     // bit1: plane fit and everything after it, bit2: prologue solve.  Results are then meaningless.
     int32_t ablate;
     int32_t coresident;      // pcr_params.reserved[4] = 1: the two-waves-per-SIMD variant of the iterate kernel (loam.hip)
-    // profiling aid (pcr_params.reserved[3] = 1): [launch][block][8] s_memrealtime stamps (100 MHz) taken by thread 0
+    // profiling aid (pcr_params.reserved[3] = 1): [launch][block][kTimelineSlots] s_memrealtime stamps (100 MHz) taken by thread 0
     unsigned long long* timeline;
 };
 
