@@ -483,8 +483,8 @@ struct WaveCand { double d; uint32_t idx, pos; };
 static constexpr int kWaveTab = 280;     // 4 waves x (280 + 8 result slots) x 16 B = the 18 KB of KnnShared, which this path reuses
 
 __device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                          double qx, double qy, double qz, double max_sq, WaveCand* tab, Knn5& out, double* l6_out,
-                                          bool* inside_out) {
+                                          double qx, double qy, double qz, double max_sq, double seed_sq, WaveCand* tab, Knn5& out,
+                                          double* l6_out, bool* inside_out) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < 5; ++j) { out.d[j] = max_sq; out.idx[j] = 0xffffffffu; out.pos[j] = 0xffffffffu; }
@@ -511,25 +511,42 @@ __device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __r
     uint32_t r_start[9], r_excl[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) { r_start[r] = __shfl(rs, r, 64); r_excl[r] = __shfl(incl - len, r, 64); }
-    // every lane computes the exact keys of its candidates
-    for (uint32_t c = lane; c < total; c += 64) {
-        uint32_t pos = 0;
+    // Every lane computes the exact keys of its candidates.  Only those within seed_sq -- an upper bound of the 5th
+    // distance (five known points lie inside it; max_sq when nothing is known) -- can be among the five nearest: they are
+    // compacted into the table and ranked among themselves (a handful instead of ~100); the others only bound the
+    // "6th neighbour" from below through their minimum.
+    uint32_t n_in = 0;                 // wave-uniform
+    double out_min = max_sq;
+    for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        bool in = false;
+        WaveCand w; w.d = max_sq; w.idx = 0xffffffffu; w.pos = 0xffffffffu;
+        if (c < total) {
+            uint32_t pos = 0;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) if (c >= r_excl[r]) pos = r_start[r] + (c - r_excl[r]);
-        const float4 p = pts[pos];
-        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        WaveCand w; w.d = d; w.idx = __float_as_uint(p.w); w.pos = pos;
-        tab[c] = w;
+            for (int r = 0; r < 9; ++r) if (c >= r_excl[r]) pos = r_start[r] + (c - r_excl[r]);
+            const float4 p = pts[pos];
+            const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            w.d = d; w.idx = __float_as_uint(p.w); w.pos = pos;
+            in = d <= seed_sq;
+            if (!in) out_min = fmin(out_min, d);
+        }
+        const unsigned long long m = __ballot(in);
+        if (in) tab[n_in + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
+        n_in += (uint32_t)__popcll(m);
     }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) out_min = fmin(out_min, __shfl_xor(out_min, sft, 64));
     // (same wave: its LDS operations complete in order, so the table is visible to the reads below)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    for (uint32_t c = lane; c < total; c += 64) {
+    for (uint32_t c = lane; c < n_in; c += 64) {
         const WaveCand me = tab[c];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < total; ++j) {
+#pragma unroll 4
+        for (uint32_t j = 0; j < n_in; ++j) {
             const WaveCand o = tab[j];
             rank += knn_less(o.d, o.idx, me.d, me.idx) ? 1u : 0u;
         }
@@ -538,9 +555,11 @@ __device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __r
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        if ((uint32_t)j < total) { const WaveCand w = tab[kWaveTab + j]; out.d[j] = w.d; out.idx[j] = w.idx; out.pos[j] = w.pos; }
+        if ((uint32_t)j < n_in) { const WaveCand w = tab[kWaveTab + j]; out.d[j] = w.d; out.idx[j] = w.idx; out.pos[j] = w.pos; }
     }
-    if (total > 5) *l6_out = fmin(max_sq, tab[kWaveTab + 5].d);
+    double l6 = out_min;
+    if (n_in > 5) l6 = fmin(l6, tab[kWaveTab + 5].d);
+    *l6_out = fmin(max_sq, l6);
     return true;
 }
 
@@ -624,7 +643,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
                 double rl6 = 0.0;
                 bool ins = false;
                 const bool done = knn5_wave(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
-                                            a.c.knn_max_sq, tab, r, &rl6, &ins);
+                                            a.c.knn_max_sq, ex.seed[owner], tab, r, &rl6, &ins);
                 if (!done) { if ((tid & 63) == 0) ex.fallback = 1; }
                 else if ((tid & 63) == 0) {
 #pragma unroll
@@ -678,8 +697,13 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     double x[3] = {0, 0, 0};
     bool plane_ok = false;
     const bool reuse = hit && ordered && (ce_in.flags & 2u);
+    // a search that comes back with the cached neighbours in the cached order (the bound was too weak, the answer is
+    // the same) can take the cached plane as well; only the anchor of the entry moves
+    bool same_set = miss && real5 && have_seed && (ce_in.flags & 2u);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) same_set = same_set && (s.idx[j] == __float_as_uint(ce_in.nb[j].w));
     const bool gate_knn = real5 && (s.d[4] < a.c.knn_max_sq);      // LoamRegister.cpp:59
-    if (reuse) {
+    if (reuse || same_set) {
         x[0] = ce_in.x[0]; x[1] = ce_in.x[1]; x[2] = ce_in.x[2];
         plane_ok = (ce_in.flags & 4u) != 0;
     } else if (real5 && !(kAblation && (a.ablate & 2))) {
