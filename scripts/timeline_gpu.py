@@ -26,10 +26,12 @@ for k in range(tl.shape[0]):
     t = tl[k]; ok = t[:, 6] > 0
     d = np.diff(t[ok][:, :7], axis=1).mean(axis=0)
     print(k, ' '.join(f'{names[i + 1]}:{d[i]:6.2f}' for i in range(6)), f'fold_done_at={t[ok, 7].mean() - t[ok, 0].mean():5.2f} after entry')
-print('slowest blocks of launch 6 (stage durations):')
-t = tl[6]; d = np.diff(t[:, :7], axis=1)
-for b in np.argsort(-t[:, 6])[:12]:
-    print(b, f'entry={t[b,0]:5.2f} stored={t[b,6]:6.2f}', ' '.join(f'{names[i + 1]}:{d[b, i]:6.2f}' for i in range(6)))
+for L in (4, 5, 6):
+    print(f'slowest blocks of launch {L} (stage durations):')
+    t = tl[L]; d = np.diff(t[:, :7], axis=1)
+    for b in np.argsort(-t[:, 6])[:4]:
+        print('   ', b, f'entry={t[b,0]:5.2f} stored={t[b,6]:6.2f}', ' '.join(f'{names[i + 1]}:{d[b, i]:6.2f}' for i in range(6)))
+t = tl[6]
 print('launch 6 stored-time percentiles', np.percentile(t[:, 6], [0, 10, 50, 90, 99, 100]))
 print('dense search of launch 0 (thread 0 of each block): posted -> ranges in LDS -> first chunk -> stream done -> searched')
 t = tl[0]
