@@ -82,6 +82,7 @@ struct pcr_handle {
     GridIndex src_grid;
     GridIndex cov_l1, cov_l2;        // the cloud whose covariances are being computed, indexed at 4x and 16x the cell
     DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, vg_partials;
+    double seq = 0.0;                    // completion numbers of the host-mapped result blocks below
     double* out32_host = nullptr;        // host-mapped: 32 doubles written by sum_partials_kernel
     double* out32_dev = nullptr;
     bool vg_target_ready = false;
@@ -269,6 +270,20 @@ int set_device(pcr_handle* h) {
     return 0;
 }
 
+// Wait until the kernel that was given `seq` has written it into the last word of a host-mapped result block (it does so
+// after everything else, with a system-scope release).  A short spin returns ~15 us before a sleeping thread would be
+// woken by the stream's completion signal, and the LM / line-search drivers wait like this a dozen times per call.
+int wait_result(pcr_handle* h, const double* flag_word, double seq) {
+    const volatile double* f = flag_word;
+    if (h->profile == 0) {
+        for (int spin = 0; spin < 200000 && *f != seq; ++spin) __builtin_ia32_pause();
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*f == seq) return 0;
+    }
+    H_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------
 // VGICP host driver: PCL align() + LsqRegistration (lsq_registration_impl.hpp:53-171)
 // ---------------------------------------------------------------------------------
@@ -366,6 +381,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
     if (!h->out32_host) {
         H_TRY(hipHostMalloc((void**)&h->out32_host, 32 * sizeof(double), hipHostMallocMapped));
+        memset(h->out32_host, 0, 32 * sizeof(double));
         H_TRY(hipHostGetDevicePointer((void**)&h->out32_dev, h->out32_host, 0));
     }
     // source covariances over the source's own index (fast_gicp_impl.hpp:103-108)
@@ -391,8 +407,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     h->vg_outer = h->vg_lin = h->vg_err = 0;
     for (int it = 0; it < h->prm.vgicp_max_iters && !conv; ++it) {
         h->vg_outer = it + 1;
-        H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream));
-        H_TRY(hipStreamSynchronize(h->stream));
+        h->seq += 1.0;
+        H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream, h->seq));
+        if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
         ++h->vg_lin;
         double H[36], b[6], D[16];
         int q = 0;
@@ -410,8 +427,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
             host_make_delta(d, D);
             Pose16 xi;
             host_mul44(D, x0.m, xi.m);
-            H_TRY(vgicp_launch_error(a, xi, h->out32_dev, h->stream));
-            H_TRY(hipStreamSynchronize(h->stream));
+            h->seq += 1.0;
+            H_TRY(vgicp_launch_error(a, xi, h->out32_dev, h->stream, h->seq));
+            if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
             ++h->vg_err;
             const double yi = h->out32_host[0];
             double den = 0;
@@ -434,8 +452,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     for (int i = 0; i < 16; ++i) pose[i] = (double)(float)x0.m[i];     // final_transformation_ is a Matrix4f
     if (converged) *converged = conv ? 1 : 0;
     // pcl::Registration::getFitnessScore() of the aligned source (VgicpRegister.cpp:42-45)
-    H_TRY(fitness_launch(h->grid, d_src, n_src, stride_floats, pose, 1.7976931348623157e308, h->vg_partials.as<double>(), h->out32_dev, h->stream));
-    H_TRY(hipStreamSynchronize(h->stream));
+    h->seq += 1.0;
+    H_TRY(fitness_launch(h->grid, d_src, n_src, stride_floats, pose, 1.7976931348623157e308, h->vg_partials.as<double>(), h->out32_dev, h->stream, h->seq));
+    if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
     h->fitness = h->out32_host[1] > 0 ? h->out32_host[0] / h->out32_host[1] : 1.7976931348623157e308;
     h->stats.iterations = h->vg_outer; h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
     h->stats.kernel_launches = h->vg_lin + h->vg_err;
@@ -590,8 +609,9 @@ int ndt_derivatives(NdtRun* r, const double p[6], bool compute_hessian, double* 
     pcr_handle* h = r->h;
     ndt_host::angle_derivatives(p, &r->ang);
     if (r->a.n_src == 0) { *score = 0; memset(grad, 0, 6 * sizeof(double)); memset(hess, 0, 36 * sizeof(double)); return 0; }
-    H_TRY(ndt_launch_derivatives(r->a, r->T, r->ang, compute_hessian ? 1 : 0, h->out48_dev, h->stream));
-    H_TRY(hipStreamSynchronize(h->stream));
+    h->seq += 1.0;
+    H_TRY(ndt_launch_derivatives(r->a, r->T, r->ang, compute_hessian ? 1 : 0, h->out48_dev, h->stream, h->seq));
+    if (wait_result(h, &h->out48_host[47], h->seq)) return 1;
     ++h->nd_deriv;
     *score = h->out48_host[0];
     for (int i = 0; i < 6; ++i) grad[i] = h->out48_host[1 + i];
@@ -651,8 +671,9 @@ int ndt_step_length(NdtRun* r, const double x[6], double dir[6], double step_ini
         it++;
     }
     if (it && r->a.n_src) {   // computeHessian (:928-929), double precision, with the tables of the last pass
-        H_TRY(ndt_launch_hessian(r->a, r->T, r->ang, h->out48_dev, h->stream));
-        H_TRY(hipStreamSynchronize(h->stream));
+        h->seq += 1.0;
+        H_TRY(ndt_launch_hessian(r->a, r->T, r->ang, h->out48_dev, h->stream, h->seq));
+        if (wait_result(h, &h->out48_host[47], h->seq)) return 1;
         ++h->nd_hess;
         for (int i = 0; i < 36; ++i) hess[i] = h->out48_host[7 + i];
     }
@@ -666,6 +687,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
     if (!h->out48_host) {
         H_TRY(hipHostMalloc((void**)&h->out48_host, 48 * sizeof(double), hipHostMallocMapped));
+        memset(h->out48_host, 0, 48 * sizeof(double));
         H_TRY(hipHostGetDevicePointer((void**)&h->out48_dev, h->out48_host, 0));
     }
     H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));
@@ -1073,6 +1095,7 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (!h->out48_host) {
         H_TRY(hipHostMalloc((void**)&h->out48_host, 48 * sizeof(double), hipHostMallocMapped));
+        memset(h->out48_host, 0, 48 * sizeof(double));
         H_TRY(hipHostGetDevicePointer((void**)&h->out48_dev, h->out48_host, 0));
     }
     H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));

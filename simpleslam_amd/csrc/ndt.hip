@@ -357,7 +357,8 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a,
 
 // fold per-block partials (48 doubles each) into 48 doubles, fixed order; 16 slices of 48 components, each
 // slice keeps 8 independent loads in flight
-__global__ __launch_bounds__(768) void ndt_sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+// out lives in host-mapped memory: out[47] receives `seq` LAST (system-scope release), the word the host spins on
+__global__ __launch_bounds__(768) void ndt_sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out, double seq) {
     __shared__ double sh[16 * 48];
     const int t = threadIdx.x, comp = t % 48, slice = t / 48;
     double acc = 0.0;
@@ -370,12 +371,15 @@ __global__ __launch_bounds__(768) void ndt_sum_partials_kernel(const double* __r
     }
     sh[slice * 48 + comp] = acc;
     __syncthreads();
-    if (t < 48) {
+    if (t < 47) {
         double v = sh[t];
 #pragma unroll
         for (int s2 = 1; s2 < 16; ++s2) v += sh[s2 * 48 + t];
         out[t] = v;
+        __threadfence_system();
     }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&out[47], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- host launchers ---------------------------------------------------------------
@@ -393,17 +397,17 @@ hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* 
     return hipGetLastError();
 }
 
-hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s) {
+hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq) {
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_derivatives_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang, compute_hessian);
-    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48);
+    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48, seq);
     return hipGetLastError();
 }
 
-hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s) {
+hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq) {
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_hessian_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
-    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48);
+    hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48, seq);
     return hipGetLastError();
 }
 

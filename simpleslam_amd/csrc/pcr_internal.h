@@ -164,10 +164,11 @@ struct VgicpArgs {
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
                             size_t n, double* d_cov6, hipStream_t s);
 hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s);
-hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s);
-hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s);
+// (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
+hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
+hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
-                          double* d_partials, double* d_out32, hipStream_t s);
+                          double* d_partials, double* d_out32, hipStream_t s, double seq = 0.0);
 uint32_t vgicp_blocks(uint32_t n_src);
 
 // pcl::VoxelGrid on the device (voxel_filter.hip); grid must have been built with pcl_mode = 1
@@ -197,8 +198,8 @@ struct NdtArgs {
 };
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, int min_points, double eig_mult,
                              hipStream_t s);
-hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s);
-hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s);
+hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq = 0.0);
+hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
 uint32_t ndt_blocks(uint32_t n_src);
 
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s);

@@ -461,19 +461,23 @@ __global__ __launch_bounds__(256) void vgicp_error_kernel(const VgicpArgs a, con
 }
 
 // fold per-block partials (32 doubles each) into 32 doubles, fixed order
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+// out lives in host-mapped memory: out[31] receives `seq` LAST (system-scope release), the word the host spins on
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out, double seq) {
     __shared__ double sh[8 * 32];
     const int t = threadIdx.x, comp = t & 31, slice = t >> 5;
     double acc = 0.0;
     for (uint32_t b = slice; b < nblocks; b += 8) acc += partials[(size_t)b * 32 + comp];
     sh[slice * 32 + comp] = acc;
     __syncthreads();
-    if (t < 32) {
+    if (t < 31) {
         double v = sh[t];
 #pragma unroll
         for (int s = 1; s < 8; ++s) v += sh[s * 32 + t];
         out[t] = v;
+        __threadfence_system();
     }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&out[31], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------
@@ -533,28 +537,28 @@ uint32_t vgicp_blocks(uint32_t n_src) {
     return b < 1 ? 1 : (b > 512 ? 512 : b);
 }
 
-hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s) {
+hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq) {
     const uint32_t nb = vgicp_blocks(a.n_src);
     hipLaunchKernelGGL(vgicp_linearize_kernel, dim3(nb), dim3(256), 0, s, a, T);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32, seq);
     return hipGetLastError();
 }
 
-hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s) {
+hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq) {
     const uint32_t nb = vgicp_blocks(a.n_src);
     hipLaunchKernelGGL(vgicp_error_kernel, dim3(nb), dim3(256), 0, s, a, T);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32, seq);
     return hipGetLastError();
 }
 
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
-                          double* d_partials, double* d_out32, hipStream_t s) {
+                          double* d_partials, double* d_out32, hipStream_t s, double seq) {
     PoseF16 T;
     for (int i = 0; i < 16; ++i) T.m[i] = (float)pose[i];
     const uint32_t nb = vgicp_blocks((uint32_t)n_src);
     const float mr = max_range >= 3.0e38 ? 3.0e38f : (float)max_range;
     hipLaunchKernelGGL(fitness_kernel, dim3(nb), dim3(256), 0, s, grid.view(), d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, mr, d_partials);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, d_partials, nb, d_out32);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, d_partials, nb, d_out32, seq);
     return hipGetLastError();
 }
 
