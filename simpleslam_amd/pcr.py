@@ -168,23 +168,44 @@ class PointCloudRegister:
         if not self._h:
             raise PcrError(self._lib.pcr_last_error(None).decode())
         self.isConverge = False
+        # per-call marshalling kept off the hot path (a C++ caller has none): one persistent pose buffer and flag, and the
+        # (pointer, size, stride) triple of the most recent device tensors remembered by identity
+        self._pose_buf = (C.c_double * 16)()
+        self._pose_cm = np.frombuffer(self._pose_buf, dtype=np.float64).reshape(4, 4)     # column-major 4x4 = transposed view
+        self._conv = C.c_int(0)
+        self._conv_ref = C.byref(self._conv)
+        self._seen = {}
+
+    def _cloud_cached(self, x):
+        if hasattr(x, "data_ptr"):
+            hit = self._seen.get(id(x))
+            if hit is not None and hit[0] is x and hit[1][0].value == x.data_ptr():
+                return hit[1]
+            c = _cloud(x)
+            if len(self._seen) > 64:
+                self._seen.clear()
+            self._seen[id(x)] = (x, c)
+            return c
+        return _cloud(x)
 
     # -- reference interface ------------------------------------------------
     def scan2Map(self, src, dst, res):
         """Refine `res` (4x4, map<-lidar) in place; returns isConverge.
         The target index is rebuilt on every call, like the reference (LoamRegister.cpp:110)."""
-        sp, sn, ss, sdev, _k1 = _cloud(src)
-        dp_, dn, ds, ddev, _k2 = _cloud(dst)
+        sp, sn, ss, sdev, _k1 = self._cloud_cached(src)
+        dp_, dn, ds, ddev, _k2 = self._cloud_cached(dst)
         if ss != ds:
             raise ValueError("src and dst must share a point stride")
         if sdev != ddev:
             raise ValueError("src and dst must both be host arrays or both be device tensors")
-        pose = _pose_in(res)
-        conv = C.c_int(0)
+        res_np = np.asarray(res)
+        if res_np.shape != (4, 4):
+            raise ValueError("pose must be 4x4")
+        self._pose_cm[...] = res_np.T
         fn = self._lib.pcr_scan2map_device if sdev else self._lib.pcr_scan2map
-        self._check(fn(self._h, sp, sn, dp_, dn, ss, pose.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
-        np.asarray(res)[...] = _pose_out(pose)
-        self.isConverge = bool(conv.value)
+        self._check(fn(self._h, sp, sn, dp_, dn, ss, self._pose_buf, self._conv_ref))
+        res_np[...] = self._pose_cm.T
+        self.isConverge = bool(self._conv.value)
         return self.isConverge
 
     def getFitnessScore(self):
