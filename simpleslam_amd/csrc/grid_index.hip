@@ -35,18 +35,19 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
                                                                float* __restrict__ partials, uint32_t* __restrict__ ticket,
                                                                GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    // four independent loads in flight per lane (a 1 M-point cloud is 16-32 MB: this pass should run at HBM speed)
+    // eight independent loads in flight per lane (a 1 M-point cloud is 16-32 MB: this pass should run at HBM speed)
+    constexpr int kU = 8;
     const uint32_t step = gridDim.x * 256;
-    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * step) {
-        float v[4][3];
+    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += kU * step) {
+        float v[kU][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const uint32_t i = i0 + u * step;
             const float* p = pts + (size_t)(i < n ? i : i0) * stride;      // out-of-range slots repeat a valid point
             v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const float x = v[u][0], y = v[u][1], z = v[u][2];
             if (isfinite(x) && isfinite(y) && isfinite(z)) {
                 mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
