@@ -81,7 +81,49 @@ public:
         return isConverge;
     }
     pcr_handle* handle() { return h_; }
+
+    // scan2Map with `dst` = the sub-map a SubMap keeps in HBM (the scan is uploaded, the map never leaves the device)
+    bool scan2Map(const PC_cPtr& src, const class SubMap& dst, pose_t& res);
 };
+
+// MapManager's key-frame store and sub-map (frontend/src/MapManager.cpp:151-201), kept in HBM
+class SubMap {
+    pcr_map* m_ = nullptr;
+public:
+    SubMap() : m_(pcr_map_create(-1)) { if (!m_) throw std::runtime_error(pcr_map_last_error(nullptr)); }
+    SubMap(const SubMap&) = delete;
+    SubMap& operator=(const SubMap&) = delete;
+    ~SubMap() { pcr_map_destroy(m_); }
+    void addKeyFrame(const PC_cPtr& pc, const pose_t& pose) {                 // KeyFrame{pc, pose}, common/types/basic.hpp:33-40
+        if (pcr_map_add_keyframe(m_, pc->points.data(), pc->size(), sizeof(PointXYZI), 0, pose.data())) throw std::runtime_error(pcr_map_last_error(m_));
+    }
+    // MapManager::updateMap around `position`; returns the number of sub-map points
+    size_t updateMap(const double position[3], double radius = 8.0 /* mSurroundingKeyframeSearchRadius */, double grid_size = 0.4) {
+        size_t n = 0;
+        if (pcr_map_update(m_, position, radius, grid_size, &n)) throw std::runtime_error(pcr_map_last_error(m_));
+        return n;
+    }
+    std::vector<int64_t> submapIdx() const {                                    // mSubmapIdx
+        size_t n = 0;
+        pcr_map_submap_indices(m_, nullptr, 0, &n);
+        std::vector<int64_t> idx(n);
+        if (n) pcr_map_submap_indices(m_, idx.data(), n, &n);
+        return idx;
+    }
+    const void* devicePointer(size_t* n, size_t* stride_bytes) const { return pcr_map_submap(m_, n, stride_bytes); }
+};
+
+inline bool HipRegister::scan2Map(const PC_cPtr& src, const SubMap& dst, pose_t& res) {
+    size_t n = 0, stride = 0;
+    const void* d_map = dst.devicePointer(&n, &stride);
+    if (stride && stride != sizeof(PointXYZI)) throw std::runtime_error("sub-map and scan must share one point layout");
+    // device-resident target + host scan: index the sub-map where it lies, then align the (uploaded) scan against it
+    int conv = 0;
+    if (pcr_set_target(h_, d_map, n, sizeof(PointXYZI), 1)) throw std::runtime_error(pcr_last_error(h_));
+    if (pcr_align(h_, src->points.data(), src->size(), sizeof(PointXYZI), 0, res.data(), &conv)) throw std::runtime_error(pcr_last_error(h_));
+    isConverge = conv != 0;
+    return isConverge;
+}
 
 class LoamRegister : public HipRegister {
 public:

@@ -51,3 +51,40 @@ def test_cpp_harness_with_voxel_downsampling(gpu, world_small, tmp_path):
     reg.scan2Map(ds, w["map"], pose_py)
     pose_cpp = np.array([[float(v) for v in ln.split()] for ln in lines[-4:]])
     np.testing.assert_array_equal(pose_cpp, pose_py)
+
+
+def test_cpp_harness_submap_mode(gpu, tmp_path):
+    """The C++ mirror of MapManager's flow: key frames -> device sub-map around the current position -> down-sampled scan
+    registered against it; same pose as the Python mirror."""
+    import oracle
+    from simpleslam_amd import SubMap, synth
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    world, _ = synth.make_map(20_000, seed=91)
+    lines, kfs = [], []
+    for j in range(8):
+        scan, T = synth.make_scan(world, j, seed=91, beams=32, azimuths=512)
+        ds, _ = oracle.voxel_filter(scan, 0.4)
+        f = tmp_path / f"kf{j}.f32"
+        ds.astype(np.float32).tofile(f)
+        lines.append(str(f) + " " + " ".join(f"{v:.17g}" for v in T.reshape(-1)))
+        kfs.append((ds, T))
+    (tmp_path / "kfs.txt").write_text("\n".join(lines) + "\n")
+    scan, T_true = synth.make_scan(world, 8, seed=91, beams=32, azimuths=512)
+    init = synth.perturb(T_true, 91, trans=0.1, rot_deg=0.5)
+    scan.astype(np.float32).tofile(tmp_path / "scan.f32")
+    np.savetxt(tmp_path / "init.txt", init, fmt="%.17g")
+    out = subprocess.run([exe, "loam", "submap:" + str(tmp_path / "kfs.txt"), str(tmp_path / "scan.f32"), str(tmp_path / "init.txt"), "0.4"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    pose_cpp = np.array([[float(v) for v in ln.split()] for ln in lines[-4:]])
+    sm = SubMap()
+    for c, T in kfs:
+        sm.addKeyFrame(c, T)
+    n_sub = sm.updateMap(init[:3, 3], radius=8.0, grid_size=0.4)
+    reg = LoamRegister()
+    ds = reg.voxelDownSample(scan, 0.4)
+    assert f"submap {n_sub} " in lines[0] and f"-> {ds.shape[0]} " in lines[0]
+    pose_py = init.copy()
+    reg.scan2MapSubmap(ds, sm, pose_py)
+    np.testing.assert_array_equal(pose_cpp, pose_py)
