@@ -598,6 +598,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     const float py = (float)(pose[1] * ox + pose[5] * oy + pose[9] * oz + pose[13] * 1.0);
     const float pz = (float)(pose[2] * ox + pose[6] * oy + pose[10] * oz + pose[14] * 1.0);
     const double qx = (double)px, qy = (double)py, qz = (double)pz;
+    const bool in_range = valid;
     bool active = valid && !h.empty && !h.overflow;
     if (a.use_tile) {
         const bool in_tile = qx >= a.tile_lo[0] && qx < a.tile_hi[0] && qy >= a.tile_lo[1] && qy < a.tile_hi[1] &&
@@ -720,6 +721,11 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         }
     }
     // ---- remember everything for the next iteration ----
+    if (a.nn_cache && in_range && !active) {
+        // not handled by this launch (outside this rank's query tile): whatever entry is there -- a previous iteration's, a
+        // previous scan's -- must not be trusted when the query comes back
+        a.nn_cache[qi].flags = 0;
+    }
     if (a.nn_cache && active) {
         if (reuse) {
             // neighbours, order and plane unchanged: the entry stays as it is
