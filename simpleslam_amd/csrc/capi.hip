@@ -195,9 +195,8 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
             while ((int)h->ev_kernel.size() < 2 * iters) { hipEvent_t e; H_TRY(hipEventCreate(&e)); h->ev_kernel.push_back(e); }
         }
         for (int k = 0; k < iters; ++k) {
-            if (per_kernel) H_TRY(hipEventRecord(h->ev_kernel[2 * k], h->stream));
-            H_TRY(loam_launch_iteration(a, k, h->stream));
-            if (per_kernel) H_TRY(hipEventRecord(h->ev_kernel[2 * k + 1], h->stream));
+            if (per_kernel) H_TRY(loam_launch_iteration(a, k, h->stream, h->ev_kernel[2 * k], h->ev_kernel[2 * k + 1]));
+            else H_TRY(loam_launch_iteration(a, k, h->stream));
             if (h->comm) {
                 H_TRY(loam_launch_reduce(a, k, h->loam_reduced.as<double>(), h->stream));
                 int rc = g_rccl.allreduce(h->loam_reduced.p, h->loam_reduced.p, kAccum, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);

@@ -18,6 +18,8 @@
 // Arithmetic is f64 with contraction off (-ffp-contract=off), in the reference's
 // operation order, so per-point results are bit-identical to the CPU oracle
 // wherever only IEEE +,-,*,/,sqrt are involved.
+#include <hip/hip_ext.h>
+
 #include "pcr_internal.h"
 #include "small_math.h"
 
@@ -1106,7 +1108,15 @@ uint32_t loam_grid_blocks(uint32_t n_src) {
     return b;
 }
 
-hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s) {
+// start/stop (optional): events that the packet processor stamps at the kernel's own begin and end (hipExtLaunchKernelGGL),
+// i.e. what a profiler reports as the kernel's duration -- events recorded around an ordinary launch also contain the
+// dispatch latency (~2 us here).
+hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    if (start && stop) {
+        if (a.coresident) hipExtLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);
+        else hipExtLaunchKernelGGL((loam_iterate_kernel<8, 1>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);
+        return hipGetLastError();
+    }
     if (a.coresident) hipLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(a.n_partials), dim3(256), 0, s, a, k);
     else hipLaunchKernelGGL((loam_iterate_kernel<8, 1>), dim3(a.n_partials), dim3(256), 0, s, a, k);
     return hipGetLastError();

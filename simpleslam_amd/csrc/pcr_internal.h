@@ -202,7 +202,7 @@ hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtA
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
 uint32_t ndt_blocks(uint32_t n_src);
 
-hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s);
+hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s);
 hipError_t loam_launch_reduce(const LoamArgs& a, int k, double* d_out, hipStream_t s);
 uint32_t loam_grid_blocks(uint32_t n_src);
