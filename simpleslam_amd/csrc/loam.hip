@@ -879,7 +879,8 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
             __builtin_amdgcn_wave_barrier();
             const double pk = sh_m[kk * 7 + kk], aik = in ? sh_m[i * 7 + kk] : 0.0, akj = in ? sh_m[kk * 7 + j] : 0.0;
             __builtin_amdgcn_wave_barrier();
-            if (in) v = (i == kk) ? akj / pk : v - (aik / pk) * akj;
+            const double rp = 1.0 / pk;                      // one division per elimination step instead of two
+            if (in) v = (i == kk) ? akj * rp : v - (aik * rp) * akj;
         }
         if (in && j == 6) sh_x[i] = v;
     }
