@@ -38,3 +38,6 @@ t = tl[0]
 ok = t[:, 10] > 0
 for a, b, n in ((2, 8, 'ranges'), (8, 9, 'first chunk'), (9, 10, 'stream'), (10, 3, 'ties + exchange')):
     print(f'  {n:16s} {np.mean(t[ok, b] - t[ok, a]):6.2f} us')
+print('prologue of launch 6: entry -> partial sums folded -> system solved -> pose updated (prologue end)')
+t = tl[6]
+print(f'  fold {np.mean(t[:, 7] - t[:, 0]):5.2f} us, solve {np.mean(t[:, 11] - t[:, 7]):5.2f} us, exp + pose update {np.mean(t[:, 1] - t[:, 11]):5.2f} us')

@@ -885,6 +885,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         if (in && j == 6) sh_x[i] = v;
     }
     __syncthreads();
+    if (tl) tl[11] = wall_clock64();      // normal equations solved
     if (t == 0) {
         double JtJ[36], rhs[6], x[6];
         int q = 0;

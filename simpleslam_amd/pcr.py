@@ -336,7 +336,8 @@ class LoamRegister(PointCloudRegister):
     def timeline(self):
         """[launch][block][8] stamps in microseconds relative to each launch's earliest block entry
         (needs pcr_params.reserved[3] = 1).  Columns 0-7: entry, prologue, posted, searched, plane, accumulated, stored, partial sums folded (inside the
-        prologue); 8-10 (dense search only): row ranges in LDS, first candidate chunk arrived, candidate stream done."""
+        prologue); 8-10 (dense search only): row ranges in LDS, first candidate chunk arrived, candidate stream done; 11: normal
+        equations solved (inside the prologue)."""
         nl, nb = C.c_int(0), C.c_int(0)
         self._check(self._lib.pcr_get_timeline(self._h, None, 0, C.byref(nl), C.byref(nb)))
         raw = np.zeros((nl.value, nb.value, 16), np.uint64)
