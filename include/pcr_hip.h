@@ -172,6 +172,9 @@ const char* pcr_map_last_error(const pcr_map* m);
 int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_bytes, int on_device, const double pose[16]);
 int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes);
 int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap);
+/* LoopClosureManager::loopFindNearKeyframes (backend/src/LoopClosureManager.cpp:40-60): key frames key - search_num .. key + search_num
+ * (clipped to the store), transformed, concatenated, voxel-filtered: the target of the loop-closure registration (:96-99). */
+int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid_size, size_t* n_submap);
 const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes);
 int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size_t* n);
 

@@ -131,26 +131,12 @@ int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes) {
     return 0;
 }
 
-int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap) {
-    if (!m) return 1;
-    m->err.clear();
-    if (!position) return mfail(m, "NULL position");
-    if (!(grid_size > 0)) return mfail(m, "grid_size must be positive");
-    M_TRY(hipSetDevice(m->device));
-    m->selected.clear();
-    m->n_submap = 0;
-    if (n_submap) *n_submap = 0;
-    if (m->kfs.empty()) return 0;                          // "no any keyframes to update!!" (MapManager.cpp:166-169)
-    // radius search over the key-frame positions: squared distance in double, accumulated x, y, z; strict '<'
+// transform + concatenate the selected key frames (m->selected, ascending) and voxel-filter the result into m->submap
+static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap) {
     std::vector<KfDesc> desc;
     size_t total = 0;
-    const double r2 = radius * radius;
-    for (size_t i = 0; i < m->kfs.size(); ++i) {
-        const pcr_map::Kf& k = m->kfs[i];
-        double d = 0;
-        for (int c = 0; c < 3; ++c) { const double e = position[c] - k.pose[12 + c]; d += e * e; }
-        if (!(d < r2)) continue;
-        m->selected.push_back((long long)i);
+    for (long long i : m->selected) {
+        const pcr_map::Kf& k = m->kfs[(size_t)i];
         if (k.n == 0) continue;
         if (total + k.n > 0xfffffff0ull) return mfail(m, "sub-map too large");
         KfDesc e;
@@ -175,6 +161,43 @@ int pcr_map_update(pcr_map* m, const double position[3], double radius, double g
     m->n_submap = n_out;
     if (n_submap) *n_submap = n_out;
     return 0;
+}
+
+int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap) {
+    if (!m) return 1;
+    m->err.clear();
+    if (!position) return mfail(m, "NULL position");
+    if (!(grid_size > 0)) return mfail(m, "grid_size must be positive");
+    M_TRY(hipSetDevice(m->device));
+    m->selected.clear();
+    m->n_submap = 0;
+    if (n_submap) *n_submap = 0;
+    if (m->kfs.empty()) return 0;                          // "no any keyframes to update!!" (MapManager.cpp:166-169)
+    // radius search over the key-frame positions: squared distance in double, accumulated x, y, z; strict '<'
+    const double r2 = radius * radius;
+    for (size_t i = 0; i < m->kfs.size(); ++i) {
+        double d = 0;
+        for (int c = 0; c < 3; ++c) { const double e = position[c] - m->kfs[i].pose[12 + c]; d += e * e; }
+        if (d < r2) m->selected.push_back((long long)i);
+    }
+    return assemble_selected(m, grid_size, n_submap);
+}
+
+int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid_size, size_t* n_submap) {
+    if (!m) return 1;
+    m->err.clear();
+    if (!(grid_size > 0)) return mfail(m, "grid_size must be positive");
+    if (search_num < 0) return mfail(m, "search_num must not be negative");
+    M_TRY(hipSetDevice(m->device));
+    m->selected.clear();
+    m->n_submap = 0;
+    if (n_submap) *n_submap = 0;
+    const long long count = (long long)m->kfs.size();
+    for (long long i = -(long long)search_num; i <= (long long)search_num; ++i) {      // LoopClosureManager.cpp:46-57
+        const long long near = key + i;
+        if (near >= 0 && near < count) m->selected.push_back(near);
+    }
+    return assemble_selected(m, grid_size, n_submap);
 }
 
 const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes) {

@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
-    "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_submap",
+    "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices",
 ]
 
@@ -106,6 +106,7 @@ def load_library():
     L.pcr_map_add_keyframe.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp]
     L.pcr_map_keyframes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.pcr_map_update.argtypes = [vp, dp, C.c_double, C.c_double, C.POINTER(C.c_size_t)]
+    L.pcr_map_update_window.argtypes = [vp, C.c_longlong, C.c_int, C.c_double, C.POINTER(C.c_size_t)]
     L.pcr_map_submap.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.pcr_map_submap.restype = vp
     L.pcr_map_submap_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -451,6 +452,13 @@ class SubMap:
         pos = np.ascontiguousarray(position, np.float64).reshape(3)
         n = C.c_size_t(0)
         self._check(self._lib.pcr_map_update(self._m, pos.ctypes.data_as(C.POINTER(C.c_double)), float(radius), float(grid_size), C.byref(n)))
+        return n.value
+
+    def loopFindNearKeyframes(self, key, search_num, grid_size=0.4):
+        """LoopClosureManager::loopFindNearKeyframes (backend/src/LoopClosureManager.cpp:40-60): the key frames key +- search_num,
+        transformed, concatenated and voxel-filtered, as the device-resident target of the loop-closure registration."""
+        n = C.c_size_t(0)
+        self._check(self._lib.pcr_map_update_window(self._m, int(key), int(search_num), float(grid_size), C.byref(n)))
         return n.value
 
     def pointer(self):

@@ -82,3 +82,42 @@ def test_mixed_layouts_rejected(gpu):
     sm.addKeyFrame(np.zeros((3, 4), np.float32), np.eye(4))
     with pytest.raises(Exception):
         sm.addKeyFrame(np.zeros((3, 8), np.float32), np.eye(4))
+
+
+def test_loop_closure_flow(gpu, keyframes):
+    """LoopClosureManager::lcHandler (backend/src/LoopClosureManager.cpp:72-110) on the device: the history sub-map around
+    an old key frame (loopFindNearKeyframes), the current key frame's cloud registered against it with the loop-closure
+    VGICP settings (VgicpRegister::initForLC), accepted on convergence and fitness."""
+    from simpleslam_amd import VgicpRegister
+    world, kfs = keyframes
+    sm = SubMap()
+    for c, T in kfs:
+        sm.addKeyFrame(c, T)
+    old_key, cur_key, rng = 3, 12, 2
+    n = sm.loopFindNearKeyframes(old_key, rng, grid_size=0.4)
+    np.testing.assert_array_equal(sm.submapIdx(), [1, 2, 3, 4, 5])
+    window = list(range(old_key - rng, old_key + rng + 1))
+    ref, _ = oracle.submap_assemble([kfs[i][0] for i in window], [kfs[i][1] for i in window], np.zeros(3), 1e12, 0.4)
+    got = sm.download()
+    assert n == got.shape[0] == ref.shape[0]
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=5e-4)
+    # clipped at the ends of the store
+    sm.loopFindNearKeyframes(0, 2)
+    np.testing.assert_array_equal(sm.submapIdx(), [0, 1, 2])
+    sm.loopFindNearKeyframes(len(kfs) - 1, 3)
+    np.testing.assert_array_equal(sm.submapIdx(), [len(kfs) - 4, len(kfs) - 3, len(kfs) - 2, len(kfs) - 1])
+    # registration of a key frame against the history map around itself, from a drifted pose (what a loop closure corrects)
+    key = 6
+    sm.loopFindNearKeyframes(key, rng, grid_size=0.4)
+    scan, T_true = kfs[key]
+    guess = synth.perturb(T_true, 7, trans=0.3, rot_deg=1.5)
+    lc = VgicpRegister(vgicp_max_iters=100, vgicp_trans_eps=1e-6)          # initForLC (VgicpRegister.cpp:21-28)
+    pose = guess.copy()
+    conv = lc.scan2MapSubmap(scan, sm, pose)
+    fs = lc.getFitnessScore()
+    et, er = synth.pose_error(pose, T_true)
+    assert conv and et < 0.05 and er < 5e-3
+    assert fs < 0.3                                                        # fitnessThreshold-style acceptance (config/params.json)
+    po, co, _ = oracle.vgicp_scan2map(scan, sm.download(), guess, oracle.vgicp_params(max_iters=100, trans_eps=1e-6, threads=8))
+    dt, dr = synth.pose_error(pose, po)
+    assert co == conv and dt <= 1e-4 and dr <= 1e-4
