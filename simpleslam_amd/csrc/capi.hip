@@ -286,9 +286,9 @@ int wait_result(pcr_handle* h, const double* flag_word, double seq) {
 // ---------------------------------------------------------------------------------
 // VGICP host driver: PCL align() + LsqRegistration (lsq_registration_impl.hpp:53-171)
 // ---------------------------------------------------------------------------------
-int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell) {
+int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell, int pcl_mode = 0) {
     for (int attempt = 0; attempt < 3; ++attempt) {
-        if (g.build(d_pts, n, stride_floats, cell, h->stream, &h->err) != hipSuccess) return 1;
+        if (g.build(d_pts, n, stride_floats, cell, h->stream, &h->err, 0.0, pcl_mode) != hipSuccess) return 1;
         GridHeader hdr;
         H_TRY(hipMemcpyAsync(&hdr, g.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
@@ -477,7 +477,9 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
     h->nd_target_ready = false;
     const double res = (double)(float)h->prm.ndt_resolution;     // resolution_ is a float (ndt_omp.h)
     if (!(res > 0)) return fail(h, "ndt_resolution must be positive");
-    if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res)) return 1;
+    // the voxel lattice is VoxelGridCovariance's own (leaf index = floor(p * inverse_leaf) - min_b in float,
+    // voxel_grid_covariance_omp_impl.hpp:218-220): GridHeader.pcl_mode, no pad cells
+    if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
     H_TRY(h->nd_vox.reserve((n_dst / std::max(1, h->prm.ndt_min_points) + 2) * sizeof(NdtVoxel)));
