@@ -89,7 +89,7 @@ struct pcr_handle {
     int vg_outer = 0, vg_lin = 0, vg_err = 0;
 
     // NDT work memory
-    DeviceBuf nd_slot, nd_vox, nd_count, nd_partials;
+    DeviceBuf nd_slot, nd_vox, nd_count, nd_list, nd_partials;
     double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
     double* out48_dev = nullptr;
     bool nd_target_ready = false;
@@ -482,10 +482,12 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
     if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
-    H_TRY(h->nd_vox.reserve((n_dst / std::max(1, h->prm.ndt_min_points) + 2) * sizeof(NdtVoxel)));
+    const size_t max_vox = n_dst / std::max(1, h->prm.ndt_min_points) + 2;      // a voxel needs min_points points
+    H_TRY(h->nd_vox.reserve(max_vox * sizeof(NdtVoxel)));
+    H_TRY(h->nd_list.reserve((max_vox + 64) * sizeof(uint32_t)));
     H_TRY(h->nd_count.reserve(16));
-    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>(),
-                            h->prm.ndt_min_points, 0.01, h->stream));
+    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>(), h->nd_list.as<uint32_t>(),
+                            max_vox, h->prm.ndt_min_points, 0.01, h->stream));
     h->nd_target_ready = true;
     return 0;
 }
@@ -872,7 +874,7 @@ void pcr_destroy(pcr_handle* h) {
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
     h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
     if (h->out32_host) (void)hipHostFree(h->out32_host);
-    h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_partials.release();
+    h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
     h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->timeline.release();

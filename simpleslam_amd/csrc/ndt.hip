@@ -68,15 +68,61 @@ __device__ inline void inv3_general(const double m[9], double out[9]) {
 static constexpr double kFix1 = 17592186044416.0;   // 2^44 for sums of (x - c)
 static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(x - c)^T
 
-__global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, uint32_t* __restrict__ vox_slot, NdtVoxel* __restrict__ vox,
-                                                        uint32_t* __restrict__ vox_count, int min_points, double eig_mult) {
+// Pass 1: the cells with enough points, compacted into a list (one atomic per wave); every slot is cleared.  Only a
+// tenth of the cells of a lidar map qualify: with one thread per cell nearly every wave carried a few of them and ran
+// the whole eigen-decomposition path at ~10 % lane utilisation.
+__global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_t* __restrict__ vox_slot, uint32_t* __restrict__ list,
+                                                             uint32_t* __restrict__ count, int min_points) {
+    __shared__ uint32_t sh_w[4];
+    __shared__ uint32_t sh_base;
     const GridHeader h = *g.hdr;
     if (h.overflow) return;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < h.n_cells; t += (uint64_t)gridDim.x * 256) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 1024 cells per block and step: four consecutive cells per thread, ONE atomic on the shared counter per step
+    // (an atomic per wave made 47 k waves queue up on one address: 280 us for 3 M cells)
+    const uint64_t n_round = (h.n_cells + 1023) & ~1023ull;
+    for (uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; t0 < n_round; t0 += (uint64_t)gridDim.x * 1024) {
+        bool cand[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t t = t0 + u;
+            cand[u] = false;
+            if (t < h.n_cells) {
+                cand[u] = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
+                vox_slot[t] = 0u;
+            }
+            mine += cand[u] ? 1u : 0u;
+        }
+        uint32_t inc = mine;                       // exclusive prefix over the block
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+        if (lane == 63) sh_w[wave] = inc;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) off += sh_w[w]; tot += sh_w[w]; }
+        if (threadIdx.x == 0) sh_base = tot ? atomicAdd(count, tot) : 0u;
+        __syncthreads();
+        uint32_t pos = sh_base + off + inc - mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (cand[u]) list[pos++] = (uint32_t)(t0 + u);
+        __syncthreads();                           // sh_w / sh_base are reused by the next step
+    }
+}
+
+// Pass 2: one thread per listed cell
+__global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                        uint32_t* __restrict__ vox_slot, NdtVoxel* __restrict__ vox, double eig_mult) {
+    const GridHeader h = *g.hdr;
+    if (h.overflow) return;
+    const uint32_t n_list = *count;
+    for (uint32_t li = blockIdx.x * 256 + threadIdx.x; li < n_list; li += gridDim.x * 256) {
+        const uint64_t t = list[li];
         const uint32_t s = g.cell_start[t], e = g.cell_start[t + 1];
         const int n = (int)(e - s);
         uint32_t slot = 0;
-        if (!h.empty && n >= min_points) {
+        {
             const int cx = (int)(t % (uint64_t)h.dims[0]), cy = (int)((t / (uint64_t)h.dims[0]) % (uint64_t)h.dims[1]),
                       cz = (int)(t / ((uint64_t)h.dims[0] * (uint64_t)h.dims[1]));
             const double ox = (h.org[0] + cx + 0.5) * h.cell, oy = (h.org[1] + cy + 0.5) * h.cell, oz = (h.org[2] + cz + 0.5) * h.cell;
@@ -129,12 +175,12 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, uint32_t* __
                 if (ok) {
                     v.mean[0] = ox + m1[0]; v.mean[1] = oy + m1[1]; v.mean[2] = oz + m1[2];
                     v.n = n; v.pad = 0;
-                    slot = atomicAdd(vox_count, 1u) + 1;                // placement only
-                    vox[slot - 1] = v;
+                    slot = li + 1;                                      // the voxel lives at its position in the list
+                    vox[li] = v;
                 }
             }
         }
-        vox_slot[t] = slot;
+        if (slot) vox_slot[t] = slot;
     }
 }
 
@@ -388,12 +434,14 @@ uint32_t ndt_blocks(uint32_t n_src) {
     return b < 1 ? 1 : (b > 1024 ? 1024 : b);
 }
 
-hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, int min_points, double eig_mult,
-                             hipStream_t s) {
+hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_list, size_t list_capacity,
+                             int min_points, double eig_mult, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const int blocks = (int)std::min<size_t>(65535, grid.cell_capacity / 256 + 1);
-    hipLaunchKernelGGL(ndt_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_vox, d_count, min_points, eig_mult);
+    const int blocks = (int)std::min<size_t>(4096, grid.cell_capacity / 1024 + 1);
+    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, min_points);
+    const int vblocks = (int)std::min<size_t>(65535, list_capacity / 256 + 1);
+    hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult);
     return hipGetLastError();
 }
 

@@ -196,8 +196,8 @@ struct NdtArgs {
     double d1, d2;           // gauss_d1_, gauss_d2_ (ndt_omp_impl.hpp:86-93)
     double* partials;        // [blocks][48]
 };
-hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, int min_points, double eig_mult,
-                             hipStream_t s);
+hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_list, size_t list_capacity,
+                             int min_points, double eig_mult, hipStream_t s);
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq = 0.0);
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
 uint32_t ndt_blocks(uint32_t n_src);
