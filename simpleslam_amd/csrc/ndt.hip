@@ -213,29 +213,32 @@ static constexpr int kNdtStride = 130;
 static constexpr int kNdtComp = 43;    // score, gradient 6, Hessian 36
 
 // fold v[43] of every thread of the block into partials[block][48] in a fixed order
-__device__ __forceinline__ void ndt_block_reduce(double* sh /* [43][kNdtStride] */, double* sh2 /* [2][64] */, const double v[kNdtComp],
+template <int kComp>     // 43 with the Hessian, 7 (score + gradient) in the passes of the line search that do not need it
+__device__ __forceinline__ void ndt_block_reduce(double* sh /* [43][kNdtStride] */, double* sh2 /* [2][64] */, const double v[kComp],
                                                  double& acc, bool last, double* __restrict__ partials) {
     const int tid = threadIdx.x, e = tid & 63, ch = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < kNdtComp; ++k) sh[k * kNdtStride + tid] = v[k];
+    for (int k = 0; k < kComp; ++k) sh[k * kNdtStride + tid] = v[k];
     __syncthreads();
-    if (e < kNdtComp) {
+    if (e < kComp) {
         const double* row = sh + e * kNdtStride + ch * 64;
 #pragma unroll 8
         for (int k = 0; k < 64; ++k) acc += row[k];
     }
     __syncthreads();
     if (last) {
-        sh2[ch * 64 + e] = e < kNdtComp ? acc : 0.0;
+        sh2[ch * 64 + e] = e < kComp ? acc : 0.0;
         __syncthreads();
-        if (tid < 48) partials[(size_t)blockIdx.x * 48 + tid] = tid < kNdtComp ? sh2[tid] + sh2[64 + tid] : 0.0;
+        if (tid < 48) partials[(size_t)blockIdx.x * 48 + tid] = tid < kComp ? sh2[tid] + sh2[64 + tid] : 0.0;
     }
 }
 
 // ------------------------------------------------------------------------------
 // N3: computeDerivatives
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang, int compute_hessian) {
+template <bool kHessian>
+__global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+    constexpr int kComp = kHessian ? kNdtComp : 7;
     __shared__ double sh[kNdtComp * kNdtStride];
     __shared__ double sh2[2 * 64];
     const GridHeader h = *a.hdr;
@@ -244,9 +247,9 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArg
     const uint32_t step = gridDim.x * kNdtBlock;
     for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
         const uint32_t idx = base + threadIdx.x;
-        double v[kNdtComp];
+        double v[kComp];
 #pragma unroll
-        for (int k = 0; k < kNdtComp; ++k) v[k] = 0.0;
+        for (int k = 0; k < kComp; ++k) v[k] = 0.0;
         if (idx < a.n_src) {
             const float* xp = a.src + (size_t)idx * a.src_stride;
             const float x4[3] = {xp[0], xp[1], xp[2]};
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArg
                     for (int c = 0; c < 6; ++c) { float s = x4t[0] * cpg[0][c]; s += x4t[1] * cpg[1][c]; s += x4t[2] * cpg[2][c]; xcpg[c] = s; }
 #pragma unroll
                     for (int c = 0; c < 6; ++c) v[1 + c] += (double)(e * xcpg[c]);
-                    if (compute_hessian) {
+                    if constexpr (kHessian) {
 #pragma unroll
                         for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArg
                 }
             }
         }
-        ndt_block_reduce(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
+        ndt_block_reduce<kComp>(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
     }
 }
 
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a,
                 }
             }
         }
-        ndt_block_reduce(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
+        ndt_block_reduce<kNdtComp>(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
     }
 }
 
@@ -447,7 +450,8 @@ hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* 
 
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq) {
     const uint32_t nb = ndt_blocks(a.n_src);
-    hipLaunchKernelGGL(ndt_derivatives_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang, compute_hessian);
+    if (compute_hessian) hipLaunchKernelGGL((ndt_derivatives_kernel<true>), dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
+    else hipLaunchKernelGGL((ndt_derivatives_kernel<false>), dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
     hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48, seq);
     return hipGetLastError();
 }
