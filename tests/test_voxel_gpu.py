@@ -111,3 +111,21 @@ def test_capacity_too_small_reports_the_size(gpu, clouds):
     cnt = C.c_size_t(0)
     rc = L.pcr_voxel_filter(reg._h, pts.ctypes.data_as(C.c_void_p), pts.shape[0], 16, 0, 0.4, out.ctypes.data_as(C.c_void_p), 10, 0, C.byref(cnt))
     assert rc != 0 and cnt.value == oracle.voxel_filter(pts, 0.4)[0].shape[0]
+
+
+@pytest.mark.parametrize("stride", [3, 5, 6])
+def test_other_point_layouts(gpu, clouds, stride):
+    """12-, 20- and 24-byte points: xyz are averaged (float 3 too when present), further floats come out as zero."""
+    src = clouds["scan"][:20000]
+    pts = np.zeros((src.shape[0], stride), np.float32)
+    pts[:, :3] = src[:, :3]
+    if stride > 3:
+        pts[:, 3] = src[:, 3]
+    reg = LoamRegister()
+    got = reg.voxelDownSample(pts, 0.4)
+    ref, _ = oracle.voxel_filter(pts, 0.4)
+    assert got.shape == ref.shape and got.shape[1] == stride
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=5e-4)
+    if stride > 3:
+        np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=1e-5, atol=1e-3)
+        assert np.all(got[:, 4:] == 0)
