@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         GridHeader h;
         h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n; h.shift = shift;
         h.empty = 0; h.overflow = 0;
-        h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0;
+        h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0; h.sum_sq = 0.f;
         h.min_b[0] = h.min_b[1] = h.min_b[2] = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
@@ -227,17 +227,39 @@ __global__ __launch_bounds__(kScanBlock) void grid_scan_local_kernel(uint32_t* _
     const uint32_t ob = block_exclusive_scan_256(b.x + b.y + b.z + b.w, &tb, sh + 4) + ta;
     if (i0 < total) *reinterpret_cast<uint4*>(cell_start + i0) = make_uint4(oa, oa + a.x, oa + a.x + a.y, oa + a.x + a.y + a.z);
     if (i1 < total) *reinterpret_cast<uint4*>(cell_start + i1) = make_uint4(ob, ob + b.x, ob + b.x + b.y, ob + b.x + b.y + b.z);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = ta + tb;
+    // sum of count^2 of the tile (a density estimate, float is plenty): second half of block_sums, as float bits
+    float sq = (float)a.x * (float)a.x + (float)a.y * (float)a.y + (float)a.z * (float)a.z + (float)a.w * (float)a.w +
+               (float)b.x * (float)b.x + (float)b.y * (float)b.y + (float)b.z * (float)b.z + (float)b.w * (float)b.w;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+    __shared__ float sh_sq[4];
+    if ((threadIdx.x & 63) == 0) sh_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = ta + tb;
+        block_sums[gridDim.x + blockIdx.x] = __float_as_uint(sh_sq[0] + sh_sq[1] + sh_sq[2] + sh_sq[3]);
+    }
 }
 
 __global__ __launch_bounds__(kScanBlock) void grid_scan_add_kernel(uint32_t* __restrict__ cell_start,
                                                                   const uint32_t* __restrict__ block_sums,
-                                                                  const GridHeader* __restrict__ hdr) {
+                                                                  GridHeader* __restrict__ hdr) {
     __shared__ uint32_t sh[4];
+    __shared__ float shf[4];
     if (hdr->overflow) return;
     const uint64_t total = hdr->n_cells + 1;
     const uint64_t tile = (uint64_t)blockIdx.x * kScanTile;
     if (tile >= total) return;
+    if (blockIdx.x == 0) {                       // density estimate: sum of the tiles' count^2
+        const uint32_t tiles = (uint32_t)((total + kScanTile - 1) / kScanTile);
+        float sq = 0.f;
+        for (uint32_t t = threadIdx.x; t < tiles; t += kScanBlock) sq += __uint_as_float(block_sums[gridDim.x + t]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+        if ((threadIdx.x & 63) == 0) shf[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) hdr->sum_sq = shf[0] + shf[1] + shf[2] + shf[3];
+    }
     uint32_t part = 0;
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kScanBlock) part += block_sums[t];
 #pragma unroll
@@ -298,7 +320,7 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
     // (+ one tile: the scan works on whole 16-byte groups)
     if ((e = cell_count.reserve((want + kScanTile) * sizeof(uint32_t))) != hipSuccess ||
         (e = cell_start.reserve((want + kScanTile) * sizeof(uint32_t))) != hipSuccess ||
-        (e = block_sums.reserve((want / kScanTile + 2) * sizeof(uint32_t))) != hipSuccess ||
+        (e = block_sums.reserve(2 * (want / kScanTile + 2) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(cell_count.p, 0, cell_count.cap)) != hipSuccess ||      // builds expect and leave the counters zeroed
         (e = hipDeviceSynchronize()) != hipSuccess) {      // (a device memset is not ordered against the handle's non-blocking stream)
         if (err) *err = std::string("hipMalloc of the cell table failed: ") + hipGetErrorString(e);
@@ -332,7 +354,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         PCR_TRY(cell_start.reserve((guess + kScanTile) * sizeof(uint32_t)));
         PCR_TRY(hipMemsetAsync(cell_count.p, 0, cell_count.cap, s));      // builds expect and leave the counters zeroed
         cell_capacity = guess;
-        PCR_TRY(block_sums.reserve((guess / kScanTile + 2) * sizeof(uint32_t)));
+        PCR_TRY(block_sums.reserve(2 * (guess / kScanTile + 2) * sizeof(uint32_t)));
     }
     const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
     const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);

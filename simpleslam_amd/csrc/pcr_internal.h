@@ -36,6 +36,8 @@ struct GridHeader {
     float inv_leaf_f;
     int32_t min_b[3];
     int32_t too_fine;        // pcl_mode: more than INT_MAX voxels ("Leaf size is too small", voxel_grid.hpp)
+    float sum_sq;            // sum over the cells of count^2 (written by the scan): sum_sq / points = occupancy of the cell a
+                             // point lives in, averaged over the points -- the density estimate behind the choice of a search cell
 };
 
 struct GridView {            // what kernels need to query the index
