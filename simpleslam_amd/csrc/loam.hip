@@ -862,7 +862,9 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     // ---- x = (JtJ)^-1 (-JtE)  (LoamRegister.cpp:198).  The reference calls Eigen's LDLT; JtJ is symmetric
     // positive definite, so plain Gauss-Jordan elimination gives the same x to rounding.  It runs with one lane
     // per entry of the augmented 6x7 system (42 lanes of wave 0, 6 short steps) instead of ~1.5k dependent
-    // instructions on a single lane while 255 threads of every block wait. ----
+    // instructions on a single lane while 255 threads of every block wait.  When the geometry does NOT constrain all six
+    // degrees of freedom (a single plane, a corridor: a pivot collapses) the answer depends on how the factorisation
+    // treats the null space, so that case is redone exactly as Eigen does it: pivoted LDLT, zero pivots dropped. ----
     double* const sh_m = sh_sum + 64;      // 42 entries of the augmented matrix
     double* const sh_x = sh_sum + 112;     // 6 entries of the solution
     if (t < 64) {
@@ -873,16 +875,22 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
             const int r = i < j ? i : j, c = i < j ? j : i;
             v = j < 6 ? sh_sum[r * 6 - (r * (r - 1)) / 2 + (c - r)] : -sh_sum[21 + i];
         }
+        // diagonal entries of the packed upper triangle: 0, 6, 11, 15, 18, 20
+        const double maxd = fmax(fmax(fmax(fabs(sh_sum[0]), fabs(sh_sum[6])), fmax(fabs(sh_sum[11]), fabs(sh_sum[15]))),
+                                 fmax(fabs(sh_sum[18]), fabs(sh_sum[20])));
+        bool weak = false;
 #pragma unroll
         for (int kk = 0; kk < 6; ++kk) {
             if (in) sh_m[t] = v;
             __builtin_amdgcn_wave_barrier();
             const double pk = sh_m[kk * 7 + kk], aik = in ? sh_m[i * 7 + kk] : 0.0, akj = in ? sh_m[kk * 7 + j] : 0.0;
             __builtin_amdgcn_wave_barrier();
+            weak = weak || !(fabs(pk) > 1e-6 * maxd);        // also catches NaN
             const double rp = 1.0 / pk;                      // one division per elimination step instead of two
             if (in) v = (i == kk) ? akj * rp : v - (aik * rp) * akj;
         }
         if (in && j == 6) sh_x[i] = v;
+        if (t == 0) sh_x[6] = weak ? 1.0 : 0.0;              // every lane saw the same pivots
     }
     __syncthreads();
     if (tl) tl[11] = wall_clock64();      // normal equations solved
@@ -891,6 +899,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         int q = 0;
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { JtJ[r * 6 + c] = JtJ[c * 6 + r] = sh_sum[q++]; }
         for (int r = 0; r < 6; ++r) { rhs[r] = -sh_sum[21 + r]; x[r] = sh_x[r]; }
+        if (sh_x[6] != 0.0) ldlt6_solve(JtJ, rhs, x);         // rank-deficient or ill-conditioned: Eigen's LDLT, step for step
         const double n = sh_sum[27];
         int done = 0, conv = 0, fail = 0;
         double pose[16];

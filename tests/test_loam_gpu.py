@@ -410,3 +410,39 @@ def test_cache_is_exact_when_queries_cross_the_tile_boundary(gpu, world_100k):
     np.testing.assert_array_equal(out[0][1]["n"], out[1][1]["n"])
     np.testing.assert_array_equal(out[0][1]["JtJ"], out[1][1]["JtJ"])
     assert out[0][1]["cache_hits"].sum() > 0
+
+
+def test_degenerate_geometry_matches_oracle(gpu, world_small):
+    """Geometry that does not constrain all six degrees of freedom.  With a single plane (or a line of points) J^T J is
+    numerically singular: Eigen's pivoted LDLT divides by pivots of ~1e-27 and the reference jumps ~1e12 m along the free
+    directions.  What can be asked of a replacement is the SAME first step (later iterations are chaos in float); so the
+    solve falls back to a step-for-step LDLT when a pivot collapses, and this test pins it.  A map 20 km from the origin
+    (float coordinates carry ~2 mm there) is well-posed and must agree all the way."""
+    w = world_small
+    rng = np.random.default_rng(3)
+    plane = np.zeros((20000, 4), np.float32)
+    plane[:, 0] = rng.uniform(-20, 20, 20000); plane[:, 1] = rng.uniform(-20, 20, 20000); plane[:, 2] = -1.5
+    line = np.zeros((5000, 4), np.float32)
+    line[:, 0] = np.linspace(-30, 30, 5000); line[:, 2] = -1.0
+    for name, m in (("single plane", plane), ("collinear points", line)):
+        reg = LoamRegister(loam_iters=1, loam_early_exit=0, record_trace=1)
+        pose = np.eye(4)
+        conv = reg.scan2Map(w["scan"], m, pose)
+        po, co, info = oracle.loam_scan2map(w["scan"], m, np.eye(4), oracle.loam_params(iters=1, early_exit=0), trace=True)
+        tr = reg.trace()
+        assert conv == co and tr["iters_run"] == info["iters_run"], name
+        np.testing.assert_array_equal(tr["n"], info["n"][: tr["iters_run"]], err_msg=name)
+        if tr["iters_run"]:
+            # huge, but the same (the pose itself is exp of a rotation of ~1e11 rad: not comparable)
+            np.testing.assert_allclose(tr["x"][0], info["x"][0], rtol=1e-6, atol=1e-9, err_msg=name)
+    far_map = w["map"].copy(); far_map[:, 0] += 20000.0
+    T = w["init"].copy(); T[0, 3] += 20000.0
+    reg = LoamRegister(record_trace=1)
+    pose = T.copy()
+    conv = reg.scan2Map(w["scan"], far_map, pose)
+    po, co, info = oracle.loam_scan2map(w["scan"], far_map, T, trace=True)
+    tr = reg.trace()
+    assert conv == co and tr["iters_run"] == info["iters_run"]
+    np.testing.assert_array_equal(tr["n"], info["n"][: tr["iters_run"]])
+    dt, dr = synth.pose_error(pose, po)
+    assert dt < 1e-6 and dr < 1e-8
