@@ -166,6 +166,15 @@ def test_edge_cases(gpu, world_small):
     po, co, _ = oracle.loam_scan2map(scan[keep_s], m[keep_m], w["init"])
     dt, dr = synth.pose_error(p, po)
     assert dt < 1e-9 and dr < 1e-9
+    # a scan point at the sensor origin: the weight 1 - 0.9|d| / sqrt(sqrt(0)) divides by zero (LoamRegister.cpp:147-148)
+    s0 = w["scan"].copy(); s0[0, :3] = 0.0
+    p = w["init"].copy()
+    c0 = reg.scan2Map(s0, w["map"], p)
+    po, co, _ = oracle.loam_scan2map(s0, w["map"], w["init"])
+    assert c0 == co and np.isfinite(p).all() == np.isfinite(po).all()
+    if np.isfinite(po).all():
+        dt, dr = synth.pose_error(p, po)
+        assert dt < 1e-9 and dr < 1e-9
     # scan far outside the map: nothing within 1 m
     far = w["scan"].copy(); far[:, :3] += 5000.0
     p = w["init"].copy()

@@ -104,3 +104,24 @@ def test_randomised_configurations(gpu):
         assert reg.stats()["iterations"] == info["iterations"], (case, res)
         dt, dr = synth.pose_error(pose, po)
         assert dt <= 1e-4 and dr <= 1e-4, (case, res, dt, dr)
+
+
+def test_edge_cases_match_oracle(gpu, nd_world):
+    """Inputs at the edge of the algorithm: a scan point at the sensor origin, a target too sparse for any voxel to
+    qualify (no Gaussians at all), an empty scan.  Same flag, same iteration count, same (possibly unchanged) pose as the
+    oracle."""
+    w = nd_world
+    T0 = synth.perturb(w["truth"], 31, trans=0.1, rot_deg=0.5)
+    scan0 = w["scan"].copy(); scan0[0, :3] = 0.0
+    sparse = w["map"][::200].copy()                               # < 6 points in every 1 m voxel
+    for name, scan, m in (("origin point", scan0, w["map"]), ("no voxels", w["scan"], sparse), ("empty scan", w["scan"][:0], w["map"])):
+        po, co, info = oracle.ndt_scan2map(scan, m, T0)
+        reg = NdtRegister()
+        pose = T0.copy()
+        conv = reg.scan2Map(scan, m, pose)
+        assert conv == co, name
+        assert reg.stats()["iterations"] == info["iterations"], name
+        assert np.isfinite(pose).all() == np.isfinite(po).all(), name
+        if np.isfinite(po).all():
+            dt, dr = synth.pose_error(pose, po)
+            assert dt <= 1e-4 and dr <= 1e-4, (name, dt, dr)

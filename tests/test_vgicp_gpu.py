@@ -119,3 +119,21 @@ def test_randomised_configurations(gpu):
         assert reg.stats()["iterations"] == info["outer"], (case, res)
         dt, dr = synth.pose_error(pose, po)
         assert dt <= 1e-4 and dr <= 1e-4, (case, res, dt, dr)
+
+
+def test_edge_cases_match_oracle(gpu, vg_world):
+    """A scan that misses the voxel map entirely (no correspondence), an empty scan, a scan point at the sensor origin."""
+    w = vg_world
+    far = w["scan"].copy(); far[:, :3] += 5000.0
+    scan0 = w["scan"].copy(); scan0[0, :3] = 0.0
+    for name, scan in (("no correspondences", far), ("empty scan", w["scan"][:0]), ("origin point", scan0)):
+        po, co, info = oracle.vgicp_scan2map(scan, w["map"], w["init"], oracle.vgicp_params(threads=8))
+        reg = VgicpRegister()
+        pose = w["init"].copy()
+        conv = reg.scan2Map(scan, w["map"], pose)
+        assert conv == co, name
+        assert reg.stats()["iterations"] == info["outer"], name
+        assert np.isfinite(pose).all() == np.isfinite(po).all(), name
+        if np.isfinite(po).all():
+            dt, dr = synth.pose_error(pose, po)
+            assert dt <= 1e-4 and dr <= 1e-4, (name, dt, dr)
