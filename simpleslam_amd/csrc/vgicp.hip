@@ -40,14 +40,21 @@ __device__ __forceinline__ void keylist_insert(KeyList<K>& L, unsigned long long
 template <int K, bool DEDUPE>
 __device__ __forceinline__ void ring_scan_run(const float4* __restrict__ pts, uint32_t s, uint32_t e, float qx, float qy, float qz,
                                               KeyList<K>& L) {
-    for (uint32_t j = s; j < e; ++j) {
-        const float4 p = pts[j];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        float d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(p.w);
-        if (key < L.k[K - 1]) keylist_insert<K, DEDUPE>(L, key);
+    // four candidates per step, their loads issued together: with one load per iteration the branchy insertion kept the
+    // compiler from overlapping them, and every candidate cost a full memory round trip
+    for (uint32_t j = s; j < e; j += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[j + u < e ? j + u : j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+            float d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(p[u].w);
+            if (j + u < e && key < L.k[K - 1]) keylist_insert<K, DEDUPE>(L, key);
+        }
     }
 }
 
