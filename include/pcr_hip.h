@@ -178,6 +178,31 @@ int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid
 const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes);
 int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size_t* n);
 
+/* ---- the loop-closure descriptor: backend/src/ScanContext.cpp (20 rings x 60 sectors over 80 m) ----
+ * pcr_sc_add = addContext (:56-66): the polar binning of the (down-sampled, lidar-frame) scan runs on the device, the ring
+ * and sector keys follow on the host.  pcr_sc_query = query (:231-279): the 10 nearest ring keys among the contexts
+ * older than num_exclude_recent (a snapshot refreshed every build_tree_gap contexts, as the reference's lazily rebuilt
+ * tree), each compared by distanceBtnScanContext (:116-150); *match = -1 when the best distance exceeds dist_thres. */
+typedef struct pcr_sc pcr_sc;
+typedef struct pcr_sc_params {
+    double lidar_height;          /* 2.0  config/params.json tf.lidar_height */
+    int32_t num_exclude_recent;   /* 40   backend.context.scancontext.numExcludeRecent */
+    int32_t build_tree_gap;       /* 10 */
+    int32_t num_candidates;       /* 10   numCandidatesFromTree */
+    int32_t pad;
+    double search_ratio;          /* 0.1 */
+    double dist_thres;            /* 0.4  scDistThres */
+} pcr_sc_params;
+void pcr_sc_default_params(pcr_sc_params* p);
+pcr_sc* pcr_sc_create(int device, const pcr_sc_params* p);
+void pcr_sc_destroy(pcr_sc* sc);
+const char* pcr_sc_last_error(const pcr_sc* sc);
+int pcr_sc_size(const pcr_sc* sc, size_t* n);
+int pcr_sc_add(pcr_sc* sc, const void* pts, size_t n, size_t stride_bytes, int on_device);
+int pcr_sc_descriptor(const pcr_sc* sc, size_t id, double* desc_row_major_20x60, double* ring_key_20, double* sector_key_60);
+int pcr_sc_distance(const pcr_sc* sc, size_t id1, size_t id2, double* dist, int* shift);
+int pcr_sc_query(pcr_sc* sc, long long id, long long* match, float* yaw_rad, double* min_dist);
+
 /* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
  * accumulation done, partial sums stored (+ the fold inside the prologue and three stamps of the dense search).  out receives

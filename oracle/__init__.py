@@ -468,3 +468,59 @@ def submap_assemble(clouds, poses, position, radius, grid):
                                   _p(sel), C.byref(nsel), _p(out), cat.shape[0], C.byref(nout))
     assert rc in (0, 1), rc
     return out[:nout.value].copy(), sel[:nsel.value].copy()
+
+
+# ---------------------------------------------------------------------------
+# ScanContext loop-closure descriptor (oracle/scancontext_oracle.c); query's state machine restated here
+# ---------------------------------------------------------------------------
+class ScanContextOracle:
+    """backend/src/ScanContext.cpp: addContext :56-66, query :231-279 (ring-key candidates by exact k-NN)."""
+
+    def __init__(self, lidar_height=2.0, num_exclude_recent=40, build_tree_gap=10, num_candidates=10, search_ratio=0.1, dist_thres=0.4):
+        self.lidar_height, self.excl, self.gap, self.ncand = lidar_height, num_exclude_recent, build_tree_gap, num_candidates
+        self.search_ratio, self.dist_thres = search_ratio, np.float32(dist_thres)
+        self.polar, self.ring, self.sector = [], [], []
+        self.tree_size = 0
+        L = lib()
+        L.oracle_sc_make.restype = None
+        L.oracle_sc_make.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_void_p]
+        L.oracle_sc_keys.restype = None
+        L.oracle_sc_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_sc_distance.restype = None
+        L.oracle_sc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        self.L = L
+
+    def add(self, pts):
+        pts = _f32(pts)
+        desc = np.zeros(20 * 60, np.float64)                      # column-major 20 x 60
+        self.L.oracle_sc_make(_p(pts), pts.shape[0], pts.shape[1], float(self.lidar_height), _p(desc))
+        rk, sk = np.zeros(20), np.zeros(60)
+        self.L.oracle_sc_keys(_p(desc), _p(rk), _p(sk))
+        self.polar.append(desc); self.ring.append(rk); self.sector.append(sk)
+
+    def descriptor(self, i):
+        return self.polar[i].reshape(60, 20).T.copy()             # as a [ring][sector] array
+
+    def distance(self, i, j):
+        d, s = C.c_double(0), C.c_int(0)
+        self.L.oracle_sc_distance(_p(self.polar[i]), _p(self.polar[j]), float(self.search_ratio), C.byref(d), C.byref(s))
+        return d.value, s.value
+
+    def query(self, i):
+        """-> (match or -1, yaw as float32, best distance or None)"""
+        if i <= self.excl + self.ncand:
+            return -1, np.float32(0), None
+        if self.tree_size == 0 or i - self.tree_size > self.excl + self.gap:
+            self.tree_size = i - self.excl
+        keys = np.stack(self.ring[:self.tree_size])
+        d2 = ((keys - self.ring[i][None, :]) ** 2).sum(1)
+        cand = np.argsort(d2, kind="stable")[:self.ncand]
+        best, align, idx = np.finfo(np.float64).max, 0, 0
+        for c in cand:
+            d, s = self.distance(i, int(c))
+            if d < best:
+                best, align, idx = d, s, int(c)
+        if best > float(self.dist_thres):
+            return -1, np.float32(0), best
+        yaw = np.float32(float(np.float32(np.float32(360.0) / np.float32(60.0)) * np.float32(align)) * np.pi / 180.0)     # trans::deg2rad<float>
+        return idx, yaw, best

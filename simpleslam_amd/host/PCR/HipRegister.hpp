@@ -9,6 +9,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/pcr_hip.h"
@@ -162,6 +163,29 @@ inline PointCloudRegister::Ptr makeRegister(const std::string& pcr_type) {
 }
 
 }  // namespace PCR
+
+// backend/include/backend/ScanContext.hpp: the loop-closure descriptor database (addContext, query)
+namespace context {
+class ScanContext {
+    pcr_sc* s_ = nullptr;
+public:
+    using QueryResult = std::pair<int, float>;                                  // {matched key frame or -1, yaw in rad}
+    explicit ScanContext(const pcr_sc_params* p = nullptr) : s_(pcr_sc_create(-1, p)) { if (!s_) throw std::runtime_error(pcr_sc_last_error(nullptr)); }
+    ScanContext(const ScanContext&) = delete;
+    ScanContext& operator=(const ScanContext&) = delete;
+    ~ScanContext() { pcr_sc_destroy(s_); }
+    void addContext(const PCR::PointCloud& scan_down) {
+        if (pcr_sc_add(s_, scan_down.points.data(), scan_down.size(), sizeof(PCR::PointXYZI), 0)) throw std::runtime_error(pcr_sc_last_error(s_));
+    }
+    QueryResult query(int id) {
+        long long match = -1;
+        float yaw = 0;
+        if (pcr_sc_query(s_, id, &match, &yaw, nullptr)) throw std::out_of_range(pcr_sc_last_error(s_));     // ringcontexts_.at(id)
+        return {(int)match, yaw};
+    }
+    size_t size() const { size_t n = 0; pcr_sc_size(s_, &n); return n; }
+};
+}  // namespace context
 
 // common/pcp/pcp.hpp:14-28 (pcl::VoxelGrid with leaf = grid_size on all axes), on the device
 namespace pcp {

@@ -51,7 +51,15 @@ ABI_SYMBOLS = [
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices",
+    "pcr_sc_default_params", "pcr_sc_create", "pcr_sc_destroy", "pcr_sc_last_error", "pcr_sc_size", "pcr_sc_add", "pcr_sc_descriptor", "pcr_sc_distance",
+    "pcr_sc_query",
 ]
+
+class ScParams(C.Structure):
+    """struct pcr_sc_params (include/pcr_hip.h)."""
+    _fields_ = [("lidar_height", C.c_double), ("num_exclude_recent", C.c_int32), ("build_tree_gap", C.c_int32), ("num_candidates", C.c_int32),
+                ("pad", C.c_int32), ("search_ratio", C.c_double), ("dist_thres", C.c_double)]
+
 
 _lib = None
 
@@ -66,6 +74,12 @@ def load_library():
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C simpleslam_amd/csrc`). "
             "There is no CPU fallback.")
+    try:
+        # torch ships its own libamdhip64 under the same soname: whichever HIP runtime is mapped first serves the whole
+        # process, and torch.cuda reports "No HIP GPUs" when that is not its own.  Map torch's first when it is installed.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
     L.pcr_default_params.argtypes = [C.POINTER(PcrParams)]
@@ -110,6 +124,19 @@ def load_library():
     L.pcr_map_submap.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.pcr_map_submap.restype = vp
     L.pcr_map_submap_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.pcr_sc_default_params.argtypes = [C.POINTER(ScParams)]
+    L.pcr_sc_default_params.restype = None
+    L.pcr_sc_create.argtypes = [C.c_int, C.POINTER(ScParams)]
+    L.pcr_sc_create.restype = vp
+    L.pcr_sc_destroy.argtypes = [vp]
+    L.pcr_sc_destroy.restype = None
+    L.pcr_sc_last_error.argtypes = [vp]
+    L.pcr_sc_last_error.restype = C.c_char_p
+    L.pcr_sc_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.pcr_sc_add.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.pcr_sc_descriptor.argtypes = [vp, C.c_size_t, vp, vp, vp]
+    L.pcr_sc_distance.argtypes = [vp, C.c_size_t, C.c_size_t, dp, ip]
+    L.pcr_sc_query.argtypes = [vp, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_float), dp]
     _lib = L
     return L
 
@@ -487,3 +514,58 @@ class SubMap:
             if rc:
                 raise PcrError(f"hipMemcpy failed: {rc}")
         return out.cpu().numpy()
+
+
+class ScanContext:
+    """context::ScanContext (backend/include/backend/ScanContext.hpp, backend/src/ScanContext.cpp): addContext(scan) builds the
+    20 x 60 polar descriptor on the device; query(id) -> (match id or -1, yaw in rad), QueryResult of the reference."""
+
+    def __init__(self, device=-1, **params):
+        self._lib = load_library()
+        p = ScParams()
+        self._lib.pcr_sc_default_params(C.byref(p))
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise ValueError(f"unknown ScanContext parameter {k}")
+            setattr(p, k, v)
+        self._s = self._lib.pcr_sc_create(int(device), C.byref(p))
+        if not self._s:
+            raise PcrError(self._lib.pcr_sc_last_error(None).decode())
+
+    def __del__(self):
+        try:
+            if self._s:
+                self._lib.pcr_sc_destroy(self._s)
+                self._s = None
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise PcrError(self._lib.pcr_sc_last_error(self._s).decode())
+
+    def addContext(self, cloud):
+        p, n, s, dev, _keep = _cloud(cloud)
+        self._check(self._lib.pcr_sc_add(self._s, p, n, s, dev))
+
+    def __len__(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.pcr_sc_size(self._s, C.byref(n)))
+        return n.value
+
+    def descriptor(self, i):
+        """-> (20 x 60 descriptor, ring key, sector key)"""
+        d, rk, sk = np.zeros((20, 60)), np.zeros(20), np.zeros(60)
+        self._check(self._lib.pcr_sc_descriptor(self._s, int(i), d.ctypes.data_as(C.c_void_p), rk.ctypes.data_as(C.c_void_p), sk.ctypes.data_as(C.c_void_p)))
+        return d, rk, sk
+
+    def distance(self, i, j):
+        d, sh = C.c_double(0), C.c_int(0)
+        self._check(self._lib.pcr_sc_distance(self._s, int(i), int(j), C.byref(d), C.byref(sh)))
+        return d.value, sh.value
+
+    def query(self, i):
+        """-> (match or -1, yaw as float32, best candidate distance or None when the search did not run)"""
+        m, yaw, d = C.c_longlong(-1), C.c_float(0), C.c_double(0)
+        self._check(self._lib.pcr_sc_query(self._s, int(i), C.byref(m), C.byref(yaw), C.byref(d)))
+        return m.value, np.float32(yaw.value), (None if d.value == np.finfo(np.float64).max else d.value)

@@ -1,0 +1,136 @@
+"""ScanContext on the device vs the CPU oracle (oracle/scancontext_oracle.c): descriptors bit-exact, the query
+sequence (candidate snapshot, alignment, threshold) identical over a trajectory that revisits its start."""
+import numpy as np
+import pytest
+
+import oracle
+from simpleslam_amd import ScanContext
+from simpleslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu(gpu):
+    return gpu
+
+
+def _scan(seed, n=6000, reach=90.0):
+    rng = np.random.default_rng(seed)
+    p = np.zeros((n, 8), np.float32)
+    r = rng.uniform(0.5, reach, n)
+    a = rng.uniform(-np.pi, np.pi, n)
+    p[:, 0], p[:, 1] = r * np.cos(a), r * np.sin(a)
+    p[:, 2] = rng.uniform(-2.0, 6.0, n) * (1 + np.sin(3 * a + seed))
+    p[:, 3] = 1
+    return p
+
+
+def test_descriptor_bit_exact():
+    sc, orc = ScanContext(), oracle.ScanContextOracle()
+    clouds = [_scan(1), _scan(2, n=100), _scan(3, reach=20.0), np.zeros((0, 8), np.float32)]
+    # points on bin edges: exact ring radii, axis directions, the origin, the -x axis (theta = 0 and 360)
+    edge = np.zeros((64, 8), np.float32)
+    edge[:20, 0] = np.arange(1, 21) * 4.0
+    edge[20:40, 1] = -np.arange(1, 21) * 4.0
+    edge[40:50, 0] = -np.arange(1, 11) * 7.0
+    edge[50:60, 0] = -np.arange(1, 11) * 7.0
+    edge[50:60, 1] = -0.0
+    edge[60] = 0
+    edge[61, :3] = [80.0, 0, 1]
+    edge[62, :3] = [56.568542, 56.568542, 1]
+    edge[63, :3] = [0.0, -80.0, 1]
+    edge[:, 2] += np.linspace(-3, 3, 64, dtype=np.float32)
+    clouds.append(edge)
+    for c in clouds:
+        sc.addContext(c)
+        orc.add(c)
+    assert len(sc) == len(clouds)
+    for i in range(len(clouds)):
+        d, rk, sk = sc.descriptor(i)
+        assert np.array_equal(d, orc.descriptor(i)), i
+        assert np.array_equal(rk, orc.ring[i]) and np.array_equal(sk, orc.sector[i])
+    assert not sc.descriptor(3)[0].any()                               # the empty scan
+
+
+def test_non_finite_points_are_skipped():
+    """int(ceil(NaN)) is undefined behaviour in the reference (ScanContext.cpp:177); here such points never reach a bin."""
+    c = _scan(9, n=500)
+    bad = c.copy()
+    bad[::7, 0] = np.nan
+    bad[3::7, 2] = np.nan
+    bad[5::7, 1] = np.inf
+    keep = np.isfinite(bad[:, :3]).all(1)
+    a, b = ScanContext(), ScanContext()
+    a.addContext(bad)
+    b.addContext(bad[keep])
+    assert np.array_equal(a.descriptor(0)[0], b.descriptor(0)[0])
+
+
+def test_device_resident_scan_and_stride():
+    import torch
+    c = _scan(5)
+    a, b, orc = ScanContext(), ScanContext(), oracle.ScanContextOracle()
+    a.addContext(torch.from_numpy(c).cuda())
+    b.addContext(np.ascontiguousarray(c[:, :3]))
+    orc.add(c)
+    assert np.array_equal(a.descriptor(0)[0], orc.descriptor(0)) and np.array_equal(b.descriptor(0)[0], orc.descriptor(0))
+
+
+def test_distance_and_yaw_alignment():
+    """The same scene seen after a yaw of k sectors: the distance is ~0 at shift k."""
+    base = _scan(7, n=20000, reach=70.0)
+    sc, orc = ScanContext(), oracle.ScanContextOracle()
+    for k in (0, 7, 31, 59):
+        th = np.deg2rad(6.0 * k)
+        rot = base.copy()
+        rot[:, 0] = np.cos(th) * base[:, 0] - np.sin(th) * base[:, 1]
+        rot[:, 1] = np.sin(th) * base[:, 0] + np.cos(th) * base[:, 1]
+        sc.addContext(rot)
+        orc.add(rot)
+    for j in range(1, 4):
+        d, s = sc.distance(j, 0)
+        do, so = orc.distance(j, 0)
+        assert s == so and abs(d - do) < 1e-12
+        assert s == (0, 7, 31, 59)[j] and d < 0.2
+        d2, s2 = sc.distance(0, j)
+        assert (s2 + s) % 60 == 0 and abs(d2 - orc.distance(0, j)[0]) < 1e-12
+
+
+def test_query_sequence_matches_oracle():
+    """A loop: 70 distinct places, then the first 30 revisited with a yaw offset and noise."""
+    prm = dict(num_exclude_recent=20, build_tree_gap=5, num_candidates=6)
+    sc = ScanContext(**prm)
+    orc = oracle.ScanContextOracle(num_exclude_recent=20, build_tree_gap=5, num_candidates=6)
+    rng = np.random.default_rng(0)
+    places = [_scan(100 + i, n=3000, reach=75.0) for i in range(70)]
+    seq = list(range(70)) + list(range(30))
+    found = 0
+    for step, pl in enumerate(seq):
+        c = places[pl].copy()
+        if step >= 70:
+            th = np.deg2rad(6.0 * 11)
+            x, y = c[:, 0].copy(), c[:, 1].copy()
+            c[:, 0], c[:, 1] = np.cos(th) * x - np.sin(th) * y, np.sin(th) * x + np.cos(th) * y
+            c[:, :3] += rng.normal(0, 0.01, (c.shape[0], 3)).astype(np.float32)
+        sc.addContext(c)
+        orc.add(c)
+        m, yaw, d = sc.query(step)
+        mo, yawo, do = orc.query(step)
+        assert m == mo and yaw == yawo, (step, m, mo, yaw, yawo)
+        assert (d is None) == (do is None) and (d is None or abs(d - do) < 1e-12)
+        if step >= 70 and m >= 0:
+            found += 1
+            assert m == pl and abs(float(yaw) - np.deg2rad(66.0)) < 1e-6
+    assert found >= 25
+
+
+def test_default_parameters_follow_the_reference_config():
+    sc = ScanContext()
+    for i in range(52):
+        sc.addContext(_scan(i, n=500))
+    assert sc.query(50) == (-1, np.float32(0), None)                   # id <= 40 + 10: no search
+    m, yaw, d = sc.query(51)
+    assert d is not None
+    with pytest.raises(Exception):
+        sc.query(52)
