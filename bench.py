@@ -161,10 +161,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # PCR_BENCH_REHEARSE=1: several ranks on ONE card (gloo for the barrier and the max over ranks) -- only to exercise the
+    # launch path of the multi-GPU run on a one-GPU box; the line it prints is not a measurement of N GPUs.
+    rehearse = os.environ.get("PCR_BENCH_REHEARSE") == "1" and world_size > 1
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     # ---- synthetic workload (same map on every rank; scans differ per rank) ----
     world, map_np = synth.make_map(args.map_points, seed=SEED + 2)
@@ -218,7 +226,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     units = args.steps * (1 if args.shard_map else world_size)
@@ -228,7 +236,7 @@ def main():
         "metric": "scans/s (65 k-pt scan vs 1 M-pt submap, LOAM 10 iters) + pose RMSE vs CPU ref",
         "value": value, "unit": "scans/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
         "config": {"workload": f"pcr=loam, {N_SCAN}-pt 64-beam scan vs {args.map_points}-pt submap, {args.iters} GN iters, "
                                "early exit off, index rebuilt per call, inputs in HBM",
                    "parallelism": parallelism, "scans_cycled": args.scans},
