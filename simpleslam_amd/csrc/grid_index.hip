@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
     // ---- last block: fold the partial boxes (read past this XCD's L2) and write the header ----
     float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
+        float t[6];      // all six loads in flight before the first use
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            fmn[d] = fminf(fmn[d], __hip_atomic_load(&partials[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            fmx[d] = fmaxf(fmx[d], __hip_atomic_load(&partials[b * 6 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
+        for (int d = 0; d < 6; ++d) t[d] = __hip_atomic_load(&partials[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { fmn[d] = fminf(fmn[d], t[d]); fmx[d] = fmaxf(fmx[d], t[3 + d]); }
     }
     __syncthreads();     // sh is reused
 #pragma unroll
