@@ -3,7 +3,7 @@
 // Kernels for the reference's PCR::NdtRegister::scan2Map (PCR/src/NdtRegister.cpp:21-31):
 //   N1 voxel Gaussians   voxel_grid_covariance_omp_impl.hpp:49-370 (serial std::map there)
 //      -> ndt_voxel_kernel: one thread per cell of the uniform index (cell = resolution):
-//         centred fixed-point sums (order independent), covariance * (n-1)/n, Jacobi eigen
+//         centred fixed-point sums (order independent) -> the reference's single-pass covariance expression, Jacobi eigen
 //         decomposition, eigenvalue inflation 0.01 * lambda_max, inverse
 //   N3 computeDerivatives / updateDerivatives   ndt_omp_impl.hpp:180-285,399-440,485-537
 //      -> ndt_derivatives_kernel: per source point, <= 7 neighbour cells (N6, :374-433),
@@ -134,20 +134,32 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
                 s2[0] += llrint(dx * dx * kFix2); s2[1] += llrint(dx * dy * kFix2); s2[2] += llrint(dx * dz * kFix2);
                 s2[3] += llrint(dy * dy * kFix2); s2[4] += llrint(dy * dz * kFix2); s2[5] += llrint(dz * dz * kFix2);
             }
-            const double inv = 1.0 / (double)n;
-            const double m1[3] = {(double)s1[0] / kFix1 * inv, (double)s1[1] / kFix1 * inv, (double)s1[2] / kFix1 * inv};
-            // population covariance (shift invariant), then the reference's (n-1)/n factor (:329-330)
-            double C[6];
-            C[0] = (double)s2[0] / kFix2 * inv - m1[0] * m1[0]; C[1] = (double)s2[1] / kFix2 * inv - m1[0] * m1[1];
-            C[2] = (double)s2[2] / kFix2 * inv - m1[0] * m1[2]; C[3] = (double)s2[3] / kFix2 * inv - m1[1] * m1[1];
-            C[4] = (double)s2[4] / kFix2 * inv - m1[1] * m1[2]; C[5] = (double)s2[5] / kFix2 * inv - m1[2] * m1[2];
-            const double f = ((double)n - 1.0) / (double)n;
+            // The reference accumulates sum(x) and sum(x x^T) about the ORIGIN and then evaluates
+            //   cov = (sum_xx - 2 (sum_x mean^T)) / n + mean mean^T,  cov *= (n-1)/n      (:329-330, all nine entries)
+            // whose cancellation noise decides whether a (nearly) flat voxel keeps a non-negative smallest eigenvalue (:337-341).
+            // Same expression here, from the order-independent centred sums moved back to the origin: identical to the
+            // reference whenever its own sums are exact (coordinates on a binary lattice), as close as its noise otherwise.
+            const double dn = (double)n, o[3] = {ox, oy, oz};
+            const double c1[3] = {(double)s1[0] / kFix1, (double)s1[1] / kFix1, (double)s1[2] / kFix1};
+            const double c2[3][3] = {{(double)s2[0] / kFix2, (double)s2[1] / kFix2, (double)s2[2] / kFix2},
+                                     {(double)s2[1] / kFix2, (double)s2[3] / kFix2, (double)s2[4] / kFix2},
+                                     {(double)s2[2] / kFix2, (double)s2[4] / kFix2, (double)s2[5] / kFix2}};
+            double sum[3], mean[3], cov[9];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) C[k] *= f;
+            for (int r = 0; r < 3; ++r) { sum[r] = dn * o[r] + c1[r]; mean[r] = sum[r] / dn; }
+            const double f = (dn - 1.0) / dn;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double sxx = ((dn * o[r]) * o[c] + (o[r] * c1[c] + o[c] * c1[r])) + c2[r][c];
+                    cov[r * 3 + c] = ((sxx - 2 * (sum[r] * mean[c])) / dn + mean[r] * mean[c]) * f;
+                }
+            // SelfAdjointEigenSolver reads the lower triangle
+            const double C[6] = {cov[0], cov[3], cov[6], cov[4], cov[7], cov[8]};
             double w[3], V[3][3];
             sym3_eig_asc(C, w, V);
             bool ok = !(w[0] < 0 || w[1] < 0 || w[2] <= 0);            // :337-341
-            double cov[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
             if (ok) {
                 const double minev = eig_mult * w[2];                   // :345-356
                 if (w[0] < minev) {
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
                 for (int k = 1; k < 9; ++k) { mx = fmax(mx, v.icov[k]); mn = fmin(mn, v.icov[k]); }
                 if (isinf(mx) || isinf(mn)) ok = false;
                 if (ok) {
-                    v.mean[0] = ox + m1[0]; v.mean[1] = oy + m1[1]; v.mean[2] = oz + m1[2];
+                    v.mean[0] = mean[0]; v.mean[1] = mean[1]; v.mean[2] = mean[2];
                     v.n = n; v.pad = 0;
                     slot = li + 1;                                      // the voxel lives at its position in the list
                     vox[li] = v;
