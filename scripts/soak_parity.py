@@ -1,7 +1,7 @@
 """Soak run on the GPU box: many seeded draws of worlds, scans, initial errors and parameters, with inputs chosen to hit the
 discrete decisions (quantised coordinates and duplicated points -> exact distance ties, non-finite points, large initial
 errors, tiny clouds).  Device path vs CPU oracle: convergence flag, iteration count, pose.  Prints one line per mismatch
-and a summary; exit code 1 when anything disagrees.   usage: soak_parity.py [loam|vgicp|ndt|all] [cases] [seed]
+and a summary; exit code 1 when anything disagrees.   usage: soak_parity.py [loam|vgicp|ndt|voxel|submap|sc|all] [cases] [seed]
 
 Two conventions.  (1) Non-finite points are outside the reference's contract (its callers remove them; what FLANN / int(floor(NaN))
 do with them is undefined): the device skips them, so the oracle is given the finite subset.  (2) NDT and VGICP sum float/double
@@ -14,7 +14,7 @@ import numpy as np
 sys.path.insert(0, '.')
 import torch  # noqa: F401
 import oracle
-from simpleslam_amd import LoamRegister, NdtRegister, VgicpRegister, synth
+from simpleslam_amd import LoamRegister, NdtRegister, ScanContext, SubMap, VgicpRegister, synth
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -138,8 +138,79 @@ def run_ndt(case, rng):
     return bad, f"map {m.shape[0]} scan {scan.shape[0]} {tag} res {res} start {tr} m / {rd} deg"
 
 
+_vox_reg = None
+
+
+def run_voxel(case, rng):
+    """pcl::VoxelGrid: same occupied voxels (exact), centroids to PCL's float-accumulation rounding."""
+    global _vox_reg
+    _vox_reg = _vox_reg or LoamRegister()
+    world, m = synth.make_map(int(rng.choice([500, 20_000, 150_000])), seed=seed0 * 100000 + 20000 + case)
+    scan, _ = synth.make_scan(world, int(rng.integers(0, 4)), seed=seed0 * 100000 + 20000 + case, beams=16, azimuths=256)
+    scan, m, tag = nasty(rng, scan, m)
+    pts = m if rng.integers(0, 2) else scan
+    leaf = float(rng.choice([0.05, 0.1, 0.25, 0.4, 0.5, 1.0, 3.0]))       # powers of two land lattice points ON voxel faces
+    got = _vox_reg.voxelDownSample(pts, leaf)
+    ref, unfiltered = oracle.voxel_filter(pts, leaf)
+    bad = []
+    if unfiltered:
+        if got.shape != pts.shape or not np.array_equal(got, pts, equal_nan=True): bad.append("leaf too small: the input must come back unchanged")
+    elif got.shape != ref.shape: bad.append(f"voxels {got.shape[0]} vs {ref.shape[0]}")
+    else:
+        # same count of occupied voxels in the same (ascending index) order; centroids within PCL's n * eps * |x|
+        if ref.size and not np.allclose(got[:, :3], ref[:, :3], rtol=0, atol=1e-3): bad.append(f"centroid differs by {np.abs(got[:, :3] - ref[:, :3]).max():.3e}")
+    return bad, f"{pts.shape[0]} points {tag} leaf {leaf}"
+
+
+def run_submap(case, rng):
+    """MapManager::updateMap: selected key frames exact, sub-map voxels as the voxel filter."""
+    world, m = synth.make_map(30_000, seed=seed0 * 100000 + 30000 + case)
+    n_kf = int(rng.integers(1, 25))
+    sm = SubMap()
+    clouds, poses = [], []
+    for k in range(n_kf):
+        scan, T = synth.make_scan(world, k, seed=seed0 * 100000 + 30000 + case, beams=8, azimuths=int(rng.choice([64, 128])))
+        if rng.integers(0, 5) == 0: scan = scan[:0]
+        if rng.integers(0, 4) == 0: T = T.copy(); T[:3, 3] = np.round(T[:3, 3] * 2) / 2      # positions exactly on the search sphere happen
+        clouds.append(scan); poses.append(T)
+        sm.addKeyFrame(scan, T)
+    centre = poses[int(rng.integers(0, n_kf))][:3, 3] + rng.choice([0.0, 0.5, 4.0]) * np.array([1.0, 0, 0])
+    radius, grid = float(rng.choice([0.5, 4.0, 8.0, 50.0])), float(rng.choice([0.2, 0.4, 1.0]))
+    n = sm.updateMap(centre, radius, grid)
+    got, idx = sm.download() if n else np.zeros((0, clouds[0].shape[1]), np.float32), sm.submapIdx()
+    ref, sel = oracle.submap_assemble(clouds, poses, centre, radius, grid)
+    bad = []
+    if not np.array_equal(idx, sel): bad.append(f"key frames {list(idx)} vs {list(sel)}")
+    elif got.shape != ref.shape: bad.append(f"sub-map points {got.shape[0]} vs {ref.shape[0]}")
+    elif ref.size and not np.allclose(got[:, :3], ref[:, :3], rtol=0, atol=1e-3): bad.append(f"centroid differs by {np.abs(got[:, :3] - ref[:, :3]).max():.3e}")
+    return bad, f"{n_kf} key frames radius {radius} grid {grid}"
+
+
+def run_sc(case, rng):
+    """ScanContext: descriptors bit-exact, query sequence identical."""
+    prm = dict(num_exclude_recent=int(rng.integers(2, 12)), build_tree_gap=int(rng.integers(1, 6)), num_candidates=int(rng.integers(1, 6)))
+    thres = float(rng.choice([0.1, 0.4, 0.9]))
+    sc = ScanContext(dist_thres=thres, lidar_height=float(rng.choice([0.0, 2.0])), **prm)
+    orc = oracle.ScanContextOracle(dist_thres=thres, lidar_height=sc_height(sc), **prm)
+    world, m = synth.make_map(20_000, seed=seed0 * 100000 + 40000 + case)
+    n = int(rng.integers(15, 45))
+    bad = []
+    for i in range(n):
+        scan, _ = synth.make_scan(world, int(rng.integers(0, 6)), seed=seed0 * 100000 + 40000 + case + 7 * (i % 9), beams=8, azimuths=128)
+        if rng.integers(0, 3) == 0: scan = scan.copy(); scan[:, :3] = np.round(scan[:, :3] * 4) / 4      # points on ring / sector edges
+        sc.addContext(scan); orc.add(scan)
+        if not np.array_equal(sc.descriptor(i)[0], orc.descriptor(i)): bad.append(f"descriptor {i}")
+        a, b = sc.query(i), orc.query(i)
+        if a[0] != b[0] or a[1] != b[1] or (a[2] is None) != (b[2] is None) or (a[2] is not None and abs(a[2] - b[2]) > 1e-12): bad.append(f"query {i}: {a} vs {b}")
+    return bad[:3], f"{n} contexts {prm} threshold {thres}"
+
+
+def sc_height(sc):
+    return sc._height
+
+
 total_bad = 0
-for name, fn in (("loam", run_loam), ("vgicp", run_vgicp), ("ndt", run_ndt)):
+for name, fn in (("loam", run_loam), ("vgicp", run_vgicp), ("ndt", run_ndt), ("voxel", run_voxel), ("submap", run_submap), ("sc", run_sc)):
     if which not in ("all", name):
         continue
     rng = np.random.default_rng(seed0 * 1000 + len(name))

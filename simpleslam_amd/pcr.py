@@ -528,6 +528,7 @@ class ScanContext:
             if not hasattr(p, k):
                 raise ValueError(f"unknown ScanContext parameter {k}")
             setattr(p, k, v)
+        self._height = float(p.lidar_height)
         self._s = self._lib.pcr_sc_create(int(device), C.byref(p))
         if not self._s:
             raise PcrError(self._lib.pcr_sc_last_error(None).decode())
