@@ -57,6 +57,28 @@ def test_create_without_gpu_fails_loudly():
     assert b"is not exist" in lib.pcr_last_error(None)
 
 
+def test_map_and_scancontext_objects_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = load_library()
+    assert not lib.pcr_map_create(-1)
+    assert lib.pcr_map_last_error(None)
+    assert not lib.pcr_sc_create(-1, None)
+    assert b"no CPU fallback" in lib.pcr_sc_last_error(None)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pcr_hip.h is the FFI boundary: it must compile as C99 (cgo / JNI / ctypes-style binders read it as C)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pcr_hip.h"\nint main(void) { pcr_params p; pcr_sc_params q; pcr_default_params(&p); pcr_sc_default_params(&q);'
+                   ' return (int)sizeof(p) + (int)sizeof(q) == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_synth_is_deterministic_and_sized():
     w1, m1 = synth.make_map(20000, seed=3)
     w2, m2 = synth.make_map(20000, seed=3)
