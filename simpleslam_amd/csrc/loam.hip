@@ -194,7 +194,9 @@ template <int kChunk>
 __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __restrict__ pts,
                                           const uint32_t* __restrict__ cell_start, double qx, double qy, double qz,
                                           double max_sq, Knn5& s, KnnShared& sh, bool active, double* l6_out, bool keep,
-                                          double seed_bound, int ablate, unsigned long long* tl = nullptr) {
+                                          double seed_bound, int ablate, unsigned long long* tl = nullptr, uint32_t part = 0u, uint32_t parts_log2 = 0u) {
+    // parts_log2 > 0: this lane takes the part-th of 2^parts_log2 equal slices of every row run; the caller merges the
+    // lists of a query's lanes (and only then looks for distance ties).
     const int tid = threadIdx.x;
     if (!keep) {
         // Empty slots are sentinels (index 0xffffffff) at an upper bound of the 5th distance: the gate
@@ -222,7 +224,11 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
             ra[r] = cell_start[key - 1]; rb[r] = cell_start[key + 2];
         }
 #pragma unroll
-        for (int r = 0; r < 9; ++r) { sh.rs[r][tid] = ra[r]; sh.re[r][tid] = rb[r]; }
+        for (int r = 0; r < 9; ++r) {
+            const uint32_t len = rb[r] - ra[r];
+            sh.rs[r][tid] = ra[r] + (uint32_t)(((uint64_t)len * part) >> parts_log2);
+            sh.re[r][tid] = ra[r] + (uint32_t)(((uint64_t)len * (part + 1u)) >> parts_log2);
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 9; ++r) { sh.rs[r][tid] = 0u; sh.re[r][tid] = 0u; }
@@ -270,7 +276,7 @@ __device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __r
     }
     *l6_out = q.l6;
     if (tl) tl[10] = wall_clock64();      // candidate stream done
-    if (inside) {
+    if (inside && parts_log2 == 0u) {
         // detect exact distance ties (inside the list, or between its last entry and anything left out); those rare
         // queries are redone with the index tie-break.  The original indices are NOT fetched here: the owner of the
         // query reads the five points anyway (coordinates for the plane fit) and takes the index from the same 16 bytes
@@ -659,13 +665,55 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             __syncthreads();
         }
         if (n_miss && dense) {
-            const bool worker = (uint32_t)tid < n_miss;
-            const uint32_t owner = worker ? ex.list[tid] : 0u;
+            // A block with few misses would leave three of its four waves idle while one wave walks whole row runs: up to 64
+            // (128) posted queries are searched by four (two) lanes each, in different waves, every lane taking its slice of
+            // each row run; the lists are merged through LDS.  Ties are looked for after the merge, on the complete list.
+            const uint32_t pl2 = n_miss <= 64u ? 2u : (n_miss <= 128u ? 1u : 0u);
+            const uint32_t per = 256u >> pl2;                          // lanes per part
+            const uint32_t m = (uint32_t)tid & (per - 1u), part = (uint32_t)tid >> (8u - pl2);
+            const bool worker = m < n_miss;
+            const uint32_t owner = worker ? ex.list[m] : 0u;
             Knn5 r;
             double rl6 = 0.0;
-            const bool ok = knn5_grid<kChunk>(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
-                                      a.c.knn_max_sq, r, sh, worker, &rl6, false, worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate, tl);
-            if (worker) {
+            const double oqx = (double)ex.qx[owner], oqy = (double)ex.qy[owner], oqz = (double)ex.qz[owner];
+            bool ok = knn5_grid<kChunk>(h, a.grid.pts, a.grid.cell_start, oqx, oqy, oqz, a.c.knn_max_sq, r, sh, worker, &rl6, false,
+                                        worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate, tl, part, pl2);
+            if (pl2) {
+                if (worker && part) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { ex.u.res.d[j][tid] = r.d[j]; ex.u.res.pos[j][tid] = r.pos[j]; }
+                    ex.l6[tid] = rl6;
+                }
+                __syncthreads();
+                if (worker && !part) {
+                    for (uint32_t q = 1; q < (1u << pl2); ++q) {
+                        const uint32_t t2 = m + q * per;
+                        rl6 = fmin(rl6, ex.l6[t2]);
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            double t = ex.u.res.d[j][t2];
+                            uint32_t tp = ex.u.res.pos[j][t2];
+                            if (tp == 0xffffffffu) t = __longlong_as_double(0x7ff0000000000000ll);     // an empty slot is not a point
+                            knn_bubble(r, t, tp);
+                            if (tp != 0xffffffffu) rl6 = fmin(rl6, t);        // what fell off bounds the 6th neighbour
+                        }
+                    }
+                    if (ok) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) r.idx[j] = 0xffffffffu;
+                        bool tie = false;
+                        if (r.pos[4] != 0xffffffffu) tie = (rl6 == r.d[4]) | (r.d[0] == r.d[1]) | (r.d[1] == r.d[2]) | (r.d[2] == r.d[3]) | (r.d[3] == r.d[4]);
+                        if (tie) {
+                            Knn5 fixed;
+                            knn5_resolve_ties(h.origin[0], h.origin[1], h.origin[2], h.inv_cell, (uint32_t)h.dims[0], (uint32_t)h.dims[1], a.grid.pts,
+                                              a.grid.cell_start, oqx, oqy, oqz, a.c.knn_max_sq, fixed);
+                            r = fixed;
+                        }
+                    }
+                }
+                __syncthreads();          // every partial list has been read: the slots may now take final results (indexed by owner)
+            }
+            if (worker && !part) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) { ex.u.res.d[j][owner] = r.d[j]; ex.u.res.pos[j][owner] = r.pos[j]; ex.u.res.idx[j][owner] = r.idx[j]; }
                 ex.l6[owner] = rl6; ex.searched[owner] = ok ? 1u : 0u;
