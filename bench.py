@@ -69,11 +69,25 @@ def secondary(args):
     import torch
     import oracle
     from simpleslam_amd import VgicpRegister, NdtRegister, synth
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    dev = torch.device("cuda", 0)
+    # replicas, as in main(): one process per GPU, each with the whole map and its own scans, no data-path collective
+    rank, local_rank, world_size = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    rehearse = os.environ.get("PCR_BENCH_REHEARSE") == "1" and world_size > 1
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
     if args.method == "vgicp":
         cfg, n_map, kw, mk = 3, 1_000_000, {}, {}
-        reg = VgicpRegister(vgicp_resolution=0.5)
+        reg = VgicpRegister(device=local_rank, vgicp_resolution=0.5)
         pert = {}
         cores = host_cores()
         ref = lambda s, m, T: oracle.vgicp_scan2map(s, m, T, oracle.vgicp_params(resolution=0.5, threads=cores))[0]
@@ -83,7 +97,7 @@ def secondary(args):
         workload = "pcr=vgicp, 0.5 m voxels, 65536-pt scan vs 1000000-pt submap, target rebuilt per call, inputs in HBM"
     else:
         cfg, n_map, kw, mk = 5, 5_000_000, dict(beams=128, azimuths=1024), dict(spacing=0.22)
-        reg = NdtRegister()
+        reg = NdtRegister(device=local_rank)
         pert = dict(trans=0.1, rot_deg=0.5)
         ref = lambda s, m, T: oracle.ndt_scan2map(s, m, T, oracle.ndt_params())[0]      # the NDT oracle is serial
         cores = 1
@@ -93,8 +107,9 @@ def secondary(args):
     world, map_np = synth.make_map(n_map, seed=SEED + cfg, **mk)
     scans, inits = [], []
     for j in range(args.scans):
-        s, T = synth.make_scan(world, j, seed=SEED + cfg, **kw)
-        scans.append(s); inits.append(synth.perturb(T, SEED + cfg + j, **pert))
+        k = rank * args.scans + j
+        s, T = synth.make_scan(world, k, seed=SEED + cfg, **kw)
+        scans.append(s); inits.append(synth.perturb(T, SEED + cfg + k, **pert))
     d_map = torch.from_numpy(map_np).to(dev)
     d_scans = [torch.from_numpy(s).to(dev) for s in scans]
 
@@ -106,16 +121,32 @@ def secondary(args):
     reg.set_profile(0)
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
-    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": args.steps / elapsed, "unit": "scans/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": args.steps * world_size / elapsed, "unit": "scans/s",
+           "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.method == "vgicp" else "f32",
-           "data": "synthetic", "config": {"workload": workload, "scans_cycled": args.scans}}
+           "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
+           "config": {"workload": workload, "scans_cycled": args.scans,
+                      "parallelism": f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"}}
     reg.set_profile(1)
     idx_ms = sol_ms = 0.0
     for i in range(8):
@@ -124,7 +155,7 @@ def secondary(args):
     ach = alg(scans[0].shape[0], n_map) / (idx_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                        "kernel": what, "target_prep_ms": idx_ms, "align_ms": sol_ms}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world_size == 1:      # the CPU leg is timed at N = 1 only
         n_done, t_cpu, et, er, nan_both, nan_one = 0, 0.0, [], [], 0, 0
         while n_done < 2 or (t_cpu < args.cpu_budget_s and n_done < args.scans):
             j = n_done % args.scans
@@ -144,6 +175,9 @@ def secondary(args):
                                    # pclomp's line search can return NaN (ndt_omp_impl.hpp:773-932); both sides then agree on it
                                    "non_finite_on_both_sides": nan_both, "non_finite_on_one_side": nan_one}
     print(json.dumps(out), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
