@@ -82,7 +82,7 @@ struct pcr_handle {
     GridIndex src_grid;
     GridIndex cov_l1, cov_l2;        // the cloud whose covariances are being computed, indexed at 4x and 16x the cell
     GridHeader cov_hdr0;             // header of the fine level of the last settle_cov_levels (density estimate)
-    DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, vg_partials;
+    DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, corr_slot2, corr_M2, vg_partials;
     double seq = 0.0;                    // completion numbers of the host-mapped result blocks below
     double* out32_host = nullptr;        // host-mapped: 32 doubles written by sum_partials_kernel
     double* out32_dev = nullptr;
@@ -412,6 +412,8 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
                            h->src_cov6.as<double>(), h->stream));
     H_TRY(h->corr_slot.reserve((n_src + 1) * sizeof(uint32_t)));
     H_TRY(h->corr_M.reserve((n_src + 1) * 6 * sizeof(double)));
+    H_TRY(h->corr_slot2.reserve((n_src + 1) * sizeof(uint32_t)));
+    H_TRY(h->corr_M2.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(h->vg_partials.reserve((size_t)512 * 32 * sizeof(double)));
     VgicpArgs a;
     a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)stride_floats;
@@ -420,6 +422,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     a.cell_start = h->grid.cell_start.as<uint32_t>();
     a.vox = h->vox.as<VgicpVoxel>();
     a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
+    a.corr_slot_next = h->corr_slot2.as<uint32_t>(); a.corr_M_next = h->corr_M2.as<double>();
     a.partials = h->vg_partials.as<double>();
 
     Pose16 x0;
@@ -427,17 +430,26 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     double lambda = -1.0;
     bool conv = false;
     h->vg_outer = h->vg_lin = h->vg_err = 0;
+    // The LM trial pass (vgicp_launch_error) also linearises at the trial pose: once a trial is accepted that pose IS the next
+    // linearisation point, so its H, b, error and correspondences are already there (one launch + round trip less per
+    // outer iteration; same values as a separate linearize() would return).
+    double lin[28];
+    bool have_lin = false;
     for (int it = 0; it < h->prm.vgicp_max_iters && !conv; ++it) {
         h->vg_outer = it + 1;
-        h->seq += 1.0;
-        H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream, h->seq));
-        if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
-        ++h->vg_lin;
+        if (!have_lin) {
+            h->seq += 1.0;
+            H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream, h->seq));
+            if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
+            ++h->vg_lin;
+            for (int k = 0; k < 28; ++k) lin[k] = h->out32_host[k];
+        }
+        have_lin = false;
         double H[36], b[6], D[16];
         int q = 0;
-        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[r * 6 + c] = H[c * 6 + r] = h->out32_host[q++]; }
-        for (int r = 0; r < 6; ++r) b[r] = h->out32_host[21 + r];
-        const double y0 = h->out32_host[27];
+        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[r * 6 + c] = H[c * 6 + r] = lin[q++]; }
+        for (int r = 0; r < 6; ++r) b[r] = lin[21 + r];
+        const double y0 = lin[27];
         if (lambda < 0.0) { double mx = 0; for (int i = 0; i < 6; ++i) mx = std::max(mx, fabs(H[i * 7])); lambda = h->prm.vgicp_lm_init_scale * mx; }
         double nu = 2.0;
         bool ok = false;
@@ -453,7 +465,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
             H_TRY(vgicp_launch_error(a, xi, h->out32_dev, h->stream, h->seq));
             if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
             ++h->vg_err;
-            const double yi = h->out32_host[0];
+            const double yi = h->out32_host[28];
             double den = 0;
             for (int k = 0; k < 6; ++k) den += d[k] * (lambda * d[k] - b[k]);
             const double rho = (y0 - yi) / den;
@@ -463,6 +475,11 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
                 continue;
             }
             x0 = xi;
+            // the pass above linearised at xi: keep its sums and make its correspondences the current ones
+            for (int k = 0; k < 28; ++k) lin[k] = h->out32_host[k];
+            std::swap(a.corr_slot, a.corr_slot_next);
+            std::swap(a.corr_M, a.corr_M_next);
+            have_lin = true;
             const double f = 1 - pow(2 * rho - 1, 3);
             lambda = lambda * std::max(1.0 / 3.0, f);
             ok = true;
@@ -886,7 +903,7 @@ void pcr_destroy(pcr_handle* h) {
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
-    h->corr_slot.release(); h->corr_M.release(); h->vg_partials.release();
+    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release();
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
@@ -1096,6 +1113,7 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     a.cell_start = h->grid.cell_start.as<uint32_t>();
     a.vox = h->vox.as<VgicpVoxel>();
     a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
+    a.corr_slot_next = h->corr_slot2.as<uint32_t>(); a.corr_M_next = h->corr_M2.as<double>();
     a.partials = h->vg_partials.as<double>();
     Pose16 T;
     memcpy(T.m, pose, sizeof T.m);

@@ -160,6 +160,8 @@ struct VgicpArgs {
     const VgicpVoxel* vox;
     uint32_t* corr_slot;         // [n_src] voxel slot + 1 of the correspondence, 0 = none
     double* corr_M;              // [n_src][6] Mahalanobis matrix of the correspondence
+    uint32_t* corr_slot_next;    // the same two for the linearisation an LM trial pass computes ahead (vgicp_launch_error)
+    double* corr_M_next;
     double* partials;            // [blocks][32]
 };
 
@@ -168,6 +170,7 @@ hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, con
 hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s);
 // (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
+// out32[28] = compute_error(T); out32[0..27] = the linearisation at T (correspondences into a.corr_*_next)
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
                           double* d_partials, double* d_out32, hipStream_t s, double seq = 0.0);

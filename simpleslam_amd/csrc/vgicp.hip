@@ -8,7 +8,8 @@
 //   V3 Gaussian voxel map         pclomp/fast_vgicp_voxel.hpp:105-174 (serial unordered_map, ADDITIVE)
 //      -> vgicp_voxel_kernel: one thread per voxel, fixed-point sums (order independent)
 //   V4/V5 correspondences, Mahalanobis, linearize, compute_error   fast_vgicp_impl.hpp:73-204
-//      -> vgicp_linearize_kernel / vgicp_error_kernel, fixed-order reductions
+//      -> vgicp_linearize_kernel<false> (linearize) and <true> (compute_error of an LM trial pose + the linearisation at
+//         that pose in the same pass), fixed-order reductions
 //   V6 LM driver                  lsq_registration_impl.hpp:53-171 -> host code in capi.hip
 // Also the PCL fitness score (pcl::Registration::getFitnessScore, VgicpRegister.cpp:42-45).
 #include "pcr_internal.h"
@@ -355,8 +356,85 @@ __device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint
 
 static constexpr int kLinStride = 258;
 
+// one source point of update_correspondences + linearize at pose T: v[0..20] H (upper triangle), v[21..26] b, v[27] error;
+// the correspondence (voxel slot, Mahalanobis matrix) goes to slot_out / M_out
+__device__ __forceinline__ void vgicp_lin_point(const VgicpArgs& a, const GridHeader& h, const Pose16& T, uint32_t i, double v[28],
+                                                uint32_t* __restrict__ slot_out, double* __restrict__ M_out) {
+    const float* sp = a.src + (size_t)i * a.src_stride;
+    const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
+    double tp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
+    const uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
+    slot_out[i] = slot;
+    if (!slot) return;
+    const VgicpVoxel vx = a.vox[slot - 1];
+    const double* ca = a.src_cov6 + (size_t)i * 6;
+    const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
+    double RC[3][3], S[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) RC[r][c] = T.m[r] * CA[0][c] + T.m[4 + r] * CA[1][c] + T.m[8 + r] * CA[2][c];
+    int o = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = r; c < 3; ++c) { S[o] = vx.cov[o] + (RC[r][0] * T.m[c] + RC[r][1] * T.m[4 + c] + RC[r][2] * T.m[8 + c]); ++o; }
+    double M6[6];
+    inv3_sym(S, M6);   // (C_B + T C_A T^T)^-1, fast_vgicp_impl.hpp:104-115
+#pragma unroll
+    for (int k = 0; k < 6; ++k) M_out[(size_t)i * 6 + k] = M6[k];
+    const double M[3][3] = {{M6[0], M6[1], M6[2]}, {M6[1], M6[3], M6[4]}, {M6[2], M6[4], M6[5]}};
+    const double er[3] = {vx.mean[0] - tp[0], vx.mean[1] - tp[1], vx.mean[2] - tp[2]};
+    double Me[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Me[r] = M[r][0] * er[0] + M[r][1] * er[1] + M[r][2] * er[2];
+    const double w = vx.w;
+    // J = [skew(Tp) | -I]   fast_vgicp_impl.hpp:156-158, so3.hpp:21-31
+    const double J[3][6] = {{0, -tp[2], tp[1], -1, 0, 0}, {tp[2], 0, -tp[0], 0, -1, 0}, {-tp[1], tp[0], 0, 0, 0, -1}};
+    double MJ[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) MJ[r][c] = M[r][0] * J[0][c] + M[r][1] * J[1][c] + M[r][2] * J[2][c];
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) v[q++] = w * (J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[21 + r] = w * (J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2]);
+    v[27] = w * (er[0] * Me[0] + er[1] * Me[1] + er[2] * Me[2]);
+}
+
+// compute_error (fast_vgicp_impl.hpp:183-204) of one point: the correspondences and Mahalanobis matrices of the LAST
+// linearisation, new pose
+__device__ __forceinline__ double vgicp_err_point(const VgicpArgs& a, const Pose16& T, uint32_t i) {
+    const uint32_t slot = a.corr_slot[i];
+    if (!slot) return 0.0;
+    const float* sp = a.src + (size_t)i * a.src_stride;
+    const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
+    const VgicpVoxel vx = a.vox[slot - 1];
+    double er[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) er[r] = vx.mean[r] - (T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0);
+    const double* M6 = a.corr_M + (size_t)i * 6;
+    const double Me0 = M6[0] * er[0] + M6[1] * er[1] + M6[2] * er[2], Me1 = M6[1] * er[0] + M6[3] * er[1] + M6[4] * er[2],
+                 Me2 = M6[2] * er[0] + M6[4] * er[1] + M6[5] * er[2];
+    return vx.w * (er[0] * Me0 + er[1] * Me1 + er[2] * Me2);
+}
+
+// kWithError = false: linearize(T) -- correspondences to a.corr_slot / a.corr_M, partial sums [0..27].
+// kWithError = true: one pass for an LM trial pose T: [28] = compute_error(T) on the correspondences of the last linearisation
+// (a.corr_slot / a.corr_M, read only) AND, speculatively, the linearisation AT T (correspondences to a.corr_slot_next /
+// a.corr_M_next, sums [0..27]).  When the trial is accepted -- the usual case -- T is the next linearisation point and the
+// host swaps the buffers instead of paying another launch and round trip; when it is rejected the sums are dropped.
+// Both sums go through the same fixed-order block reduction as a stand-alone linearisation: bit-identical values.
+template <bool kWithError>
 __global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a, const Pose16 T) {
-    __shared__ double sh[28 * kLinStride];
+    constexpr int kRows = kWithError ? 29 : 28;
+    __shared__ double sh[kRows * kLinStride];
     __shared__ double sh_sum[8 * 32];
     const GridHeader h = *a.hdr;
     const int tid = threadIdx.x, e = tid & 31, ch = tid >> 5;
@@ -366,104 +444,33 @@ __global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a,
         double v[28];
 #pragma unroll
         for (int k = 0; k < 28; ++k) v[k] = 0.0;
+        double err = 0.0;
         if (i < a.n_src) {
-            const float* sp = a.src + (size_t)i * a.src_stride;
-            const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
-            double tp[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
-            const uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
-            a.corr_slot[i] = slot;
-            if (slot) {
-                const VgicpVoxel vx = a.vox[slot - 1];
-                const double* ca = a.src_cov6 + (size_t)i * 6;
-                const double CA[3][3] = {{ca[0], ca[1], ca[2]}, {ca[1], ca[3], ca[4]}, {ca[2], ca[4], ca[5]}};
-                double RC[3][3], S[6];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) RC[r][c] = T.m[r] * CA[0][c] + T.m[4 + r] * CA[1][c] + T.m[8 + r] * CA[2][c];
-                int o = 0;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = r; c < 3; ++c) { S[o] = vx.cov[o] + (RC[r][0] * T.m[c] + RC[r][1] * T.m[4 + c] + RC[r][2] * T.m[8 + c]); ++o; }
-                double M6[6];
-                inv3_sym(S, M6);   // (C_B + T C_A T^T)^-1, fast_vgicp_impl.hpp:104-115
-#pragma unroll
-                for (int k = 0; k < 6; ++k) a.corr_M[(size_t)i * 6 + k] = M6[k];
-                const double M[3][3] = {{M6[0], M6[1], M6[2]}, {M6[1], M6[3], M6[4]}, {M6[2], M6[4], M6[5]}};
-                const double er[3] = {vx.mean[0] - tp[0], vx.mean[1] - tp[1], vx.mean[2] - tp[2]};
-                double Me[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) Me[r] = M[r][0] * er[0] + M[r][1] * er[1] + M[r][2] * er[2];
-                const double w = vx.w;
-                // J = [skew(Tp) | -I]   fast_vgicp_impl.hpp:156-158, so3.hpp:21-31
-                const double J[3][6] = {{0, -tp[2], tp[1], -1, 0, 0}, {tp[2], 0, -tp[0], 0, -1, 0}, {-tp[1], tp[0], 0, 0, 0, -1}};
-                double MJ[3][6];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) MJ[r][c] = M[r][0] * J[0][c] + M[r][1] * J[1][c] + M[r][2] * J[2][c];
-                int q = 0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = r; c < 6; ++c) v[q++] = w * (J[0][r] * MJ[0][c] + J[1][r] * MJ[1][c] + J[2][r] * MJ[2][c]);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) v[21 + r] = w * (J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2]);
-                v[27] = w * (er[0] * Me[0] + er[1] * Me[1] + er[2] * Me[2]);
+            if (kWithError) {
+                err = vgicp_err_point(a, T, i);
+                vgicp_lin_point(a, h, T, i, v, a.corr_slot_next, a.corr_M_next);
+            } else {
+                vgicp_lin_point(a, h, T, i, v, a.corr_slot, a.corr_M);
             }
         }
 #pragma unroll
         for (int k = 0; k < 28; ++k) sh[k * kLinStride + tid] = v[k];
+        if (kWithError) sh[28 * kLinStride + tid] = err;
         __syncthreads();
-        if (e < 28) {
+        if (e < kRows) {
             const double* row = sh + e * kLinStride + ch * 32;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) acc += row[k];
         }
         __syncthreads();
     }
-    sh_sum[ch * 32 + e] = e < 28 ? acc : 0.0;
+    sh_sum[ch * 32 + e] = e < kRows ? acc : 0.0;
     __syncthreads();
     if (tid < 32) {
         double s = sh_sum[tid];
 #pragma unroll
         for (int c = 1; c < 8; ++c) s += sh_sum[c * 32 + tid];
         a.partials[(size_t)blockIdx.x * 32 + tid] = s;
-    }
-}
-
-// compute_error (fast_vgicp_impl.hpp:183-204): same correspondences and Mahalanobis matrices, new pose
-__global__ __launch_bounds__(256) void vgicp_error_kernel(const VgicpArgs a, const Pose16 T) {
-    __shared__ double sh[256];
-    double acc = 0.0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n_src; i += gridDim.x * 256) {
-        const uint32_t slot = a.corr_slot[i];
-        if (slot) {
-            const float* sp = a.src + (size_t)i * a.src_stride;
-            const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
-            const VgicpVoxel vx = a.vox[slot - 1];
-            double er[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) er[r] = vx.mean[r] - (T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0);
-            const double* M6 = a.corr_M + (size_t)i * 6;
-            const double Me0 = M6[0] * er[0] + M6[1] * er[1] + M6[2] * er[2], Me1 = M6[1] * er[0] + M6[3] * er[1] + M6[4] * er[2],
-                         Me2 = M6[2] * er[0] + M6[4] * er[1] + M6[5] * er[2];
-            acc += vx.w * (er[0] * Me0 + er[1] * Me1 + er[2] * Me2);
-        }
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    // fixed-order tree
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        a.partials[(size_t)blockIdx.x * 32] = sh[0];
-        for (int k = 1; k < 32; ++k) a.partials[(size_t)blockIdx.x * 32 + k] = 0.0;
     }
 }
 
@@ -546,14 +553,14 @@ uint32_t vgicp_blocks(uint32_t n_src) {
 
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq) {
     const uint32_t nb = vgicp_blocks(a.n_src);
-    hipLaunchKernelGGL(vgicp_linearize_kernel, dim3(nb), dim3(256), 0, s, a, T);
+    hipLaunchKernelGGL(vgicp_linearize_kernel<false>, dim3(nb), dim3(256), 0, s, a, T);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32, seq);
     return hipGetLastError();
 }
 
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq) {
     const uint32_t nb = vgicp_blocks(a.n_src);
-    hipLaunchKernelGGL(vgicp_error_kernel, dim3(nb), dim3(256), 0, s, a, T);
+    hipLaunchKernelGGL(vgicp_linearize_kernel<true>, dim3(nb), dim3(256), 0, s, a, T);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32, seq);
     return hipGetLastError();
 }
