@@ -80,7 +80,13 @@ struct pcr_handle {
 
     // VGICP work memory
     GridIndex src_grid;
-    GridIndex cov_l1, cov_l2;        // the cloud whose covariances are being computed, indexed at 4x and 16x the cell
+    GridIndex cov_l1, cov_l2;        // the TARGET cloud while its covariances are computed, indexed at 4x and 16x the cell
+    GridIndex src_l1, src_l2;        // the same for the source (own buffers: its side runs on side_stream next to the target's)
+    hipStream_t side_stream = nullptr;     // source index + covariances of a scan2map call, concurrent with the target preparation
+    hipEvent_t ev_side_in = nullptr, ev_side_done = nullptr;
+    GridHeader* side_hdr = nullptr;  // pinned: headers of the three source levels, read back without blocking the host
+    bool side_pending = false;       // source work of (side_src, side_n, side_stride) is in flight on side_stream
+    const float* side_src = nullptr; size_t side_n = 0, side_stride = 0;
     GridHeader cov_hdr0;             // header of the fine level of the last settle_cov_levels (density estimate)
     DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, corr_slot2, corr_M2, vg_partials;
     double seq = 0.0;                    // completion numbers of the host-mapped result blocks below
@@ -306,8 +312,9 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
 int cov_levels(size_t n) { return n <= 300000 ? 3 : 1; }
 
 // the fine index plus the coarse ones of the covariance search, settled with one round trip
-int settle_cov_levels(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell, double shift0) {
-    GridIndex* lv[3] = {&g, &h->cov_l1, &h->cov_l2};
+int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
+                      double shift0, GridHeader* hdr0_out) {
+    GridIndex* lv[3] = {&g, &l1, &l2};
     const double cells[3] = {cell, 4.0 * cell, 16.0 * cell};
     const int levels = cov_levels(n);
     bool todo[3] = {true, levels > 1, levels > 2};
@@ -323,11 +330,61 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n,
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
             if (hdr[l].overflow) { if (lv[l]->grow_cells(hdr[l].n_cells, &h->err) != hipSuccess) return 1; again = true; }
-            else { todo[l] = false; if (l == 0) h->cov_hdr0 = hdr[0]; }
+            else { todo[l] = false; if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
         }
         if (!again) return 0;
     }
     return fail(h, "index could not be sized");
+}
+
+// Source side of a VGICP scan2map call (its own index levels + covariances, fast_gicp_impl.hpp:103-108) enqueued on the side
+// stream BEFORE the target is prepared on the main one: the 65 k-point covariance search is latency-bound and hides under
+// the target's kernels.  Speculative about the cell tables: an overflowing level makes its kernels return early, which
+// vgicp_source_settle() detects from the headers and redoes in order.
+int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats) {
+    h->side_pending = false;
+    if (!h->side_stream) {
+        H_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        H_TRY(hipEventCreateWithFlags(&h->ev_side_in, hipEventDisableTiming));
+        H_TRY(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+        H_TRY(hipHostMalloc((void**)&h->side_hdr, 3 * sizeof(GridHeader), hipHostMallocDefault));
+    }
+    if (n_src > 0xfffffff0ull) return 0;                         // run_vgicp reports it
+    H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
+    H_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
+    H_TRY(hipStreamWaitEvent(h->side_stream, h->ev_side_in, 0));
+    GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
+    const double cell = h->prm.vgicp_resolution, cells[3] = {cell, 4.0 * cell, 16.0 * cell};
+    const int levels = cov_levels(n_src);
+    for (int l = 0; l < levels; ++l) {
+        if (lv[l]->build(d_src, n_src, stride_floats, cells[l], h->side_stream, &h->err, 0.0) != hipSuccess) return 1;
+        H_TRY(hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream));
+    }
+    H_TRY(vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
+                           h->src_cov6.as<double>(), h->side_stream));
+    H_TRY(hipEventRecord(h->ev_side_done, h->side_stream));
+    h->side_pending = true; h->side_src = d_src; h->side_n = n_src; h->side_stride = stride_floats;
+    return 0;
+}
+
+// Source covariances ready on return (ordered before whatever the main stream runs next).
+int vgicp_source_settle(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats) {
+    const int levels = cov_levels(n_src);
+    if (h->side_pending && h->side_src == d_src && h->side_n == n_src && h->side_stride == stride_floats) {
+        h->side_pending = false;
+        H_TRY(hipEventSynchronize(h->ev_side_done));
+        bool overflow = false;
+        for (int l = 0; l < levels; ++l) overflow = overflow || h->side_hdr[l].overflow != 0;
+        if (!overflow) { H_TRY(hipStreamWaitEvent(h->stream, h->ev_side_done, 0)); return 0; }
+    } else if (h->side_pending) {
+        h->side_pending = false;
+        H_TRY(hipEventSynchronize(h->ev_side_done));             // never leave side work in flight behind the caller's back
+    }
+    if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_src, n_src, stride_floats, h->prm.vgicp_resolution, 0.0, nullptr)) return 1;
+    H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
+    H_TRY(vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
+                           h->src_cov6.as<double>(), h->stream));
+    return 0;
 }
 
 int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
@@ -335,7 +392,7 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     const double res = h->prm.vgicp_resolution;
     if (!(res > 0)) return fail(h, "vgicp_resolution must be positive");
     if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
-    if (settle_cov_levels(h, h->grid, d_dst, n_dst, stride_floats, res, 0.5)) return 1;
+    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->tgt_cov6.reserve((n_dst + 1) * 6 * sizeof(double)));
     H_TRY(h->vox.reserve((n_dst + 1) * sizeof(VgicpVoxel)));
@@ -405,11 +462,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         memset(h->out32_host, 0, 32 * sizeof(double));
         H_TRY(hipHostGetDevicePointer((void**)&h->out32_dev, h->out32_host, 0));
     }
-    // source covariances over the source's own index (fast_gicp_impl.hpp:103-108)
-    if (settle_cov_levels(h, h->src_grid, d_src, n_src, stride_floats, h->prm.vgicp_resolution, 0.0)) return 1;
-    H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
-    H_TRY(vgicp_launch_cov(h->src_grid, cov_levels(n_src) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_src) > 2 ? &h->cov_l2 : nullptr, d_src, stride_floats, n_src,
-                           h->src_cov6.as<double>(), h->stream));
+    // source covariances over the source's own index (fast_gicp_impl.hpp:103-108): already in flight when this is a
+    // scan2map call, computed here otherwise
+    if (vgicp_source_settle(h, d_src, n_src, stride_floats)) return 1;
     H_TRY(h->corr_slot.reserve((n_src + 1) * sizeof(uint32_t)));
     H_TRY(h->corr_M.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(h->corr_slot2.reserve((n_src + 1) * sizeof(uint32_t)));
@@ -818,7 +873,11 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     if (h->method == kVgicp) {
         // the reference keeps its target structures while the cloud POINTER is unchanged and goes stale
         // when the cloud is edited in place; this entry point always rebuilds them
-        if (vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
+        if (vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4)) return 1;
+        if (vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4)) {
+            if (h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
+            return 1;
+        }
         if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
         if (run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
         if (h->profile >= 1) {
@@ -902,7 +961,8 @@ void pcr_destroy(pcr_handle* h) {
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
-    h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
     h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release();
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
@@ -914,6 +974,10 @@ void pcr_destroy(pcr_handle* h) {
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_index) (void)hipEventDestroy(h->ev_index);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->side_hdr) (void)hipHostFree(h->side_hdr);
+    if (h->ev_side_in) (void)hipEventDestroy(h->ev_side_in);
+    if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1078,10 +1142,11 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     const float* d_pts = (const float*)pts;
     if (!on_device && stage_host(h, &h->src_stage, pts, n, stride_bytes, &d_pts)) return 1;
-    if (settle_cov_levels(h, h->src_grid, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution, 0.0)) return 1;
+    if (h->side_pending) { H_TRY(hipEventSynchronize(h->ev_side_done)); h->side_pending = false; }
+    if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution, 0.0, nullptr)) return 1;
     H_TRY(h->src_cov6.reserve((n + 1) * 6 * sizeof(double)));
     H_TRY(hipMemsetAsync(h->src_cov6.p, 0, (n + 1) * 6 * sizeof(double), h->stream));
-    H_TRY(vgicp_launch_cov(h->src_grid, cov_levels(n) > 1 ? &h->cov_l1 : nullptr, cov_levels(n) > 2 ? &h->cov_l2 : nullptr, d_pts, stride_bytes / 4, n,
+    H_TRY(vgicp_launch_cov(h->src_grid, cov_levels(n) > 1 ? &h->src_l1 : nullptr, cov_levels(n) > 2 ? &h->src_l2 : nullptr, d_pts, stride_bytes / 4, n,
                            h->src_cov6.as<double>(), h->stream));
     H_TRY(hipMemcpyAsync(cov_out, h->src_cov6.p, n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipStreamSynchronize(h->stream));
