@@ -70,14 +70,15 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
         __hip_atomic_store(&partials[blockIdx.x * 6 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                                       // partials visible device-wide before the ticket
-        sh_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        // The six stores above come from this wave and go to device scope (sc1, past this XCD's L2), as do the loads of the
+        // folding block: waiting for their acknowledgement orders them before the ticket.  (A release fence here writes
+        // back and invalidates the whole L2 of the XCD -- once per block.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!sh_last) return;
-    __threadfence();
     // ---- last block: fold the partial boxes (read past this XCD's L2) and write the header ----
     float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
