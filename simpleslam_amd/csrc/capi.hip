@@ -65,6 +65,8 @@ struct pcr_handle {
     const float* tgt_ptr = nullptr;   // device pointer the index was built from (for rebuild on overflow)
     size_t tgt_n = 0, tgt_stride = 0;
     bool have_target = false;
+    ClampBox clamp{};                // LOAM scan2map fallback: region of interest of a target whose full box cannot be tabulated
+    bool clamp_allowed = false;      // set while a scan2map call (target rebuilt for this very scan) is running
     uint32_t last_blocks = 0;        // linearisation blocks of the last LOAM call (timeline readout)
     // source
     DeviceBuf src_stage;
@@ -170,7 +172,7 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
 int build_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
     double cell = 1.0;
     if (h->method == kLoam) cell = grid_cell_for(h->prm.loam_knn_max_sq);
-    hipError_t e = h->grid.build(d_dst, n_dst, stride_floats, cell, h->stream, &h->err);
+    hipError_t e = h->grid.build(d_dst, n_dst, stride_floats, cell, h->stream, &h->err, 0.0, 0, h->clamp.use ? &h->clamp : nullptr);
     if (e != hipSuccess) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     return 0;
@@ -178,8 +180,45 @@ int build_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_
 
 // After a synchronisation: did the device-side build overflow the cell table?  Then grow and rebuild.
 // Returns 0 ok (no overflow), 2 rebuilt (caller must rerun), 1 error.
-int check_grid_overflow(pcr_handle* h, int overflow, uint64_t need_cells) {
+// Dense tables stop at 4e9 cells.  A cloud that needs more -- a stray point kilometres away from the map -- is refused,
+// except where the caller's scan tells which part of it can matter: LOAM scan2map then indexes only the target points
+// within kClampMargin of the scan as the initial pose places it (a query only ever looks one gate radius around itself;
+// the margin is the room the pose has to move during the iterations).  Exact unless the pose travels farther than that.
+static constexpr double kClampMargin = 10.0;
+
+int set_clamp_from_scan(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16]) {
+    if (!n_src) return fail(h, "target bounding box too large for the dense index and the scan is empty");
+    // bounding box of the scan: one index build over it (rare path), read back from its header
+    if (h->src_grid.build(d_src, n_src, stride_floats, 1.0, h->stream, &h->err) != hipSuccess) return 1;
+    GridHeader sh;
+    H_TRY(hipMemcpyAsync(&sh, h->src_grid.header.p, sizeof sh, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    if (sh.empty) return fail(h, "target bounding box too large for the dense index and the scan has no finite point");
+    double lo[3], hi[3], mlo[3] = {1e300, 1e300, 1e300}, mhi[3] = {-1e300, -1e300, -1e300};
+    for (int d = 0; d < 3; ++d) { lo[d] = sh.origin[d]; hi[d] = sh.origin[d] + sh.dims[d] * sh.cell; }      // a superset of the scan's box
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {c & 1 ? hi[0] : lo[0], c & 2 ? hi[1] : lo[1], c & 4 ? hi[2] : lo[2]};
+        for (int r = 0; r < 3; ++r) {
+            const double v = pose[r] * p[0] + pose[4 + r] * p[1] + pose[8 + r] * p[2] + pose[12 + r];
+            mlo[r] = std::min(mlo[r], v); mhi[r] = std::max(mhi[r], v);
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (!(mlo[d] == mlo[d] && mhi[d] == mhi[d])) return fail(h, "target bounding box too large for the dense index and the initial pose is not finite");
+        h->clamp.lo[d] = mlo[d] - kClampMargin; h->clamp.hi[d] = mhi[d] + kClampMargin;
+    }
+    h->clamp.use = 1;
+    return 0;
+}
+
+int check_grid_overflow(pcr_handle* h, int overflow, uint64_t need_cells, const float* d_src = nullptr, size_t n_src = 0, size_t stride_floats = 0,
+                        const double* pose = nullptr) {
     if (!overflow) return 0;
+    if (need_cells > 4000000000ull && h->method == kLoam && d_src && pose && !h->clamp.use) {
+        if (set_clamp_from_scan(h, d_src, n_src, stride_floats, pose)) return 1;
+        if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
+        return 2;
+    }
     if (h->grid.grow_cells(need_cells, &h->err) != hipSuccess) return 1;
     if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
     return 2;
@@ -225,7 +264,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         }
         const LoamResult r = *h->result_host;
         if (r.pad != 1) return fail(h, "LOAM finalize kernel did not complete");
-        int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells);
+        int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
         if (ov == 1) return 1;
         if (ov == 2) { index_timed = false; continue; }
         memcpy(pose, r.pose, 16 * sizeof(double));
@@ -891,9 +930,14 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         return 0;
     }
     // the reference rebuilds its index on every call (LoamRegister.cpp:110); so do we
+    h->clamp.use = 0;
     if (build_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
     if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
-    return run_loam(h, d_src, n_src, stride_bytes / 4, pose, converged, true);
+    h->clamp_allowed = true;           // this target exists for this scan only: a box that cannot be tabulated may be cut around it
+    const int rc = run_loam(h, d_src, n_src, stride_bytes / 4, pose, converged, true);
+    h->clamp_allowed = false;
+    if (h->clamp.use) { h->clamp.use = 0; h->have_target = false; h->grid.valid = false; }      // not an index pcr_align may reuse
+    return rc;
 }
 
 }  // namespace
@@ -1006,6 +1050,7 @@ int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_b
     if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     if (h->method == kVgicp) return vgicp_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
     if (h->method == kNdt) return ndt_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
+    h->clamp.use = 0;
     if (build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4)) return 1;
     // settle the cell-table size now so that pcr_align never has to rebuild
     for (int attempt = 0; attempt < 3; ++attempt) {

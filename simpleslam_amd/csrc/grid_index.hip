@@ -10,6 +10,7 @@
 // Everything is enqueued on one stream with no host synchronisation; the grid
 // geometry lives in a device-side GridHeader that the later kernels read.
 #include "pcr_internal.h"
+#include <string.h>
 
 namespace pcr {
 
@@ -33,7 +34,8 @@ __device__ inline float wave_max(float v) {
 // (one launch instead of two; the cell counters are NOT cleared here: every build leaves them zeroed, see the scan)
 __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
                                                                float* __restrict__ partials, uint32_t* __restrict__ ticket,
-                                                               GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode) {
+                                                               GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode,
+                                                               const ClampBox clamp) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     // eight independent loads in flight per lane (a 1 M-point cloud is 16-32 MB: this pass should run at HBM speed)
     constexpr int kU = 8;
@@ -102,11 +104,16 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         h.empty = 0; h.overflow = 0;
         h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0; h.sum_sq = 0.f;
         h.min_b[0] = h.min_b[1] = h.min_b[2] = 0;
+        h.clamped = (clamp.use && !pcl_mode) ? 1 : 0; h.pad_ = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
             float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
             if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
+            if (h.clamped) {      // keep the part of the box inside the region of interest (points outside get no key)
+                lo = fmaxf(lo, (float)clamp.lo[d]); hi = fminf(hi, (float)clamp.hi[d]);
+                if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
+            }
             if (pcl_mode) {
                 // pcl::VoxelGrid::applyFilter: min_b = floor(min_p * inverse_leaf_size), float arithmetic throughout
                 const float flo = floorf(lo * h.inv_leaf_f), fhi = floorf(hi * h.inv_leaf_f);
@@ -148,6 +155,8 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
     const double fx = floor((double)x / h.cell - h.shift) - h.org[0];
     const double fy = floor((double)y / h.cell - h.shift) - h.org[1];
     const double fz = floor((double)z / h.cell - h.shift) - h.org[2];
+    if (h.clamped && !(fx >= (double)kPad && fx < (double)(h.dims[0] - kPad) && fy >= (double)kPad && fy < (double)(h.dims[1] - kPad) &&
+                       fz >= (double)kPad && fz < (double)(h.dims[2] - kPad))) return false;      // outside the region of interest
     const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
     *key = (cz * (uint32_t)h.dims[1] + cy) * (uint32_t)h.dims[0] + cx;
     return true;
@@ -335,7 +344,7 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 #define PCR_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { if (err) *err = std::string(#x) + ": " + hipGetErrorString(_e); return _e; } } while (0)
 
 hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift,
-                            int pcl_mode) {
+                            int pcl_mode, const ClampBox* clamp) {
     valid = false;
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
@@ -357,10 +366,13 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         cell_capacity = guess;
         PCR_TRY(block_sums.reserve(2 * (guess / kScanTile + 2) * sizeof(uint32_t)));
     }
+    ClampBox cb;
+    memset(&cb, 0, sizeof cb);
+    if (clamp) cb = *clamp;
     const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
     const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);
     hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
-                       ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode);
+                       ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode, cb);
     hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
                        cell_count.as<uint32_t>(), keys.as<uint32_t>(), ranks.as<uint32_t>());
     const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);

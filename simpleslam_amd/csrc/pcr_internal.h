@@ -38,7 +38,12 @@ struct GridHeader {
     int32_t too_fine;        // pcl_mode: more than INT_MAX voxels ("Leaf size is too small", voxel_grid.hpp)
     float sum_sq;            // sum over the cells of count^2 (written by the scan): sum_sq / points = occupancy of the cell a
                              // point lives in, averaged over the points -- the density estimate behind the choice of a search cell
+    int32_t clamped;         // the box was cut to a region of interest (ClampBox): points outside it are not indexed
+    int32_t pad_;
 };
+
+// Region of interest for an index whose full bounding box cannot be tabulated (a far outlier in the cloud): see capi.hip
+struct ClampBox { double lo[3], hi[3]; int32_t use, pad_; };
 
 struct GridView {            // what kernels need to query the index
     const GridHeader* hdr;
@@ -136,7 +141,7 @@ struct GridIndex {
     // Enqueue the build of the index over n points (device pointer, stride in floats).
     // No host synchronisation unless the cell table must grow.  cell = grid edge.
     hipError_t build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s,
-                     std::string* err, double shift = 0.0, int pcl_mode = 0);
+                     std::string* err, double shift = 0.0, int pcl_mode = 0, const ClampBox* clamp = nullptr);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
     void release();

@@ -485,3 +485,31 @@ def test_handles_release_their_device_memory(gpu, world_small):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned after 25 create/use/destroy cycles"
+
+
+def test_far_outlier_in_the_target(gpu, world_small):
+    """One stray point kilometres (or 3e38 m) away makes the bounding box too large for dense cell tables.  scan2Map then
+    indexes the part of the target around the scan (it only ever looks one gate radius around a query) and returns what
+    the oracle returns on the same cloud; an index without a scan to cut the box around (setTarget) is still refused, and
+    the cut index is not offered to a later align()."""
+    from simpleslam_amd import PcrError
+    w = world_small
+    clean = LoamRegister()
+    p0 = w["init"].copy()
+    c0 = clean.scan2Map(w["scan"], w["map"], p0)
+    for dist in (2.0e4, 1.0e6, 3.0e38):
+        m = w["map"].copy()
+        m[0, :3] = [dist, -dist / 2, dist / 7]
+        po, co, _ = oracle.loam_scan2map(w["scan"], m, w["init"])
+        reg = LoamRegister()
+        p = w["init"].copy()
+        assert reg.scan2Map(w["scan"], m, p) == co
+        dt, dr = synth.pose_error(p, po)
+        assert dt < 1e-9 and dr < 1e-9, (dist, dt, dr)
+        with pytest.raises(PcrError):
+            reg.align(w["scan"], w["init"].copy())                 # the cut index is private to that call
+        with pytest.raises(PcrError, match="too sparse"):
+            reg.setTarget(m)
+        p2 = w["init"].copy()                                      # and the handle is as good as new on an ordinary target
+        assert reg.scan2Map(w["scan"], w["map"], p2) == c0
+        np.testing.assert_array_equal(p2, p0)
