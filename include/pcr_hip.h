@@ -71,7 +71,10 @@ typedef struct pcr_params {
      *   [0] ablation mask for profiling (only in a -DPCR_ABLATION build; results become meaningless)   [1] unused
      *   [2] = 1: disable the temporal-coherence neighbour cache          [3] = 1: record the in-kernel timeline (pcr_get_timeline)
      *   [4] = 1: two-waves-per-SIMD variant of the iterate kernel -- ~3 % slower for one handle, ~25 % more scans/s when
-     *            several handles register scans concurrently on one GPU (their blocks can then share the CUs) */
+     *            several handles register scans concurrently on one GPU (their blocks can then share the CUs)
+     *   [5] != 0: first margin, in millimetres, of the region a LOAM target too sparse for the dense index is cut to around the
+     *            scan (default 10 m; it grows whenever a query reaches a cut face -- a test hook for that path: a negative value
+     *            cuts into the scan's own box, so that the first attempts must be widened) */
     int32_t reserved[7];
 } pcr_params;
 
@@ -84,6 +87,8 @@ typedef struct pcr_stats {
     int32_t kernel_launches;/* launches summed in kernel_ms */
     int32_t iterations;     /* linearisations performed */
     int64_t n_src, n_dst;
+    int32_t attempts;       /* LOAM: passes over the iteration loop (> 1: the cell table grew, or a cut index was widened) */
+    int32_t pad_;
 } pcr_stats;
 
 void pcr_default_params(pcr_params* p);
@@ -233,6 +238,37 @@ int pcr_set_query_tile(pcr_handle* h, const double lo[3], const double hi[3]);
  * caller (e.g. torch.distributed broadcast).  librccl is dlopen'ed here, never before. */
 int pcr_comm_unique_id(void* out128);
 int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks);
+/* The same exchange through a caller-supplied collective (MPI, gloo, threads of one process ...), used when no RCCL
+ * communicator is set: fn must combine `count` doubles IN PLACE over all ranks -- op 0 = sum, 1 = max -- return 0 on
+ * success, and leave bitwise-identical results on every rank (the ranks then solve redundantly and must agree).  It is
+ * called on the thread that called the registration entry point, between device launches (one host round trip per
+ * linearisation: the fallback and test path; RCCL keeps the exchange on the device).  fn == NULL clears it. */
+typedef int (*pcr_allreduce_fn)(double* inout, size_t count, int op, void* user);
+int pcr_comm_init_host(pcr_handle* h, pcr_allreduce_fn fn, void* user, int rank, int nranks);
+/* Tile of a sharded target, all three methods: the handle processes the scan points whose transformed position lies in
+ * [lo, hi) (as pcr_set_query_tile) and is promised that the target cloud it is given holds EVERY map point inside
+ * [lo - halo, hi + halo) (faces at +-1e30 are open).  What the halo must cover:
+ *   loam   the k-NN gate radius (sqrt(loam_knn_max_sq) = 1 m, LoamRegister.cpp:59);
+ *   ndt    lo, hi multiples of ndt_resolution and halo >= one voxel (two unless the resolution is a power of two): the
+ *          DIRECT7 neighbourhood (ndt_omp_impl.hpp:242) reads the six face voxels, which must be complete;
+ *   vgicp  lo, hi on the voxel lattice ((k + 0.5) * vgicp_resolution, fast_vgicp_voxel.hpp:158-160) and a halo that holds
+ *          the 20 nearest neighbours of every point of the tile (fast_gicp_impl.hpp:253): checked on the device for every
+ *          point within one voxel of the tile -- a neighbourhood that reaches past the halo fails the call on all ranks.
+ * Misaligned bounds are refused.  lo[0] > hi[0] clears the tile. */
+int pcr_set_shard(pcr_handle* h, const double lo[3], const double hi[3], double halo);
+
+/* Replace the parameters of a live handle (host-side state; the prepared target is dropped when a parameter that shaped
+ * it changed).  VgicpRegister::initForLC() (PCR/src/VgicpRegister.cpp:21-28, called on a constructed object at
+ * backend/src/LoopClosureManager.cpp:21-22) = pcr_set_params with vgicp_max_iters 100, vgicp_trans_eps 1e-6.  device and
+ * struct_size must match the handle's. */
+int pcr_set_params(pcr_handle* h, const pcr_params* p);
+int pcr_get_params(const pcr_handle* h, pcr_params* out);
+
+/* The fitness score of the reference's test/align.cpp:29-61: the source transformed by `pose` (float, as
+ * pcl::transformPointCloud), 1-NN in the handle's current target, mean of the squared distances that are <= max_sq
+ * (align.cpp uses 1.0); *n_in = points counted.  score = DBL_MAX when none is.  Any method's handle with a target. */
+int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, const double pose[16],
+                      double max_sq, double* score, int64_t* n_in);
 
 #ifdef __cplusplus
 }

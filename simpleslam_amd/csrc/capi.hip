@@ -108,8 +108,18 @@ struct pcr_handle {
     // multi-GPU
     int use_tile = 0;
     double tile_lo[3] = {0, 0, 0}, tile_hi[3] = {0, 0, 0};
-    void* comm = nullptr;
-    int nranks = 1;
+    bool have_halo = false;          // pcr_set_shard: the target holds every map point inside [tile_lo - halo, tile_hi + halo)
+    double halo = 0.0;
+    void* comm = nullptr;            // RCCL communicator (pcr_comm_init)
+    pcr_allreduce_fn host_ar = nullptr;     // or the caller's collective (pcr_comm_init_host)
+    void* host_ar_user = nullptr;
+    int nranks = 1, rank = 0;
+    double* red_host = nullptr;      // host-mapped, kAccum doubles: the LOAM sums on their way through the caller's collective
+    double* red_dev = nullptr;
+    DeviceBuf ar_stage;              // RCCL: staging of the 48 doubles the host-driven optimisers exchange
+    DeviceBuf dummy_grid;            // a GridHeader marked overflow + empty: the grid view of a rank whose index failed
+    DeviceBuf cov_viol;              // VGICP halo check: number of neighbourhoods that reach past the halo
+    double clamp_margin = 10.0;      // LOAM ClampBox: room around the scan, doubled when a query reached a cut face
 
     // timing
     hipEvent_t ev_start = nullptr, ev_index = nullptr, ev_end = nullptr;
@@ -123,6 +133,36 @@ namespace {
 #define H_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(_e); return 1; } } while (0)
 
 int fail(pcr_handle* h, const std::string& msg) { h->err = msg; return 1; }
+
+bool sharded(const pcr_handle* h) { return h->comm != nullptr || h->host_ar != nullptr; }
+
+// Combine n (<= 64) doubles held in host memory over the ranks of a sharded handle, in place: the caller's collective, or RCCL
+// through a device staging buffer.  The stream is idle when this is called (the values were just waited for).
+int ranks_allreduce(pcr_handle* h, double* v, int n, int op = 0) {
+    if (h->host_ar) {
+        const int rc = h->host_ar(v, (size_t)n, op, h->host_ar_user);
+        if (rc != 0) return fail(h, "the caller's all-reduce failed with code " + std::to_string(rc));
+        return 0;
+    }
+    if (h->comm) {
+        H_TRY(h->ar_stage.reserve(64 * sizeof(double)));
+        H_TRY(hipMemcpyAsync(h->ar_stage.p, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const int rc = g_rccl.allreduce(h->ar_stage.p, h->ar_stage.p, (size_t)n, /*ncclFloat64*/ 8, op == 1 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, h->comm, h->stream);
+        if (rc != 0) return fail(h, "ncclAllReduce failed with code " + std::to_string(rc));
+        H_TRY(hipMemcpyAsync(v, h->ar_stage.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+// pcr_set_shard: faces farther out than this are open (the outer tiles reach to +-1e30, shard.py)
+inline bool open_face(double v) { return !(fabs(v) < 1e29); }
+void shard_extent(const pcr_handle* h, double ext_lo[3], double ext_hi[3]) {
+    for (int d = 0; d < 3; ++d) {
+        ext_lo[d] = open_face(h->tile_lo[d]) ? -1e300 : h->tile_lo[d] - h->halo;
+        ext_hi[d] = open_face(h->tile_hi[d]) ? 1e300 : h->tile_hi[d] + h->halo;
+    }
+}
 
 double grid_cell_for(double max_sq) {
     // smallest power of two >= the gate radius, so that x / cell is exact in f64
@@ -141,6 +181,10 @@ int ensure_loam_buffers(pcr_handle* h) {
     if (!h->result_host) {
         H_TRY(hipHostMalloc((void**)&h->result_host, sizeof(LoamResult), hipHostMallocMapped));
         H_TRY(hipHostGetDevicePointer((void**)&h->result_dev, h->result_host, 0));
+    }
+    if (h->host_ar && !h->red_host) {
+        H_TRY(hipHostMalloc((void**)&h->red_host, kAccum * sizeof(double), hipHostMallocMapped));
+        H_TRY(hipHostGetDevicePointer((void**)&h->red_dev, h->red_host, 0));
     }
     return 0;
 }
@@ -182,9 +226,12 @@ int build_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_
 // Returns 0 ok (no overflow), 2 rebuilt (caller must rerun), 1 error.
 // Dense tables stop at 4e9 cells.  A cloud that needs more -- a stray point kilometres away from the map -- is refused,
 // except where the caller's scan tells which part of it can matter: LOAM scan2map then indexes only the target points
-// within kClampMargin of the scan as the initial pose places it (a query only ever looks one gate radius around itself;
-// the margin is the room the pose has to move during the iterations).  Exact unless the pose travels farther than that.
+// within clamp_margin of the scan as the initial pose places it (a query only ever looks one gate radius around itself;
+// the margin is the room the pose has to move during the iterations).  The kernels count the queries that come within a
+// cell of a cut face (LoamState.fail == 3): such a call is redone on a region twice as wide, so the result is the full
+// index's whenever the call succeeds.
 static constexpr double kClampMargin = 10.0;
+static constexpr int kClampRetries = 6;      // 10 m ... 320 m
 
 int set_clamp_from_scan(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16]) {
     if (!n_src) return fail(h, "target bounding box too large for the dense index and the scan is empty");
@@ -205,7 +252,7 @@ int set_clamp_from_scan(pcr_handle* h, const float* d_src, size_t n_src, size_t 
     }
     for (int d = 0; d < 3; ++d) {
         if (!(mlo[d] == mlo[d] && mhi[d] == mhi[d])) return fail(h, "target bounding box too large for the dense index and the initial pose is not finite");
-        h->clamp.lo[d] = mlo[d] - kClampMargin; h->clamp.hi[d] = mhi[d] + kClampMargin;
+        h->clamp.lo[d] = mlo[d] - h->clamp_margin; h->clamp.hi[d] = mhi[d] + h->clamp_margin;
     }
     h->clamp.use = 1;
     return 0;
@@ -224,16 +271,53 @@ int check_grid_overflow(pcr_handle* h, int overflow, uint64_t need_cells, const 
     return 2;
 }
 
+// Bring the enqueued index build to a usable state before anything else is launched: read the header back and grow the
+// cell table (or cut the box around the scan) until it fits.  No collective in here -- a sharded call settles its tile
+// on every rank independently and only then enters the exchange loop (a rank that retried on its own after the loop, as the
+// unsharded path does, would leave the other ranks' all-reduces without a peer).
+int settle_loam_index(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, const double* pose) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        GridHeader hdr;
+        H_TRY(hipMemcpyAsync(&hdr, h->grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        const int ov = check_grid_overflow(h, hdr.overflow, hdr.n_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
+        if (ov == 0) return 0;
+        if (ov == 1) return 1;
+    }
+    return fail(h, "target index could not be sized");
+}
 
 int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged,
              bool index_timed) {
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
     if (ensure_loam_buffers(h)) return 1;
     const int iters = std::max(0, h->prm.loam_iters);
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool shard = sharded(h);
+    // (pcr_params.reserved[5]: first margin in millimetres, a test hook that makes the widening path reachable with ordinary clouds)
+    // (may be negative: the scan's box is padded by two index cells already, so only a region cut INTO the scan makes queries reach its edge)
+    h->clamp_margin = h->prm.reserved[5] != 0 ? 1e-3 * h->prm.reserved[5] : kClampMargin;
+    const double margin_cap = kClampMargin * (1 << kClampRetries);
+    for (int attempt = 0; attempt < 24; ++attempt) {
+        bool rank_fail = false;
+        std::string rank_err;
+        if (shard) {
+            // The exchange loop below must run the same number of collectives on every rank whatever happens to this rank's
+            // index: settle it first, and if that fails take part with empty sums and a flag that stops all ranks together.
+            if (!h->grid.valid || settle_loam_index(h, d_src, n_src, stride_floats, pose)) {
+                rank_fail = true; rank_err = h->err.empty() ? "target index not built" : h->err;
+                if (!h->dummy_grid.p) {
+                    GridHeader dh;
+                    memset(&dh, 0, sizeof dh);
+                    dh.overflow = 1; dh.empty = 1; dh.cell = dh.inv_cell = 1.0; dh.n_cells = 1;
+                    if (h->dummy_grid.reserve(sizeof dh) != hipSuccess || hipMemcpy(h->dummy_grid.p, &dh, sizeof dh, hipMemcpyHostToDevice) != hipSuccess)
+                        return fail(h, rank_err + " (and no memory for the stand-in header: the other ranks of this call will hang)");
+                }
+            }
+        }
         LoamArgs a;
         fill_loam_args(h, &a, d_src, n_src, stride_floats, pose);
-        if (h->comm) a.reduced = h->loam_reduced.as<double>();
+        if (rank_fail) { a.grid.hdr = h->dummy_grid.as<GridHeader>(); a.grid.pts = nullptr; a.grid.cell_start = nullptr; a.rank_fail = 1; a.nn_cache = nullptr; }
+        if (shard) a.reduced = h->host_ar ? h->red_dev : h->loam_reduced.as<double>();
         h->result_host->pad = 0;
         if (h->profile >= 1 && !index_timed) { H_TRY(hipEventRecord(h->ev_start, h->stream)); H_TRY(hipEventRecord(h->ev_index, h->stream)); }
         const bool per_kernel = h->profile >= 2;
@@ -243,7 +327,12 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         for (int k = 0; k < iters; ++k) {
             if (per_kernel) H_TRY(loam_launch_iteration(a, k, h->stream, h->ev_kernel[2 * k], h->ev_kernel[2 * k + 1]));
             else H_TRY(loam_launch_iteration(a, k, h->stream));
-            if (h->comm) {
+            if (h->host_ar) {
+                // the caller's collective: sums to the host, through fn, back (one host round trip per linearisation)
+                H_TRY(loam_launch_reduce(a, k, h->red_dev, h->stream));
+                H_TRY(hipStreamSynchronize(h->stream));
+                if (ranks_allreduce(h, h->red_host, kAccum)) return 1;
+            } else if (h->comm) {
                 H_TRY(loam_launch_reduce(a, k, h->loam_reduced.as<double>(), h->stream));
                 int rc = g_rccl.allreduce(h->loam_reduced.p, h->loam_reduced.p, kAccum, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
                 if (rc != 0) return fail(h, "ncclAllReduce failed with code " + std::to_string(rc));
@@ -264,12 +353,28 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         }
         const LoamResult r = *h->result_host;
         if (r.pad != 1) return fail(h, "LOAM finalize kernel did not complete");
-        int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
-        if (ov == 1) return 1;
-        if (ov == 2) { index_timed = false; continue; }
+        if (r.fail == 2 || rank_fail)      // (every rank sees the flag in the sums of the first linearisation: all return here together)
+            return fail(h, rank_fail ? "this rank could not index its map tile: " + rank_err : "sharded scan2map: another rank could not index its map tile");
+        if (r.fail == 3) {
+            // some query reached a face the index was cut at: the same call again, twice the room around the scan.  Sharded: all
+            // ranks see the count in the same sums and come back here together, whether or not their own tile was cut.
+            h->clamp_margin = std::max(2.0 * h->clamp_margin, h->clamp_margin + 1.0);
+            if (h->clamp_margin > margin_cap) return fail(h, "the pose left the region of a target too sparse for the dense index (a stray point far from the map?)");
+            if (h->clamp.use) {
+                if (set_clamp_from_scan(h, d_src, n_src, stride_floats, pose)) { if (!shard) return 1; h->grid.valid = false; }
+                else if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) { if (!shard) return 1; }
+            }
+            index_timed = false;
+            continue;
+        }
+        if (!shard) {
+            int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
+            if (ov == 1) return 1;
+            if (ov == 2) { index_timed = false; continue; }
+        }
         memcpy(pose, r.pose, 16 * sizeof(double));
         if (converged) *converged = r.converged;
-        h->stats.iterations = r.iters_run;
+        h->stats.iterations = r.iters_run; h->stats.attempts = attempt + 1;
         h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
         h->stats.kernel_ms = 0; h->stats.kernel_launches = 0;
         if (h->profile >= 1) {
@@ -312,6 +417,16 @@ int check_stride(pcr_handle* h, size_t stride_bytes) {
 
 int set_device(pcr_handle* h) {
     H_TRY(hipSetDevice(h->device));
+    return 0;
+}
+
+int ensure_out32(pcr_handle* h) {
+    if (!h->out32_host) {
+        H_TRY(hipHostMalloc((void**)&h->out32_host, 32 * sizeof(double), hipHostMallocMapped));
+        memset(h->out32_host, 0, 32 * sizeof(double));
+        H_TRY(hipHostGetDevicePointer((void**)&h->out32_dev, h->out32_host, 0));
+    }
+    H_TRY(h->vg_partials.reserve((size_t)512 * 32 * sizeof(double)));
     return 0;
 }
 
@@ -395,13 +510,19 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
     GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
     const double cell = h->prm.vgicp_resolution, cells[3] = {cell, 4.0 * cell, 16.0 * cell};
     const int levels = cov_levels(n_src);
-    for (int l = 0; l < levels; ++l) {
-        if (lv[l]->build(d_src, n_src, stride_floats, cells[l], h->side_stream, &h->err, 0.0) != hipSuccess) return 1;
-        H_TRY(hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream));
+    // from here on kernels reading the caller's d_src may be queued on the side stream: an error must not return before they
+    // have drained (the caller is free to release d_src as soon as the call has failed)
+    hipError_t e = hipSuccess;
+    for (int l = 0; l < levels && e == hipSuccess; ++l) {
+        e = lv[l]->build(d_src, n_src, stride_floats, cells[l], h->side_stream, &h->err, 0.0);
+        if (e == hipSuccess && (e = hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream)) != hipSuccess)
+            h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
     }
-    H_TRY(vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
-                           h->src_cov6.as<double>(), h->side_stream));
-    H_TRY(hipEventRecord(h->ev_side_done, h->side_stream));
+    if (e == hipSuccess && (e = vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
+                                                 h->src_cov6.as<double>(), h->side_stream)) != hipSuccess)
+        h->err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
+    if (e == hipSuccess && (e = hipEventRecord(h->ev_side_done, h->side_stream)) != hipSuccess) h->err = std::string("hipEventRecord: ") + hipGetErrorString(e);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(h->side_stream); return 1; }
     h->side_pending = true; h->side_src = d_src; h->side_n = n_src; h->side_stride = stride_floats;
     return 0;
 }
@@ -448,9 +569,27 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
             cov_grid = &h->cov_l1;
         }
     }
+    CovCheck chk;
+    const bool check = h->use_tile && h->have_halo;
+    if (check) {
+        // sharded target (pcr_set_shard): the covariances of the points that can enter a voxel of the tile must be the whole
+        // map's -- every neighbourhood of a point within one voxel of the tile has to end inside the halo
+        H_TRY(h->cov_viol.reserve(16));
+        H_TRY(hipMemsetAsync(h->cov_viol.p, 0, 16, h->stream));
+        shard_extent(h, chk.ext_lo, chk.ext_hi);
+        for (int d = 0; d < 3; ++d) { chk.chk_lo[d] = h->tile_lo[d] - res; chk.chk_hi[d] = h->tile_hi[d] + res; }
+        chk.violations = h->cov_viol.as<uint32_t>();
+    }
     H_TRY(vgicp_launch_cov(*cov_grid, cov_levels(n_dst) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_dst) > 2 ? &h->cov_l2 : nullptr, d_dst, stride_floats,
-                           n_dst, h->tgt_cov6.as<double>(), h->stream));
+                           n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr));
     H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream));
+    if (check) {
+        uint32_t viol = 0;
+        H_TRY(hipMemcpyAsync(&viol, h->cov_viol.p, sizeof viol, hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        if (viol) return fail(h, std::to_string(viol) + " target points near this rank's tile have their 20 nearest neighbours reaching past the halo of " +
+                                 std::to_string(h->halo) + " m: shard the map with a wider halo");
+    }
     h->vg_target_ready = true;
     return 0;
 }
@@ -496,11 +635,7 @@ bool host_is_converged(const double D[16], double rot_eps, double trans_eps) {
 int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged) {
     if (!h->vg_target_ready) return fail(h, "no target prepared");
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
-    if (!h->out32_host) {
-        H_TRY(hipHostMalloc((void**)&h->out32_host, 32 * sizeof(double), hipHostMallocMapped));
-        memset(h->out32_host, 0, 32 * sizeof(double));
-        H_TRY(hipHostGetDevicePointer((void**)&h->out32_dev, h->out32_host, 0));
-    }
+    if (ensure_out32(h)) return 1;
     // source covariances over the source's own index (fast_gicp_impl.hpp:103-108): already in flight when this is a
     // scan2map call, computed here otherwise
     if (vgicp_source_settle(h, d_src, n_src, stride_floats)) return 1;
@@ -508,7 +643,6 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     H_TRY(h->corr_M.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(h->corr_slot2.reserve((n_src + 1) * sizeof(uint32_t)));
     H_TRY(h->corr_M2.reserve((n_src + 1) * 6 * sizeof(double)));
-    H_TRY(h->vg_partials.reserve((size_t)512 * 32 * sizeof(double)));
     VgicpArgs a;
     a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)stride_floats;
     a.src_cov6 = h->src_cov6.as<double>();
@@ -518,6 +652,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
     a.corr_slot_next = h->corr_slot2.as<uint32_t>(); a.corr_M_next = h->corr_M2.as<double>();
     a.partials = h->vg_partials.as<double>();
+    a.use_tile = h->use_tile; a.pad_ = 0;
+    for (int d = 0; d < 3; ++d) { a.tile_lo[d] = h->tile_lo[d]; a.tile_hi[d] = h->tile_hi[d]; }
+    const bool shard = sharded(h);      // every rank linearises its tile's share of the scan; H, b and the error are summed over the ranks
 
     Pose16 x0;
     for (int i = 0; i < 16; ++i) x0.m[i] = (double)(float)pose[i];     // guess handed over as Matrix4f (VgicpRegister.cpp:36)
@@ -535,6 +672,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
             h->seq += 1.0;
             H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream, h->seq));
             if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
+            if (shard && ranks_allreduce(h, h->out32_host, 29)) return 1;
             ++h->vg_lin;
             for (int k = 0; k < 28; ++k) lin[k] = h->out32_host[k];
         }
@@ -558,6 +696,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
             h->seq += 1.0;
             H_TRY(vgicp_launch_error(a, xi, h->out32_dev, h->stream, h->seq));
             if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
+            if (shard && ranks_allreduce(h, h->out32_host, 29)) return 1;
             ++h->vg_err;
             const double yi = h->out32_host[28];
             double den = 0;
@@ -586,9 +725,21 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     if (converged) *converged = conv ? 1 : 0;
     // pcl::Registration::getFitnessScore() of the aligned source (VgicpRegister.cpp:42-45)
     h->seq += 1.0;
-    H_TRY(fitness_launch(h->grid, d_src, n_src, stride_floats, pose, 1.7976931348623157e308, h->vg_partials.as<double>(), h->out32_dev, h->stream, h->seq));
+    FitTile ft;
+    memset(&ft, 0, sizeof ft);
+    if (h->use_tile) {
+        ft.use = 1;
+        for (int d = 0; d < 3; ++d) { ft.lo[d] = h->tile_lo[d]; ft.hi[d] = h->tile_hi[d]; ft.ext_lo[d] = -1e300; ft.ext_hi[d] = 1e300; }
+        if (h->have_halo) shard_extent(h, ft.ext_lo, ft.ext_hi);
+    }
+    H_TRY(fitness_launch(h->grid, d_src, n_src, stride_floats, pose, 1.7976931348623157e308, h->vg_partials.as<double>(), h->out32_dev, h->stream, h->seq,
+                         h->use_tile ? &ft : nullptr));
     if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
+    if (shard && ranks_allreduce(h, h->out32_host, 3)) return 1;
     h->fitness = h->out32_host[1] > 0 ? h->out32_host[0] / h->out32_host[1] : 1.7976931348623157e308;
+    // sharded: a source point farther from every map point than its rank's halo has its nearest neighbour on another rank; the
+    // score is then not the map's and is reported as unavailable (the pose is unaffected)
+    if (h->use_tile && h->out32_host[2] > 0) h->fitness = -1.0;
     h->stats.iterations = h->vg_outer; h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
     h->stats.kernel_launches = h->vg_lin + h->vg_err;
     return 0;
@@ -607,12 +758,14 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
     if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
-    const size_t max_vox = n_dst / std::max(1, h->prm.ndt_min_points) + 2;      // a voxel needs min_points points
+    // setMinPointPerVoxel (pclomp/voxel_grid_covariance_omp.h:229-240): "Covariance calculation requires at least 3 points"
+    const int min_points = std::max(3, h->prm.ndt_min_points);
+    const size_t max_vox = n_dst / (size_t)min_points + 2;      // a voxel needs min_points points
     H_TRY(h->nd_vox.reserve(max_vox * sizeof(NdtVoxel)));
     H_TRY(h->nd_list.reserve((max_vox + 64) * sizeof(uint32_t)));
     H_TRY(h->nd_count.reserve(16));
     H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>(), h->nd_list.as<uint32_t>(),
-                            max_vox, h->prm.ndt_min_points, 0.01, h->stream));
+                            max_vox, min_points, 0.01, h->stream));
     h->nd_target_ready = true;
     return 0;
 }
@@ -749,6 +902,7 @@ int ndt_derivatives(NdtRun* r, const double p[6], bool compute_hessian, double* 
     h->seq += 1.0;
     H_TRY(ndt_launch_derivatives(r->a, r->T, r->ang, compute_hessian ? 1 : 0, h->out48_dev, h->stream, h->seq));
     if (wait_result(h, &h->out48_host[47], h->seq)) return 1;
+    if (sharded(h) && ranks_allreduce(h, h->out48_host, 43)) return 1;      // score, gradient, Hessian summed over the ranks' tiles
     ++h->nd_deriv;
     *score = h->out48_host[0];
     for (int i = 0; i < 6; ++i) grad[i] = h->out48_host[1 + i];
@@ -811,6 +965,7 @@ int ndt_step_length(NdtRun* r, const double x[6], double dir[6], double step_ini
         h->seq += 1.0;
         H_TRY(ndt_launch_hessian(r->a, r->T, r->ang, h->out48_dev, h->stream, h->seq));
         if (wait_result(h, &h->out48_host[47], h->seq)) return 1;
+        if (sharded(h) && ranks_allreduce(h, h->out48_host, 43)) return 1;
         ++h->nd_hess;
         for (int i = 0; i < 36; ++i) hess[i] = h->out48_host[7 + i];
     }
@@ -833,6 +988,8 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)stride_floats;
     r.a.hdr = h->grid.header.as<GridHeader>(); r.a.vox_slot = h->nd_slot.as<uint32_t>(); r.a.vox = h->nd_vox.as<NdtVoxel>();
     r.a.partials = h->nd_partials.as<double>();
+    r.a.use_tile = h->use_tile; r.a.pad_ = 0;
+    for (int d = 0; d < 3; ++d) { r.a.tile_lo[d] = h->tile_lo[d]; r.a.tile_hi[d] = h->tile_hi[d]; }
     {   // Gauss constants (ndt_omp_impl.hpp:86-93)
         const double res = (double)(float)h->prm.ndt_resolution;
         const double c1 = 10 * (1 - h->prm.ndt_outlier_ratio), c2 = h->prm.ndt_outlier_ratio / pow(res, 3);
@@ -880,6 +1037,18 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     return 0;
 }
 
+// Sharded calls: before any rank enters an exchange loop every rank must know that ALL ranks have a usable target (a rank
+// returning early would leave the others' collectives without a peer).  One MAX over the ranks of a status word.
+int agree_prepared(pcr_handle* h, int rc_local) {
+    if (!sharded(h)) return rc_local;
+    const std::string err = h->err;
+    double flag = rc_local ? 1.0 : 0.0;
+    if (ranks_allreduce(h, &flag, 1, 1)) return 1;
+    if (rc_local) { h->err = err; return 1; }
+    if (flag != 0.0) return fail(h, "sharded call: another rank could not prepare its map tile");
+    return 0;
+}
+
 int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst, size_t stride_bytes,
                 double pose[16], int* converged, bool on_device) {
     if (!h) return 1;
@@ -896,7 +1065,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     }
     if (h->method == kNdt) {
         // NdtRegister::scan2Map calls setInputTarget every time, which rebuilds the voxel grid (NdtRegister.cpp:23)
-        if (ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
+        if (agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4))) return 1;
         if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
         if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
         if (h->profile >= 1) {
@@ -912,8 +1081,10 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     if (h->method == kVgicp) {
         // the reference keeps its target structures while the cloud POINTER is unchanged and goes stale
         // when the cloud is edited in place; this entry point always rebuilds them
-        if (vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4)) return 1;
-        if (vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4)) {
+        int prc = vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4);
+        if (!prc) prc = vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4);
+        if (prc && h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
+        if (agree_prepared(h, prc)) {
             if (h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
             return 1;
         }
@@ -931,7 +1102,11 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     }
     // the reference rebuilds its index on every call (LoamRegister.cpp:110); so do we
     h->clamp.use = 0;
-    if (build_target(h, d_dst, n_dst, stride_bytes / 4)) return 1;
+    if (build_target(h, d_dst, n_dst, stride_bytes / 4)) {
+        if (!sharded(h)) return 1;
+        h->grid.valid = false;         // sharded: run_loam tells the other ranks and all of them fail together
+        h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_bytes / 4;
+    }
     if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
     h->clamp_allowed = true;           // this target exists for this scan only: a box that cannot be tabulated may be cut around it
     const int rc = run_loam(h, d_src, n_src, stride_bytes / 4, pose, converged, true);
@@ -1014,6 +1189,8 @@ void pcr_destroy(pcr_handle* h) {
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
     h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->timeline.release();
     if (h->result_host) (void)hipHostFree(h->result_host);
+    if (h->red_host) (void)hipHostFree(h->red_host);
+    h->ar_stage.release(); h->dummy_grid.release(); h->cov_viol.release();
     for (hipEvent_t e : h->ev_kernel) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_index) (void)hipEventDestroy(h->ev_index);
@@ -1048,20 +1225,14 @@ int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_b
     const size_t bytes = n_dst * stride_bytes;
     H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
     if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-    if (h->method == kVgicp) return vgicp_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
-    if (h->method == kNdt) return ndt_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
+    if (h->method == kVgicp) return agree_prepared(h, vgicp_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4));
+    if (h->method == kNdt) return agree_prepared(h, ndt_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4));
     h->clamp.use = 0;
-    if (build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4)) return 1;
     // settle the cell-table size now so that pcr_align never has to rebuild
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        GridHeader hdr;
-        H_TRY(hipMemcpyAsync(&hdr, h->grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
-        H_TRY(hipStreamSynchronize(h->stream));
-        int ov = check_grid_overflow(h, hdr.overflow, hdr.n_cells);
-        if (ov == 1) return 1;
-        if (ov == 0) return 0;
-    }
-    return fail(h, "target index could not be sized");
+    int rc = build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
+    if (!rc) rc = settle_loam_index(h, nullptr, 0, 0, nullptr);
+    if (rc) { h->have_target = false; h->grid.valid = false; }
+    return agree_prepared(h, rc);
 }
 
 int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, double pose_inout[16],
@@ -1225,12 +1396,15 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     a.corr_slot = h->corr_slot.as<uint32_t>(); a.corr_M = h->corr_M.as<double>();
     a.corr_slot_next = h->corr_slot2.as<uint32_t>(); a.corr_M_next = h->corr_M2.as<double>();
     a.partials = h->vg_partials.as<double>();
+    a.use_tile = h->use_tile; a.pad_ = 0;
+    for (int d = 0; d < 3; ++d) { a.tile_lo[d] = h->tile_lo[d]; a.tile_hi[d] = h->tile_hi[d]; }
     Pose16 T;
     memcpy(T.m, pose, sizeof T.m);
     H_TRY(vgicp_launch_linearize(a, T, h->out32_dev, h->stream));
     std::vector<uint32_t> slots(n_src);
     if (n_src) H_TRY(hipMemcpyAsync(slots.data(), h->corr_slot.p, n_src * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipStreamSynchronize(h->stream));
+    if (sharded(h) && ranks_allreduce(h, h->out32_host, 29)) return 1;
     int q = 0;
     for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[r * 6 + c] = H[c * 6 + r] = h->out32_host[q++]; }
     for (int r = 0; r < 6; ++r) b[r] = h->out32_host[21 + r];
@@ -1259,6 +1433,8 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)(stride_bytes / 4);
     r.a.hdr = h->grid.header.as<GridHeader>(); r.a.vox_slot = h->nd_slot.as<uint32_t>(); r.a.vox = h->nd_vox.as<NdtVoxel>();
     r.a.partials = h->nd_partials.as<double>();
+    r.a.use_tile = h->use_tile; r.a.pad_ = 0;
+    for (int d = 0; d < 3; ++d) { r.a.tile_lo[d] = h->tile_lo[d]; r.a.tile_hi[d] = h->tile_hi[d]; }
     const double res = (double)(float)h->prm.ndt_resolution;
     const double c1 = 10 * (1 - h->prm.ndt_outlier_ratio), c2 = h->prm.ndt_outlier_ratio / pow(res, 3), d3 = -log(c2);
     r.a.d1 = -log(c1 + c2) - d3;
@@ -1270,6 +1446,7 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     if (hess_d && n_src) {
         H_TRY(ndt_launch_hessian(r.a, r.T, r.ang, h->out48_dev, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
+        if (sharded(h) && ranks_allreduce(h, h->out48_host, 43)) return 1;
         for (int i = 0; i < 36; ++i) hess_d[i] = h->out48_host[7 + i];
     }
     return 0;
@@ -1337,9 +1514,111 @@ int pcr_set_stream(pcr_handle* h, void* hip_stream) {
 
 int pcr_set_query_tile(pcr_handle* h, const double lo[3], const double hi[3]) {
     if (!h) return 1;
-    if (!lo || !hi || lo[0] > hi[0]) { h->use_tile = 0; return 0; }
-    h->use_tile = 1;
+    h->err.clear();
+    if (!lo || !hi || lo[0] > hi[0]) { h->use_tile = 0; h->have_halo = false; return 0; }
+    // NDT and VGICP tiles must sit on the voxel lattice and come with a halo that is checked: pcr_set_shard
+    if (h->method != kLoam) return fail(h, "pcr_set_query_tile serves loam handles; ndt and vgicp tiles are set with pcr_set_shard (voxel-aligned bounds + halo)");
+    h->use_tile = 1; h->have_halo = false;
     for (int d = 0; d < 3; ++d) { h->tile_lo[d] = lo[d]; h->tile_hi[d] = hi[d]; }
+    return 0;
+}
+
+int pcr_set_shard(pcr_handle* h, const double lo[3], const double hi[3], double halo) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!lo || !hi || lo[0] > hi[0]) { h->use_tile = 0; h->have_halo = false; return 0; }
+    if (!(halo >= 0.0)) return fail(h, "halo must be >= 0");
+    for (int d = 0; d < 3; ++d) if (!(lo[d] < hi[d])) return fail(h, "tile bounds must satisfy lo < hi on every axis");
+    auto on_lattice = [](double v, double res, double shift) {      // v = (k + shift) * res for an integer k, or an open face
+        if (open_face(v)) return true;
+        const double k = v / res - shift;
+        return fabs(k - nearbyint(k)) <= 1e-9 * std::max(1.0, fabs(k));
+    };
+    auto pow2 = [](double r) { int e; return frexp(r, &e) == 0.5; };
+    if (h->method == kLoam) {
+        const double gate = sqrt(std::max(0.0, h->prm.loam_knn_max_sq));
+        if (halo < gate) return fail(h, "loam: the halo must cover the k-NN gate radius (" + std::to_string(gate) + " m, LoamRegister.cpp:59)");
+    } else if (h->method == kNdt) {
+        const double res = (double)(float)h->prm.ndt_resolution;
+        for (int d = 0; d < 3; ++d)
+            if (!on_lattice(lo[d], res, 0.0) || !on_lattice(hi[d], res, 0.0)) return fail(h, "ndt: tile bounds must be multiples of ndt_resolution (whole voxels per rank)");
+        const double need = (pow2(res) ? 1.0 : 2.0) * res;
+        if (halo < need * (1.0 - 1e-12)) return fail(h, "ndt: the halo must hold the DIRECT7 face voxels: >= " + std::to_string(need) + " m at this resolution");
+    } else {
+        const double res = h->prm.vgicp_resolution;
+        for (int d = 0; d < 3; ++d)
+            if (!on_lattice(lo[d], res, 0.5) || !on_lattice(hi[d], res, 0.5))
+                return fail(h, "vgicp: tile bounds must lie on the voxel lattice, (k + 0.5) * vgicp_resolution (fast_vgicp_voxel.hpp:158-160)");
+        if (halo < res) return fail(h, "vgicp: the halo must be at least one voxel (and hold every tile point's 20 nearest neighbours: checked per call)");
+    }
+    h->use_tile = 1; h->have_halo = true; h->halo = halo;
+    for (int d = 0; d < 3; ++d) { h->tile_lo[d] = lo[d]; h->tile_hi[d] = hi[d]; }
+    // a target prepared for another tile was checked against another halo
+    h->vg_target_ready = false;
+    return 0;
+}
+
+int pcr_comm_init_host(pcr_handle* h, pcr_allreduce_fn fn, void* user, int rank, int nranks) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!fn) { h->host_ar = nullptr; h->host_ar_user = nullptr; if (!h->comm) { h->nranks = 1; h->rank = 0; } return 0; }
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, "bad communicator arguments");
+    if (h->comm) return fail(h, "an RCCL communicator is already set on this handle");
+    h->host_ar = fn; h->host_ar_user = user; h->rank = rank; h->nranks = nranks;
+    return 0;
+}
+
+int pcr_get_params(const pcr_handle* h, pcr_params* out) {
+    if (!h || !out) return 1;
+    *out = h->prm;
+    return 0;
+}
+
+int pcr_set_params(pcr_handle* h, const pcr_params* p) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!p) return fail(h, "params is NULL");
+    if (p->struct_size != sizeof(pcr_params)) return fail(h, "pcr_params.struct_size mismatch (start from pcr_get_params or pcr_default_params)");
+    if (p->device >= 0 && p->device != h->device) return fail(h, "a handle cannot move to another device");
+    if (h->method == kVgicp && p->vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
+    const pcr_params old = h->prm;
+    h->prm = *p;
+    h->prm.device = old.device;
+    // whatever was derived from a parameter that changed is dropped; the optimiser settings are read at every call
+    if (p->loam_knn_max_sq != old.loam_knn_max_sq && h->method == kLoam) { h->have_target = false; h->grid.valid = false; }
+    if ((p->ndt_resolution != old.ndt_resolution || p->ndt_min_points != old.ndt_min_points) && h->method == kNdt) { h->nd_target_ready = false; h->have_target = false; h->grid.valid = false; }
+    if (p->vgicp_resolution != old.vgicp_resolution && h->method == kVgicp) { h->vg_target_ready = false; h->have_target = false; h->grid.valid = false; }
+    return 0;
+}
+
+int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, const double pose[16], double max_sq,
+                      double* score, int64_t* n_in) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!pose || !score) return fail(h, "pose or score is NULL");
+    if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (!h->have_target || !h->grid.valid) return fail(h, "no target: register a scan or call pcr_set_target first");
+    if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
+    const float* d_src = (const float*)src;
+    if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
+    if (ensure_out32(h)) return 1;
+    FitTile ft;
+    memset(&ft, 0, sizeof ft);
+    if (h->use_tile) {
+        ft.use = 1;
+        for (int d = 0; d < 3; ++d) { ft.lo[d] = h->tile_lo[d]; ft.hi[d] = h->tile_hi[d]; ft.ext_lo[d] = -1e300; ft.ext_hi[d] = 1e300; }
+        if (h->have_halo) shard_extent(h, ft.ext_lo, ft.ext_hi);
+    }
+    h->seq += 1.0;
+    H_TRY(fitness_launch(h->grid, d_src, n_src, stride_bytes / 4, pose, max_sq, h->vg_partials.as<double>(), h->out32_dev, h->stream, h->seq,
+                         h->use_tile ? &ft : nullptr));
+    if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
+    if (sharded(h) && ranks_allreduce(h, h->out32_host, 3)) return 1;
+    const double cnt = h->out32_host[1];
+    *score = cnt > 0 ? h->out32_host[0] / cnt : -1.0;      // align.cpp:56-59
+    if (n_in) *n_in = (int64_t)cnt;
+    if (h->use_tile && h->out32_host[2] > 0) return fail(h, "sharded fitness: a source point's nearest map point may lie beyond this rank's halo");
     return 0;
 }
 
@@ -1364,7 +1643,8 @@ int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks)
     memcpy(&id, unique_id128, sizeof(id));
     int rc = g_rccl.init_rank(&h->comm, nranks, id, rank);
     if (rc != 0) { h->comm = nullptr; return fail(h, "ncclCommInitRank failed with code " + std::to_string(rc)); }
-    h->nranks = nranks;
+    h->nranks = nranks; h->rank = rank;
+    h->host_ar = nullptr; h->host_ar_user = nullptr;
     return 0;
 }
 

@@ -104,13 +104,15 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         h.empty = 0; h.overflow = 0;
         h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0; h.sum_sq = 0.f;
         h.min_b[0] = h.min_b[1] = h.min_b[2] = 0;
-        h.clamped = (clamp.use && !pcl_mode) ? 1 : 0; h.pad_ = 0;
+        h.clamped = (clamp.use && !pcl_mode) ? 1 : 0; h.cut_mask = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
             float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
             if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
             if (h.clamped) {      // keep the part of the box inside the region of interest (points outside get no key)
+                if (lo < (float)clamp.lo[d]) h.cut_mask |= 1 << d;          // target points lie beyond this face: a query next to it
+                if (hi > (float)clamp.hi[d]) h.cut_mask |= 8 << d;          // would miss neighbours (loam.hip counts such queries)
                 lo = fmaxf(lo, (float)clamp.lo[d]); hi = fminf(hi, (float)clamp.hi[d]);
                 if (!(lo <= hi)) { h.empty = 1; lo = hi = 0.f; }
             }

@@ -600,7 +600,7 @@ template <int kChunk>
 __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h, const double* __restrict__ pose,
                                           float sx, float sy, float sz, bool valid, const NnCacheEntry& ce_in, bool have_entry,
                                           KnnShared& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how,
-                                          unsigned long long* tl) {
+                                          bool* escaped, unsigned long long* tl) {
     const double ox = (double)sx, oy = (double)sy, oz = (double)sz;
     // LoamRegister.cpp:126-130: Isometry3d * Vector4d in f64, then cast to f32
     const float px = (float)(pose[0] * ox + pose[4] * oy + pose[8] * oz + pose[12] * 1.0);
@@ -613,6 +613,16 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         const bool in_tile = qx >= a.tile_lo[0] && qx < a.tile_hi[0] && qy >= a.tile_lo[1] && qy < a.tile_hi[1] &&
                              qz >= a.tile_lo[2] && qz < a.tile_hi[2];
         if (!in_tile) { active = false; valid = false; }
+    }
+    *escaped = false;
+    if (h.clamped && active) {
+        // The index covers only part of the target (capi.hip, ClampBox).  A query whose 3x3x3 block touches cells beyond a
+        // cut face could miss neighbours there: it is counted, and the host redoes the call on a wider region.
+        const double fx = floor((qx - h.origin[0]) * h.inv_cell), fy = floor((qy - h.origin[1]) * h.inv_cell), fz = floor((qz - h.origin[2]) * h.inv_cell);
+        const int cm = h.cut_mask;
+        *escaped = ((cm & 1) && fx <= (double)kPad) || ((cm & 8) && fx >= (double)(h.dims[0] - kPad - 1)) ||
+                   ((cm & 2) && fy <= (double)kPad) || ((cm & 16) && fy >= (double)(h.dims[1] - kPad - 1)) ||
+                   ((cm & 4) && fz <= (double)kPad) || ((cm & 32) && fz >= (double)(h.dims[2] - kPad - 1));
     }
     Knn5 s;
     double A[5][3];
@@ -962,7 +972,9 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         int done = 0, conv = 0, fail = 0;
         double pose[16];
         for (int i = 0; i < 16; ++i) pose[i] = sh->pose[i];      // previous pose, staged below
-        if (n < 6.0) { done = 1; fail = 1; for (int r = 0; r < 6; ++r) x[r] = 0.0; }   // LoamRegister.cpp:173-176
+        if (a.reduced && sh_sum[kSlotRankFail] != 0.0) { done = 1; fail = 2; for (int r = 0; r < 6; ++r) x[r] = 0.0; }   // a rank has no index: every rank stops here
+        else if (sh_sum[kSlotEscapes] != 0.0) { done = 1; fail = 3; for (int r = 0; r < 6; ++r) x[r] = 0.0; }        // the clamped index was too small
+        else if (n < 6.0) { done = 1; fail = 1; for (int r = 0; r < 6; ++r) x[r] = 0.0; }   // LoamRegister.cpp:173-176
         else {
             const double np = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
             const double nr = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
@@ -1064,13 +1076,14 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         if (e >= 21 && e < 27) { er = e - 21; ec = 6; }
     }
     double acc = 0.0;
-    uint32_t n_hit = 0, n_search = 0;
+    uint32_t n_hit = 0, n_search = 0, n_esc = 0;
     for (uint32_t base = blk * 256; base < a.n_src; base += gridDim.x * 256) {
         const uint32_t q = base + tid;
         const bool valid = q < a.n_src;
         double row[7] = {0, 0, 0, 0, 0, 0, 0};
         uint32_t nn[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         int how = 0;
+        bool esc = false;
         float sx = pre_x, sy = pre_y, sz = pre_z;
         union { NnCacheEntry e; float4 v[8]; } ce;
         ce.e.flags = 0;
@@ -1092,7 +1105,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
                 if (use_cache) ce.e = a.nn_cache[q];
             }
         }
-        const int st = loam_point<kChunk>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, base == blk * 256 ? tl : nullptr);
+        const int st = loam_point<kChunk>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, &esc, base == blk * 256 ? tl : nullptr);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const size_t oi = (size_t)q;
             if (a.dbg_status) a.dbg_status[oi] = (int8_t)st;
@@ -1104,6 +1117,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         sh_rows[7 * kRowStride + tid] = st == 0 ? 1.0 : 0.0;
         __syncthreads();
         n_hit += (uint32_t)__popcll(__ballot(how == 1)); n_search += (uint32_t)__popcll(__ballot(how == 2));   // per wave
+        if (h.clamped) n_esc += (uint32_t)__popcll(__ballot(esc));
         if (e < 28) {
             const double* ra = sh_rows + er * kRowStride + ch * 32;
             const double* rb = sh_rows + ec * kRowStride + ch * 32;
@@ -1115,8 +1129,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
     if (tl) tl[5] = wall_clock64();
     sh_sum[ch * 32 + e] = e < 28 ? acc : 0.0;
     // statistics ride in the two spare components (exact small integers in f64)
-    __shared__ uint32_t sh_cnt[8];
-    if ((tid & 63) == 0) { sh_cnt[(tid >> 6) * 2] = n_hit; sh_cnt[(tid >> 6) * 2 + 1] = n_search; }
+    __shared__ uint32_t sh_cnt[12];
+    if ((tid & 63) == 0) { sh_cnt[(tid >> 6) * 2] = n_hit; sh_cnt[(tid >> 6) * 2 + 1] = n_search; sh_cnt[8 + (tid >> 6)] = n_esc; }
     __syncthreads();
     if (tid < 32) {
         double v = sh_sum[tid];
@@ -1124,6 +1138,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         for (int c = 1; c < 8; ++c) v += sh_sum[c * 32 + tid];
         if (tid == 28) v = (double)(sh_cnt[0] + sh_cnt[2] + sh_cnt[4] + sh_cnt[6]);
         if (tid == 29) v = (double)(sh_cnt[1] + sh_cnt[3] + sh_cnt[5] + sh_cnt[7]);
+        if (tid == kSlotEscapes) v = (double)(sh_cnt[8] + sh_cnt[9] + sh_cnt[10] + sh_cnt[11]);
         a.partials[((size_t)(k & 1) * kMaxPartials + blockIdx.x) * kAccum + tid] = v;
     }
     if (tl) tl[6] = wall_clock64();
@@ -1166,6 +1181,7 @@ __global__ __launch_bounds__(256) void loam_reduce_kernel(const LoamArgs a, cons
         double v = sh_sum[t];
 #pragma unroll
         for (int s = 1; s < 8; ++s) v += sh_sum[s * 32 + t];
+        if (t == kSlotRankFail) v = (a.rank_fail || a.grid.hdr->overflow) ? 1.0 : 0.0;
         out[t] = v;
     }
 }

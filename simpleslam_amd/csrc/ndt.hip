@@ -72,7 +72,7 @@ static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(
 // tenth of the cells of a lidar map qualify: with one thread per cell nearly every wave carried a few of them and ran
 // the whole eigen-decomposition path at ~10 % lane utilisation.
 __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_t* __restrict__ vox_slot, uint32_t* __restrict__ list,
-                                                             uint32_t* __restrict__ count, int min_points) {
+                                                             uint32_t* __restrict__ count, int min_points, uint32_t capacity) {
     __shared__ uint32_t sh_w[4];
     __shared__ uint32_t sh_base;
     const GridHeader h = *g.hdr;
@@ -106,17 +106,17 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
         __syncthreads();
         uint32_t pos = sh_base + off + inc - mine;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (cand[u]) list[pos++] = (uint32_t)(t0 + u);
+        for (int u = 0; u < 4; ++u) if (cand[u]) { if (pos < capacity) list[pos] = (uint32_t)(t0 + u); ++pos; }      // (capacity = points / min_points: never short)
         __syncthreads();                           // sh_w / sh_base are reused by the next step
     }
 }
 
 // Pass 2: one thread per listed cell
 __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                        uint32_t* __restrict__ vox_slot, NdtVoxel* __restrict__ vox, double eig_mult) {
+                                                        uint32_t* __restrict__ vox_slot, NdtVoxel* __restrict__ vox, double eig_mult, uint32_t capacity) {
     const GridHeader h = *g.hdr;
     if (h.overflow) return;
-    const uint32_t n_list = *count;
+    const uint32_t n_list = min(*count, capacity);
     for (uint32_t li = blockIdx.x * 256 + threadIdx.x; li < n_list; li += gridDim.x * 256) {
         const uint64_t t = list[li];
         const uint32_t s = g.cell_start[t], e = g.cell_start[t + 1];
@@ -220,6 +220,12 @@ __device__ __forceinline__ int ndt_neighbours(const GridHeader& h, const uint32_
     return n;
 }
 
+// sharded target (pcr_set_shard): a source point belongs to the rank whose tile holds its transformed position
+__device__ __forceinline__ bool ndt_in_tile(const NdtArgs& a, const float tp[3]) {
+    return (double)tp[0] >= a.tile_lo[0] && (double)tp[0] < a.tile_hi[0] && (double)tp[1] >= a.tile_lo[1] && (double)tp[1] < a.tile_hi[1] &&
+           (double)tp[2] >= a.tile_lo[2] && (double)tp[2] < a.tile_hi[2];
+}
+
 static constexpr int kNdtBlock = 128;
 static constexpr int kNdtStride = 130;
 static constexpr int kNdtComp = 43;    // score, gradient 6, Hessian 36
@@ -270,7 +276,8 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArg
 #pragma unroll
             for (int r = 0; r < 3; ++r) { float s = T.R[r * 3] * x4[0]; s += T.R[r * 3 + 1] * x4[1]; s += T.R[r * 3 + 2] * x4[2]; s += T.t[r]; tp[r] = s; }
             uint32_t slots[7];
-            const int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            if (a.use_tile && !ndt_in_tile(a, tp)) nn = 0;       // another rank's query
             if (nn > 0) {
                 // computePointDerivatives (float): :399-440
                 float pg[3][6];
@@ -359,7 +366,8 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a,
 #pragma unroll
             for (int r = 0; r < 3; ++r) { float s = T.R[r * 3] * xp[0]; s += T.R[r * 3 + 1] * xp[1]; s += T.R[r * 3 + 2] * xp[2]; s += T.t[r]; tp[r] = s; }
             uint32_t slots[7];
-            const int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            if (a.use_tile && !ndt_in_tile(a, tp)) nn = 0;
             if (nn > 0) {
                 const double x[3] = {(double)xp[0], (double)xp[1], (double)xp[2]};
                 double pg[3][6];
@@ -454,9 +462,9 @@ hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* 
     hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const int blocks = (int)std::min<size_t>(4096, grid.cell_capacity / 1024 + 1);
-    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, min_points);
+    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     const int vblocks = (int)std::min<size_t>(65535, list_capacity / 256 + 1);
-    hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult);
+    hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     return hipGetLastError();
 }
 

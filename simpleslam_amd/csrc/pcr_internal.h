@@ -39,7 +39,7 @@ struct GridHeader {
     float sum_sq;            // sum over the cells of count^2 (written by the scan): sum_sq / points = occupancy of the cell a
                              // point lives in, averaged over the points -- the density estimate behind the choice of a search cell
     int32_t clamped;         // the box was cut to a region of interest (ClampBox): points outside it are not indexed
-    int32_t pad_;
+    int32_t cut_mask;        // clamped: bit d = the lower face of axis d was cut (target points lie beyond it), bit 3 + d = the upper
 };
 
 // Region of interest for an index whose full bounding box cannot be tabulated (a far outlier in the cloud): see capi.hip
@@ -65,9 +65,13 @@ struct LoamState {
     int32_t converged;   // isConverge (PointCloudRegister.hpp:15)
     int32_t iters_run;   // linearisations whose result was consumed
     int32_t fail;        // 1: fewer than 6 accepted points (LoamRegister.cpp:173-176)
+                         // 2: sharded call, some rank could not index its tile (kSlotRankFail)
+                         // 3: a query came within one cell of a cut face of a clamped index (kSlotEscapes): the call is redone
 };
 
-static constexpr int kAccum = 32;        // 21 JtJ (upper) + 6 JtE + 1 count, padded
+static constexpr int kAccum = 32;        // 21 JtJ (upper) + 6 JtE + 1 count, padded; [28], [29] search statistics and
+static constexpr int kSlotRankFail = 30; //   sharded: > 0 when a rank's index is unusable (summed over the ranks by the exchange)
+static constexpr int kSlotEscapes = 31;  //   queries that left the region a clamped index covers
 static constexpr int kMaxPartials = 512; // linearisation blocks
 static constexpr int kTimelineSlots = 16; // s_memrealtime stamps per block and launch (pcr_get_timeline)
 
@@ -117,6 +121,7 @@ struct LoamArgs {
     // bit1: plane fit and everything after it, bit2: prologue solve.  Results are then meaningless.
     int32_t ablate;
     int32_t coresident;      // pcr_params.reserved[4] = 1: the two-waves-per-SIMD variant of the iterate kernel (loam.hip)
+    int32_t rank_fail;       // sharded: this rank has no usable index (its grid view is a dummy marked overflow); told to the others
     // profiling aid (pcr_params.reserved[3] = 1): [launch][block][kTimelineSlots] s_memrealtime stamps (100 MHz) taken by thread 0
     unsigned long long* timeline;
 };
@@ -168,17 +173,25 @@ struct VgicpArgs {
     uint32_t* corr_slot_next;    // the same two for the linearisation an LM trial pass computes ahead (vgicp_launch_error)
     double* corr_M_next;
     double* partials;            // [blocks][32]
+    int32_t use_tile, pad_;      // sharded target: only source points whose transformed position lies in [tile_lo, tile_hi)
+    double tile_lo[3], tile_hi[3];
 };
 
+// Halo check of a sharded target (pcr_set_shard): for every point inside [chk_lo, chk_hi) the 20th neighbour must be nearer
+// than the faces of [ext_lo, ext_hi) -- the region the rank's cloud is complete in; *violations counts the others.
+struct CovCheck { double chk_lo[3], chk_hi[3], ext_lo[3], ext_hi[3]; uint32_t* violations; };
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s);
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr);
 hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s);
 // (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
 // out32[28] = compute_error(T); out32[0..27] = the linearisation at T (correspondences into a.corr_*_next)
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
+// out32[0] = sum of the squared 1-NN distances <= max_range, [1] = their number, [2] = (tile given) source points whose nearest
+// neighbour could lie outside [ext_lo, ext_hi)
+struct FitTile { int32_t use, pad_; double lo[3], hi[3], ext_lo[3], ext_hi[3]; };
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
-                          double* d_partials, double* d_out32, hipStream_t s, double seq = 0.0);
+                          double* d_partials, double* d_out32, hipStream_t s, double seq = 0.0, const FitTile* tile = nullptr);
 uint32_t vgicp_blocks(uint32_t n_src);
 
 // pcl::VoxelGrid on the device (voxel_filter.hip); grid must have been built with pcl_mode = 1
@@ -205,6 +218,8 @@ struct NdtArgs {
     const NdtVoxel* vox;
     double d1, d2;           // gauss_d1_, gauss_d2_ (ndt_omp_impl.hpp:86-93)
     double* partials;        // [blocks][48]
+    int32_t use_tile, pad_;  // sharded target: only source points whose transformed position lies in [tile_lo, tile_hi)
+    double tile_lo[3], tile_hi[3];
 };
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_list, size_t list_capacity,
                              int min_points, double eig_mult, hipStream_t s);

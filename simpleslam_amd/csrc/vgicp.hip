@@ -12,6 +12,8 @@
 //         that pose in the same pass), fixed-order reductions
 //   V6 LM driver                  lsq_registration_impl.hpp:53-171 -> host code in capi.hip
 // Also the PCL fitness score (pcl::Registration::getFitnessScore, VgicpRegister.cpp:42-45).
+#include <string.h>
+
 #include "pcr_internal.h"
 #include "small_math.h"
 
@@ -222,7 +224,8 @@ __device__ inline void sym3_eig(const double A[6] /* xx xy xz yy yz zz */, doubl
 static constexpr int kCovK = 20;
 
 __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
-                                                        uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6) {
+                                                        uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6, const int use_check,
+                                                        const CovCheck chk) {
     const GridHeader h = *g.hdr;
     if (h.empty || h.overflow) return;
     GridLevels lv;
@@ -279,7 +282,22 @@ __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1,
         double* dst = cov6 + (size_t)__float_as_uint(q.w) * 6;
 #pragma unroll
         for (int e = 0; e < 6; ++e) dst[e] = out[e];
-        (void)found;
+        if (use_check) {
+            // sharded target: this rank holds every map point inside [ext_lo, ext_hi) only.  The neighbourhood of a point that
+            // can enter a voxel of the tile is the map's own iff its 20th neighbour is nearer than every face of that region.
+            const double qd[3] = {(double)q.x, (double)q.y, (double)q.z};
+            bool in = true;
+            double margin = 1e300;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                in = in && qd[d] >= chk.chk_lo[d] && qd[d] < chk.chk_hi[d];
+                margin = fmin(margin, fmin(qd[d] - chk.ext_lo[d], chk.ext_hi[d] - qd[d]));
+            }
+            if (in && margin < 1e29) {
+                const double r20 = found == kCovK ? sqrt((double)__uint_as_float((uint32_t)(L.k[kCovK - 1] >> 32))) * (1.0 + 1e-6) : 1e300;
+                if (!(r20 < margin)) atomicAdd(chk.violations, 1u);
+            }
+        }
     }
 }
 
@@ -365,7 +383,9 @@ __device__ __forceinline__ void vgicp_lin_point(const VgicpArgs& a, const GridHe
     double tp[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
-    const uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
+    uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
+    if (a.use_tile && !(tp[0] >= a.tile_lo[0] && tp[0] < a.tile_hi[0] && tp[1] >= a.tile_lo[1] && tp[1] < a.tile_hi[1] &&
+                        tp[2] >= a.tile_lo[2] && tp[2] < a.tile_hi[2])) slot = 0;      // sharded target: another rank's query
     slot_out[i] = slot;
     if (!slot) return;
     const VgicpVoxel vx = a.vox[slot - 1];
@@ -508,41 +528,60 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 struct PoseF16 { float m[16]; };
 
 __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* __restrict__ src, uint32_t n_src, uint32_t stride,
-                                                      const PoseF16 T, float max_range, double* __restrict__ partials) {
+                                                      const PoseF16 T, float max_range, double* __restrict__ partials, const FitTile tile) {
     __shared__ double sh[256];
     __shared__ double shc[256];
-    double acc = 0.0, cnt = 0.0;
+    __shared__ double shv[256];
+    double acc = 0.0, cnt = 0.0, viol = 0.0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_src; i += gridDim.x * 256) {
         const float* p = src + (size_t)i * stride;
         const float qx = T.m[0] * p[0] + T.m[4] * p[1] + T.m[8] * p[2] + T.m[12];
         const float qy = T.m[1] * p[0] + T.m[5] * p[1] + T.m[9] * p[2] + T.m[13];
         const float qz = T.m[2] * p[0] + T.m[6] * p[1] + T.m[10] * p[2] + T.m[14];
+        double margin = 1e300;
+        if (tile.use) {         // sharded target: the rank whose tile holds the transformed point scores it
+            const double qd[3] = {(double)qx, (double)qy, (double)qz};
+            bool in = true;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                in = in && qd[d] >= tile.lo[d] && qd[d] < tile.hi[d];
+                margin = fmin(margin, fmin(qd[d] - tile.ext_lo[d], tile.ext_hi[d] - qd[d]));
+            }
+            if (!in) continue;
+        }
         KeyList<1> L;
         ring_knn<1>(one_level(g), qx, qy, qz, max_range, L);
+        float d = 3.0e38f;
         if (L.k[0] != ~0ull) {
-            const float d = __uint_as_float((uint32_t)(L.k[0] >> 32));
+            d = __uint_as_float((uint32_t)(L.k[0] >> 32));
             if (d <= max_range) { acc += (double)d; cnt += 1.0; }
         }
+        // the nearest point of the rank's cloud is the map's nearest only if it is nearer than the faces of the region the
+        // cloud is complete in (or than the gate: farther points do not count anyway)
+        if (tile.use && margin < 1e29 && !(sqrt((double)d) * (1.0 + 1e-6) < margin) && !(sqrt((double)max_range) < margin)) viol += 1.0;
     }
-    sh[threadIdx.x] = acc; shc[threadIdx.x] = cnt;
+    sh[threadIdx.x] = acc; shc[threadIdx.x] = cnt; shv[threadIdx.x] = viol;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shc[threadIdx.x] += shc[threadIdx.x + s]; }
+        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shc[threadIdx.x] += shc[threadIdx.x + s]; shv[threadIdx.x] += shv[threadIdx.x + s]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        partials[(size_t)blockIdx.x * 32] = sh[0]; partials[(size_t)blockIdx.x * 32 + 1] = shc[0];
-        for (int k = 2; k < 32; ++k) partials[(size_t)blockIdx.x * 32 + k] = 0.0;
+        partials[(size_t)blockIdx.x * 32] = sh[0]; partials[(size_t)blockIdx.x * 32 + 1] = shc[0]; partials[(size_t)blockIdx.x * 32 + 2] = shv[0];
+        for (int k = 3; k < 32; ++k) partials[(size_t)blockIdx.x * 32 + k] = 0.0;
     }
 }
 
 // ---- host launchers ---------------------------------------------------------------
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s) {
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check) {
     const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
     const int levels = coarse1 ? (coarse2 ? 3 : 2) : 1;
+    CovCheck chk;
+    memset(&chk, 0, sizeof chk);
+    if (check) chk = *check;
     hipLaunchKernelGGL(vgicp_cov_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
-                       coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6);
+                       coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk);
     return hipGetLastError();
 }
 
@@ -573,12 +612,15 @@ hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out
 }
 
 hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_src, size_t stride_floats, const double pose[16], double max_range,
-                          double* d_partials, double* d_out32, hipStream_t s, double seq) {
+                          double* d_partials, double* d_out32, hipStream_t s, double seq, const FitTile* tile) {
     PoseF16 T;
     for (int i = 0; i < 16; ++i) T.m[i] = (float)pose[i];
     const uint32_t nb = vgicp_blocks((uint32_t)n_src);
     const float mr = max_range >= 3.0e38 ? 3.0e38f : (float)max_range;
-    hipLaunchKernelGGL(fitness_kernel, dim3(nb), dim3(256), 0, s, grid.view(), d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, mr, d_partials);
+    FitTile ft;
+    memset(&ft, 0, sizeof ft);
+    if (tile) ft = *tile;
+    hipLaunchKernelGGL(fitness_kernel, dim3(nb), dim3(256), 0, s, grid.view(), d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, mr, d_partials, ft);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, d_partials, nb, d_out32, seq);
     return hipGetLastError();
 }

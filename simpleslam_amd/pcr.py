@@ -41,6 +41,7 @@ class PcrStats(C.Structure):
     _fields_ = [
         ("total_ms", C.c_double), ("index_ms", C.c_double), ("solve_ms", C.c_double), ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_int32), ("iterations", C.c_int32), ("n_src", C.c_int64), ("n_dst", C.c_int64),
+        ("attempts", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -49,11 +50,16 @@ ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
+    "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices",
     "pcr_sc_default_params", "pcr_sc_create", "pcr_sc_destroy", "pcr_sc_last_error", "pcr_sc_size", "pcr_sc_add", "pcr_sc_descriptor", "pcr_sc_distance",
     "pcr_sc_query",
 ]
+
+# pcr_allreduce_fn (include/pcr_hip.h): int fn(double* inout, size_t count, int op, void* user)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_int, C.c_void_p)
+
 
 class ScParams(C.Structure):
     """struct pcr_sc_params (include/pcr_hip.h)."""
@@ -111,6 +117,11 @@ def load_library():
     L.pcr_set_query_tile.argtypes = [vp, dp, dp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.pcr_comm_init_host.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int, C.c_int]
+    L.pcr_set_shard.argtypes = [vp, dp, dp, C.c_double]
+    L.pcr_set_params.argtypes = [vp, C.POINTER(PcrParams)]
+    L.pcr_get_params.argtypes = [vp, C.POINTER(PcrParams)]
+    L.pcr_fitness_gated.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, C.c_double, dp, C.POINTER(C.c_int64)]
     L.pcr_map_create.argtypes = [C.c_int]
     L.pcr_map_create.restype = vp
     L.pcr_map_destroy.argtypes = [vp]
@@ -310,6 +321,40 @@ class PointCloudRegister:
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._check(self._lib.pcr_comm_init(self._h, C.cast(buf, C.c_void_p), rank, nranks))
 
+    def comm_init_host(self, fn, rank, nranks):
+        """The exchange of a sharded call through the caller's collective (pcr_comm_init_host): fn(ptr, count, op, user) -> 0,
+        combining `count` doubles in place over all ranks (op 0 = sum, 1 = max).  shard.ThreadCollective / shard.gloo_collective
+        provide one.  fn = None clears it."""
+        self._ar = ALLREDUCE_FN(fn) if fn is not None else ALLREDUCE_FN()      # kept alive with the handle
+        self._check(self._lib.pcr_comm_init_host(self._h, self._ar, None, rank, nranks))
+
+    def set_shard(self, lo, hi, halo):
+        """pcr_set_shard: this rank's tile [lo, hi) and the halo its target cloud carries (shard.tile_for_method)."""
+        lo = np.ascontiguousarray(lo, np.float64)
+        hi = np.ascontiguousarray(hi, np.float64)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.pcr_set_shard(self._h, lo.ctypes.data_as(dp), hi.ctypes.data_as(dp), float(halo)))
+
+    def set_params(self, **overrides):
+        """pcr_set_params on the live handle: change optimiser settings between calls (e.g. VgicpRegister.initForLC)."""
+        p = PcrParams()
+        self._check(self._lib.pcr_get_params(self._h, C.byref(p)))
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise AttributeError(f"pcr_params has no field {k!r}")
+            setattr(p, k, v)
+        self._check(self._lib.pcr_set_params(self._h, C.byref(p)))
+        self.params = p
+
+    def fitnessGated(self, src, pose, max_sq=1.0):
+        """getFitnessScore of the reference's test/align.cpp:29-61 against the handle's current target: mean of the squared
+        1-NN distances <= max_sq of the source transformed by `pose` (-1 when none) and the number of points counted."""
+        p, n, s, dev, _k = _cloud(src)
+        pc = _pose_in(pose)
+        score, cnt = C.c_double(0), C.c_int64(0)
+        self._check(self._lib.pcr_fitness_gated(self._h, p, n, s, dev, pc.ctypes.data_as(C.POINTER(C.c_double)), float(max_sq), C.byref(score), C.byref(cnt)))
+        return score.value, int(cnt.value)
+
     def _check(self, rc):
         if rc != 0:
             raise PcrError(self._lib.pcr_last_error(self._h).decode())
@@ -399,10 +444,10 @@ class VgicpRegister(PointCloudRegister):
     method = "vgicp"
 
     def initForLC(self):
-        """VgicpRegister::initForLC (VgicpRegister.cpp:21-28): loop-closure settings.  Must be called
-        before the first registration (parameters are fixed at pcr_create): use
-        VgicpRegister(vgicp_max_iters=100, vgicp_trans_eps=1e-6) instead."""
-        raise NotImplementedError("construct with vgicp_max_iters=100, vgicp_trans_eps=1e-6")
+        """VgicpRegister::initForLC (VgicpRegister.cpp:21-28) on the live object, as LoopClosureManager's constructor calls it
+        (backend/src/LoopClosureManager.cpp:21-22): 100 iterations, transformation epsilon 1e-6.  (Its
+        setMaxCorrespondenceDistance(150) only acts in the non-voxel GICP, fast_gicp_impl.hpp:18.)"""
+        self.set_params(vgicp_max_iters=100, vgicp_trans_eps=1e-6)
 
     def covariances(self, pts):
         """(n,3,3) per-point covariances (fast_gicp_impl.hpp:241-297)."""

@@ -158,3 +158,125 @@ def test_sharded_normal_equations_gloo_world_size_2():
     assert int(round(buf[42])) == full["n"]
     np.testing.assert_allclose(buf[:36].reshape(6, 6), full["JtJ"], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(buf[36:42], full["JtE"], rtol=1e-10, atol=1e-12)
+
+
+def _rot_xyz_f32(p6):
+    """Translation * Rx * Ry * Rz in float (ndt_omp_impl.hpp:146-149), as pcl::transformPointCloud applies it."""
+    from scipy.spatial.transform import Rotation as Rot
+    R = Rot.from_euler("XYZ", np.asarray(p6[3:], np.float64)).as_matrix().astype(np.float32)
+    return R, np.asarray(p6[:3], np.float32)
+
+
+def _ndt_vgicp_worker(rank, world_size, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    # ---- NDT: score + gradient + Hessian of computeDerivatives (43 values, ndt_omp_impl.hpp:206-285) ----
+    world, m = synth.make_map(60000, seed=11, spacing=0.2)
+    scan, T = synth.make_scan(world, 0, seed=11, beams=16, azimuths=256)
+    from scipy.spatial.transform import Rotation as Rot
+    p6 = np.concatenate([T[:3, 3] + [0.05, -0.03, 0.02], Rot.from_matrix(T[:3, :3]).as_euler("XYZ") + [0.002, -0.001, 0.004]])
+    tile = shard.tile_for_method(m, rank, world_size, "ndt", 1.0, halo=2.0)
+    R, t = _rot_xyz_f32(p6)
+    tp = (scan[:, :3] @ R.T + t).astype(np.float64)
+    mine = ((tp >= tile.lo) & (tp < tile.hi)).all(1)
+    d = oracle.ndt_derivatives(scan[mine], tile.points, p6)
+    buf = torch.from_numpy(np.concatenate([[d["score"]], d["grad"], d["hess"].ravel()]))
+    dist.all_reduce(buf)
+    # ---- VGICP: H, b, error of linearize (fast_vgicp_impl.hpp:119-180); tiles on the voxel lattice, covariances of the
+    #      tile's own cloud (the halo holds every 20-neighbourhood) ----
+    world2, m2 = synth.make_map(40000, seed=12)
+    scan2, T2 = synth.make_scan(world2, 0, seed=12, beams=16, azimuths=256)
+    pose = synth.perturb(T2, 12, trans=0.2, rot_deg=1.0)
+    tile2 = shard.tile_for_method(m2, rank, world_size, "vgicp", 1.0, halo=6.0)
+    tq = scan2[:, :3].astype(np.float64) @ pose[:3, :3].T + pose[:3, 3]
+    mine2 = ((tq >= tile2.lo) & (tq < tile2.hi)).all(1)
+    sc = oracle.vgicp_covariances(scan2, 20, 2)                 # source covariances come from the WHOLE scan on every rank
+    dc = oracle.vgicp_covariances(tile2.points, 20, 2)
+    v = oracle.vgicp_linearize(scan2[mine2], tile2.points, pose, sc[mine2], dc)
+    buf2 = torch.from_numpy(np.concatenate([v["H"].ravel(), v["b"], [v["err"], float(v["n"])]]))
+    dist.all_reduce(buf2)
+    if rank == 0:
+        q.put((buf.numpy().copy(), int(mine.sum()), buf2.numpy().copy(), int(mine2.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ndt_and_vgicp_sums_gloo_world_size_2():
+    """SURVEY 8(e) partition row for the other two methods, with the oracle standing in for the kernels: NDT tiles cut on voxel
+    faces + a voxel halo, VGICP tiles cut on the voxel lattice + a neighbourhood halo, every source point owned once, one
+    all-reduce of 43 doubles: the sums equal the single-process ones."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ndt_vgicp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    buf, n0, buf2, n02 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from scipy.spatial.transform import Rotation as Rot
+    world, m = synth.make_map(60000, seed=11, spacing=0.2)
+    scan, T = synth.make_scan(world, 0, seed=11, beams=16, azimuths=256)
+    p6 = np.concatenate([T[:3, 3] + [0.05, -0.03, 0.02], Rot.from_matrix(T[:3, :3]).as_euler("XYZ") + [0.002, -0.001, 0.004]])
+    full = oracle.ndt_derivatives(scan, m, p6)
+    assert 0 < n0 < scan.shape[0]
+    assert abs(buf[0] - full["score"]) <= 1e-9 * abs(full["score"]) and abs(full["score"]) > 1.0
+    np.testing.assert_allclose(buf[1:7], full["grad"], rtol=1e-9, atol=1e-9 * np.abs(full["grad"]).max())
+    np.testing.assert_allclose(buf[7:].reshape(6, 6), full["hess"], rtol=1e-9, atol=1e-9 * np.abs(full["hess"]).max())
+    world2, m2 = synth.make_map(40000, seed=12)
+    scan2, T2 = synth.make_scan(world2, 0, seed=12, beams=16, azimuths=256)
+    pose = synth.perturb(T2, 12, trans=0.2, rot_deg=1.0)
+    sc, dc = oracle.vgicp_covariances(scan2, 20, 4), oracle.vgicp_covariances(m2, 20, 4)
+    v = oracle.vgicp_linearize(scan2, m2, pose, sc, dc)
+    assert 0 < n02 < scan2.shape[0]
+    assert int(round(buf2[43])) == v["n"] and v["n"] > 500
+    np.testing.assert_allclose(buf2[:36].reshape(6, 6), v["H"], rtol=1e-10, atol=1e-10 * np.abs(v["H"]).max())
+    np.testing.assert_allclose(buf2[36:42], v["b"], rtol=1e-9, atol=1e-10 * np.abs(v["b"]).max())
+    np.testing.assert_allclose(buf2[42], v["err"], rtol=1e-10)
+
+
+def test_tiles_for_ndt_and_vgicp_sit_on_the_voxel_lattice():
+    _, m = synth.make_map(30000, seed=9)
+    for method, res, shift in (("ndt", 1.0, 0.0), ("ndt", 0.8, 0.0), ("vgicp", 0.5, 0.5), ("vgicp", 1.0, 0.5)):
+        tiles = [shard.tile_for_method(m, r, 4, method, res) for r in range(4)]
+        assert sum(t.n_core for t in tiles) == m.shape[0]
+        for t in tiles:
+            for v in (t.lo[t.axis], t.hi[t.axis]):
+                if abs(v) < 1e29:
+                    k = v / float(np.float32(res) if method == "ndt" else res) - shift
+                    assert abs(k - round(k)) < 1e-9
+            c = m[:, t.axis].astype(np.float64)
+            assert ((c >= t.lo[t.axis] - t.halo) & (c < t.hi[t.axis] + t.halo)).sum() == t.points.shape[0]
+        assert tiles[0].halo == ({"ndt": {1.0: 1.0, 0.8: 2 * float(np.float32(0.8))}, "vgicp": {0.5: 4.0, 1.0: 8.0}}[method][res])
+
+
+def test_thread_collective_sums_in_rank_order():
+    """The in-process collective the GPU suite shards over: same bits on every rank, fixed order of additions."""
+    import threading
+    n = 5
+    coll = shard.ThreadCollective(n)
+    vals = [np.array([0.1 * (r + 1), 1e16 if r == 2 else 1.0, float(r)]) for r in range(n)]
+    outs, mx = [None] * n, [None] * n
+
+    def work(r):
+        f = coll.fn(r)
+        a = vals[r].copy()
+        assert f(a.ctypes.data_as(C.POINTER(C.c_double)), 3, 0, None) == 0
+        outs[r] = a
+        b = vals[r].copy()
+        assert f(b.ctypes.data_as(C.POINTER(C.c_double)), 3, 1, None) == 0
+        mx[r] = b
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in th: t.start()
+    for t in th: t.join(30)
+    expect = vals[0].copy()
+    for r in range(1, n):
+        expect += vals[r]
+    for r in range(n):
+        np.testing.assert_array_equal(outs[r], expect)
+        np.testing.assert_array_equal(mx[r], np.max(vals, axis=0))

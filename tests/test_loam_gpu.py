@@ -513,3 +513,27 @@ def test_far_outlier_in_the_target(gpu, world_small):
         p2 = w["init"].copy()                                      # and the handle is as good as new on an ordinary target
         assert reg.scan2Map(w["scan"], w["map"], p2) == c0
         np.testing.assert_array_equal(p2, p0)
+
+
+def test_cut_index_is_widened_when_a_query_reaches_its_edge(gpu, world_small):
+    """The region a too-sparse target is cut to around the scan must never change the answer: the kernels count the queries
+    that come within a cell of a cut face and the call is redone on a wider region until none does.  With the first margin
+    set to -2.5 m (pcr_params.reserved[5], a test hook; default +10 m: the region then cuts INTO the scan's box) the first
+    attempts lose neighbours at the edge of the region and are thrown away; the pose that comes back is the one the full
+    index gives, bit for bit."""
+    from simpleslam_amd import pcr
+    w = world_small
+    m = w["map"].copy()
+    m[0, :3] = [1.0e6, -5.0e5, 1.0e5]
+    ref = w["init"].copy()
+    c_ref = LoamRegister().scan2Map(w["scan"], m, ref)             # default margin: nothing reaches the edge
+    prm = pcr.default_params()
+    prm.reserved[5] = -2500
+    reg = LoamRegister(params=prm)
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], m, p) == c_ref
+    assert reg.stats()["attempts"] >= 4                            # overflow -> cut at -2.5 m -> widened at least twice
+    np.testing.assert_array_equal(p, ref)
+    po, co, _ = oracle.loam_scan2map(w["scan"], m, w["init"])
+    dt, dr = synth.pose_error(p, po)
+    assert co == c_ref and dt < 1e-9 and dr < 1e-9

@@ -1,0 +1,324 @@
+"""The sharded scan2Map (BASELINE configs[3] and the NDT curve of configs[4]) END TO END with more than one rank,
+on one card: every rank is a handle of its own (own stream, own tile of the map + halo, one host thread), the exchange of
+the normal equations goes through pcr_comm_init_host -- threads of this process (shard.ThreadCollective) or two processes
+over gloo.  Between GPUs the same call sequence uses RCCL (pcr_comm_init); no box with more than one GPU was available, so
+that transport is covered by the one-rank communicator test in test_loam_gpu.py only.
+
+What must hold (reference loops: PCR/src/LoamRegister.cpp:112-217, ndt_omp_impl.hpp:206-285, fast_vgicp_impl.hpp:119-180):
+every rank returns the SAME pose bit for bit (they solve redundantly on identical sums); that pose equals the unsharded HIP
+pose up to the order of the additions (<= 1e-12; NDT / VGICP poses leave as Matrix4f: equal, or one float ulp) and the CPU
+oracle's within BASELINE's 1e-4."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from simpleslam_amd import LoamRegister, NdtRegister, VgicpRegister, make_register, pcr, shard, synth
+
+pytestmark = pytest.mark.gpu
+S = 20261003 + 4
+
+
+def run_ranks(method, n_ranks, scan, init, m, resolution=1.0, halo=None, maps=None, via="scan2Map", **kw):
+    """n_ranks handles on cuda:0, one host thread each.  -> (poses, converged flags, registers, errors)"""
+    import torch
+    coll = shard.ThreadCollective(n_ranks, timeout=300.0)
+    d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
+    regs, d_tiles, tiles = [], [], []
+    for r in range(n_ranks):
+        tile = shard.tile_for_method(m, r, n_ranks, method, resolution, halo)
+        if maps is not None:
+            tile.points = maps[r]
+        reg = make_register(method, **kw)
+        reg.set_shard(tile.lo, tile.hi, tile.halo)
+        reg.comm_init_host(coll.fn(r), r, n_ranks)
+        regs.append(reg); tiles.append(tile); d_tiles.append(torch.from_numpy(tile.points).cuda())
+    poses, convs, errs = [None] * n_ranks, [None] * n_ranks, [None] * n_ranks
+
+    def work(r):
+        pose = init.copy()
+        try:
+            if via == "scan2Map":
+                convs[r] = regs[r].scan2Map(d_scan, d_tiles[r], pose)
+            else:
+                regs[r].setTarget(d_tiles[r])
+                convs[r] = regs[r].align(d_scan, pose)
+            poses[r] = pose
+        except Exception as e:      # noqa: BLE001  (the test inspects it)
+            errs[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th: t.start()
+    for t in th: t.join(600)
+    assert not any(t.is_alive() for t in th), "a rank hangs"
+    return poses, convs, regs, errs, tiles
+
+
+def _all_equal(poses):
+    for p in poses[1:]:
+        np.testing.assert_array_equal(p, poses[0])
+
+
+@pytest.fixture(scope="module")
+def w1m():
+    world, m = synth.make_map(1_000_000, seed=S)
+    scan, T = synth.make_scan(world, 0, seed=S)
+    return dict(map=m, scan=scan, truth=T, init=synth.perturb(T, S))
+
+
+@pytest.mark.parametrize("n_ranks", [2, 8])
+def test_loam_sharded_equals_unsharded(gpu, w1m, n_ranks):
+    w = w1m
+    kw = dict(loam_iters=10, loam_early_exit=0)
+    poses, convs, regs, errs, tiles = run_ranks("loam", n_ranks, w["scan"], w["init"], w["map"], **kw)
+    assert errs == [None] * n_ranks, errs
+    _all_equal(poses)
+    assert len(set(convs)) == 1
+    ref = w["init"].copy()
+    c_ref = LoamRegister(**kw).scan2Map(w["scan"], w["map"], ref)
+    assert convs[0] == c_ref
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 1e-12 and dr <= 1e-12, (dt, dr)
+    po, _, _ = oracle.loam_scan2map(w["scan"], w["map"], w["init"], oracle.loam_params(iters=10, early_exit=0, threads=8))
+    dt, dr = synth.pose_error(poses[0], po)
+    assert dt <= 1e-4 and dr <= 1e-4
+    # a tile is what it says: core points balanced, every rank indexed less than the whole map
+    assert max(t.points.shape[0] for t in tiles) < 0.75 * w["map"].shape[0]
+
+
+def test_loam_sharded_reference_defaults_and_static_target(gpu, w1m):
+    """8 iterations + early exit (LoamRegister.hpp:37-40): the converged flag and the iteration count come out of the same
+    redundantly solved system on every rank; and the prepared-target entry points (pcr_set_target + pcr_align) shard the same way."""
+    w = w1m
+    ref = w["init"].copy()
+    r0 = LoamRegister()
+    c_ref = r0.scan2Map(w["scan"], w["map"], ref)
+    for via in ("scan2Map", "align"):
+        poses, convs, regs, errs, _ = run_ranks("loam", 4, w["scan"], w["init"], w["map"], via=via)
+        assert errs == [None] * 4, errs
+        _all_equal(poses)
+        assert convs == [c_ref] * 4
+        assert [r.stats()["iterations"] for r in regs] == [r0.stats()["iterations"]] * 4
+        dt, dr = synth.pose_error(poses[0], ref)
+        assert dt <= 1e-12 and dr <= 1e-12
+
+
+def test_config4_ten_iterations_on_a_10m_map_sharded_over_eight_ranks(gpu):
+    """BASELINE configs[3] as stated -- pcr=loam, 10 M-point sub-map, 8 ranks, all-reduce of JtJ/JtE per iteration -- end to end."""
+    world, m = synth.make_map(10_000_000, seed=S + 2)
+    scan, T = synth.make_scan(world, 0, seed=S + 2)
+    init = synth.perturb(T, S + 2)
+    kw = dict(loam_iters=10, loam_early_exit=0)
+    poses, convs, regs, errs, tiles = run_ranks("loam", 8, scan, init, m, **kw)
+    assert errs == [None] * 8, errs
+    _all_equal(poses)
+    assert max(t.points.shape[0] for t in tiles) < 1.35 * 10_000_000 / 8
+    ref = init.copy()
+    LoamRegister(**kw).scan2Map(scan, m, ref)
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 1e-12 and dr <= 1e-12, (dt, dr)
+    po, _, _ = oracle.loam_scan2map(scan, m, init, oracle.loam_params(iters=10, early_exit=0, threads=16))
+    dt, dr = synth.pose_error(poses[0], po)
+    assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    et, er = synth.pose_error(poses[0], T)
+    assert et < 0.02 and er < 2e-3
+
+
+def test_unequal_tiles_one_rank_regrows_its_cell_table(gpu):
+    """Quantile-cut slabs of a map of uneven density have unequal boxes: here one tile fits the first-guess cell table
+    (2^20 cells) and the other needs three times that.  The rank that must grow and rebuild does so BEFORE the first exchange;
+    every rank runs the same number of collectives and none is left waiting (round-1 advisor finding)."""
+    world, m = synth.make_map(1_000_000, seed=S)
+    scan, T = synth.make_scan(world, 0, seed=S)
+    init = synth.perturb(T, S)
+    x = m[:, 0]
+    x0 = x.min() + 0.2 * (x.max() - x.min())
+    rng = np.random.default_rng(7)
+    keep = (x < x0) | (rng.random(m.shape[0]) < 0.12)
+    m2 = np.ascontiguousarray(m[keep])
+    poses, convs, regs, errs, tiles = run_ranks("loam", 2, scan, init, m2)
+    assert errs == [None, None], errs
+
+    def cells(t):
+        f = np.isfinite(t.points[:, :3]).all(1)
+        ext = np.floor(t.points[f, :3].max(0)) - np.floor(t.points[f, :3].min(0)) + 5
+        return float(np.prod(ext))
+    nc = sorted(cells(t) for t in tiles)
+    assert nc[0] < 2 ** 20 < nc[1], nc                      # exactly the situation described above
+    _all_equal(poses)
+    ref = init.copy()
+    c_ref = LoamRegister().scan2Map(scan, m2, ref)
+    assert convs == [c_ref, c_ref]
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 1e-12 and dr <= 1e-12
+
+
+@pytest.fixture(scope="module")
+def nd_w():
+    world, m = synth.make_map(1_000_000, seed=S + 5, spacing=0.22)
+    scan, T = synth.make_scan(world, 0, seed=S + 5, beams=64, azimuths=1024)
+    return dict(map=m, scan=scan, truth=T, init=synth.perturb(T, S + 5, trans=0.1, rot_deg=0.5))
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_ndt_sharded_equals_unsharded(gpu, nd_w, n_ranks):
+    w = nd_w
+    poses, convs, regs, errs, tiles = run_ranks("ndt", n_ranks, w["scan"], w["init"], w["map"], resolution=1.0)
+    assert errs == [None] * n_ranks, errs
+    _all_equal(poses)
+    r0 = NdtRegister()
+    ref = w["init"].copy()
+    c_ref = r0.scan2Map(w["scan"], w["map"], ref)
+    assert convs == [c_ref] * n_ranks
+    assert [r.stats()["iterations"] for r in regs] == [r0.stats()["iterations"]] * n_ranks
+    # the pose leaves as a Matrix4f (NdtRegister.cpp:28): identical, or one float ulp where the other order of the sums tipped a rounding
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 2e-6 and dr <= 2e-7, (dt, dr)
+    po, co, info = oracle.ndt_scan2map(w["scan"], w["map"], w["init"], oracle.ndt_params())
+    assert co == convs[0] and info["iterations"] == r0.stats()["iterations"]
+    dt, dr = synth.pose_error(poses[0], po)
+    assert dt <= 1e-4 and dr <= 1e-4
+    assert max(t.points.shape[0] for t in tiles) < 0.75 * w["map"].shape[0]
+
+
+@pytest.fixture(scope="module")
+def vg_w():
+    world, m = synth.make_map(400_000, seed=S + 6)
+    scan, T = synth.make_scan(world, 0, seed=S + 6)
+    return dict(map=m, scan=scan, truth=T, init=synth.perturb(T, S + 6, trans=0.3, rot_deg=2.0))
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_vgicp_sharded_equals_unsharded(gpu, vg_w, n_ranks):
+    w = vg_w
+    kw = dict(vgicp_resolution=0.5)
+    poses, convs, regs, errs, tiles = run_ranks("vgicp", n_ranks, w["scan"], w["init"], w["map"], resolution=0.5, **kw)
+    assert errs == [None] * n_ranks, errs
+    _all_equal(poses)
+    r0 = VgicpRegister(**kw)
+    ref = w["init"].copy()
+    c_ref = r0.scan2Map(w["scan"], w["map"], ref)
+    assert convs == [c_ref] * n_ranks
+    assert [r.stats()["iterations"] for r in regs] == [r0.stats()["iterations"]] * n_ranks
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 2e-6 and dr <= 2e-7, (dt, dr)                  # Matrix4f result (VgicpRegister.cpp:37)
+    # the fitness score (VgicpRegister.cpp:42-45) is a sum over the ranks' shares of the scan too
+    f = [r.getFitnessScore() for r in regs]
+    assert len(set(f)) == 1 and abs(f[0] - r0.getFitnessScore()) <= 1e-9 * r0.getFitnessScore()
+    po, co, _ = oracle.vgicp_scan2map(w["scan"], w["map"], w["init"], oracle.vgicp_params(resolution=0.5, threads=16))
+    assert co == convs[0]
+    dt, dr = synth.pose_error(poses[0], po)
+    assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_vgicp_halo_too_small_fails_on_every_rank(gpu, vg_w):
+    """A halo that does not hold the 20 nearest neighbours of the tile's points would change their covariances
+    (fast_gicp_impl.hpp:253): the device check finds them, and ALL ranks fail the call together (none is left in a collective)."""
+    w = vg_w
+    poses, convs, regs, errs, _ = run_ranks("vgicp", 2, w["scan"], w["init"], w["map"], resolution=0.5, halo=0.5, vgicp_resolution=0.5)
+    assert all(isinstance(e, pcr.PcrError) for e in errs), errs
+    assert any("halo" in str(e) for e in errs)
+    assert any("another rank" in str(e) or "halo" in str(e) for e in errs)
+
+
+def test_a_rank_without_a_usable_target_stops_all_ranks(gpu, w1m):
+    """One rank's tile cannot be indexed (a stray point 1e7 m away: its box needs more cells than the dense table of the
+    VGICP voxel lattice can hold).  The others learn it from the status exchange before the first linearisation and return an
+    error instead of waiting for a peer that has left."""
+    w = w1m
+    n = 3
+    stray = np.array([[1.0e7, -1.0e7, 3.0e6, 0.0]], np.float32)
+
+    def maps_for(method, res):
+        out = []
+        for r in range(n):
+            pts = shard.tile_for_method(w["map"], r, n, method, res).points
+            out.append(np.ascontiguousarray(np.vstack([pts, stray]) if r == 1 else pts))
+        return out
+    poses, convs, regs, errs, _ = run_ranks("vgicp", n, w["scan"], w["init"], w["map"], resolution=0.5, maps=maps_for("vgicp", 0.5), vgicp_resolution=0.5)
+    assert all(isinstance(e, pcr.PcrError) for e in errs), errs
+    assert "another rank" in str(errs[0]) and "another rank" in str(errs[2])
+    assert "another rank" not in str(errs[1])
+    # the LOAM prepared-target path (pcr_set_target has no scan to cut the box around) agrees the same way
+    poses, convs, regs, errs, _ = run_ranks("loam", n, w["scan"], w["init"], w["map"], maps=maps_for("loam", 1.0), via="align")
+    assert all(isinstance(e, pcr.PcrError) for e in errs), errs
+    assert "another rank" in str(errs[0]) and "another rank" not in str(errs[1])
+    # whereas scan2Map cuts that rank's box around the scan and succeeds everywhere
+    poses, convs, regs, errs, _ = run_ranks("loam", n, w["scan"], w["init"], w["map"], maps=maps_for("loam", 1.0))
+    assert errs == [None] * n, errs
+    _all_equal(poses)
+    ref = w["init"].copy()
+    LoamRegister().scan2Map(w["scan"], w["map"], ref)
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 1e-12 and dr <= 1e-12
+
+
+def test_shard_bounds_are_validated(gpu):
+    big = shard.BIG
+    lo, hi = np.array([-big, -big, -big]), np.array([big, big, big])
+    nd = NdtRegister()
+    with pytest.raises(pcr.PcrError, match="multiples of ndt_resolution"):
+        nd.set_shard(np.array([0.3, -big, -big]), hi, 1.0)
+    with pytest.raises(pcr.PcrError, match="halo"):
+        nd.set_shard(np.array([2.0, -big, -big]), hi, 0.5)
+    nd.set_shard(np.array([2.0, -big, -big]), hi, 1.0)
+    with pytest.raises(pcr.PcrError, match="pcr_set_shard"):
+        nd.set_query_tile(lo, hi)
+    vg = VgicpRegister(vgicp_resolution=0.5)
+    with pytest.raises(pcr.PcrError, match="voxel lattice"):
+        vg.set_shard(np.array([1.0, -big, -big]), hi, 2.0)
+    vg.set_shard(np.array([1.25, -big, -big]), hi, 2.0)
+    lm = LoamRegister()
+    with pytest.raises(pcr.PcrError, match="gate radius"):
+        lm.set_shard(lo, hi, 0.5)
+    lm.set_shard(lo, hi, 1.0)
+
+
+def _proc_worker(rank, world_size, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world, m = synth.make_map(300_000, seed=S + 8)
+    scan, T = synth.make_scan(world, 0, seed=S + 8)
+    init = synth.perturb(T, S + 8)
+    out = {}
+    for method, kw, res in (("loam", dict(loam_iters=10, loam_early_exit=0), 1.0), ("vgicp", dict(vgicp_resolution=0.5), 0.5)):
+        tile = shard.tile_for_method(m, rank, world_size, method, res)
+        reg = make_register(method, **kw)
+        reg.set_shard(tile.lo, tile.hi, tile.halo)
+        reg.comm_init_host(shard.gloo_collective(), rank, world_size)
+        pose = init.copy()
+        conv = reg.scan2Map(torch.from_numpy(scan).cuda(), torch.from_numpy(tile.points).cuda(), pose)
+        out[method] = (pose, conv)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_over_gloo(gpu):
+    """One process per rank, as on a multi-GPU node (here both on the one card), the exchange on torch.distributed/gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_proc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    world, m = synth.make_map(300_000, seed=S + 8)
+    scan, T = synth.make_scan(world, 0, seed=S + 8)
+    init = synth.perturb(T, S + 8)
+    for method, kw, tol in (("loam", dict(loam_iters=10, loam_early_exit=0), 1e-12), ("vgicp", dict(vgicp_resolution=0.5), 2e-6)):
+        np.testing.assert_array_equal(got[0][method][0], got[1][method][0])
+        ref = init.copy()
+        c = make_register(method, **kw).scan2Map(scan, m, ref)
+        assert got[0][method][1] == c
+        dt, dr = synth.pose_error(got[0][method][0], ref)
+        assert dt <= tol and dr <= tol, (method, dt, dr)
