@@ -111,9 +111,25 @@ def test_loop_closure_flow(gpu, keyframes):
     sm.loopFindNearKeyframes(key, rng, grid_size=0.4)
     scan, T_true = kfs[key]
     guess = synth.perturb(T_true, 7, trans=0.3, rot_deg=1.5)
-    lc = VgicpRegister(vgicp_max_iters=100, vgicp_trans_eps=1e-6)          # initForLC (VgicpRegister.cpp:21-28)
+    # the reference's call sequence: a constructed registrar is switched to the loop-closure settings (LoopClosureManager.cpp:21-22)
+    # and then registers (:98) -- same answer as a handle created with those settings
+    lc = VgicpRegister()
+    lc.initForLC()                                                         # VgicpRegister.cpp:21-28 on the live object
+    assert (lc.params.vgicp_max_iters, lc.params.vgicp_trans_eps) == (100, 1e-6)
     pose = guess.copy()
     conv = lc.scan2MapSubmap(scan, sm, pose)
+    born = VgicpRegister(vgicp_max_iters=100, vgicp_trans_eps=1e-6)
+    pose_b = guess.copy()
+    assert born.scan2MapSubmap(scan, sm, pose_b) == conv
+    np.testing.assert_array_equal(pose, pose_b)
+    # and a handle that has already registered with the odometry settings can be switched too (the prepared target survives)
+    lc2 = VgicpRegister()
+    tmp = guess.copy()
+    lc2.scan2MapSubmap(scan, sm, tmp)
+    lc2.initForLC()
+    pose_c = guess.copy()
+    assert lc2.scan2MapSubmap(scan, sm, pose_c) == conv
+    np.testing.assert_array_equal(pose, pose_c)
     fs = lc.getFitnessScore()
     et, er = synth.pose_error(pose, T_true)
     assert conv and et < 0.05 and er < 5e-3

@@ -137,3 +137,25 @@ def test_edge_cases_match_oracle(gpu, vg_world):
         if np.isfinite(po).all():
             dt, dr = synth.pose_error(pose, po)
             assert dt <= 1e-4 and dr <= 1e-4, (name, dt, dr)
+
+
+def test_gated_fitness_of_align_cpp(gpu, vg_world):
+    """test/align.cpp:29-61: mean squared 1-NN distance over the source points within 1 m of the target (float distances,
+    transform in float), -1 when none -- for every method's handle, against the target of its last registration."""
+    from simpleslam_amd import LoamRegister, NdtRegister
+    w = vg_world
+    T, gate = w["init"], 0.02                                     # 0.3 m / 2 deg off: part of the scan is farther than the gate
+    want = oracle.fitness_score(w["scan"], w["map"], T, gate)
+    src_t = (w["scan"][:, :3] @ T[:3, :3].astype(np.float32).T + T[:3, 3].astype(np.float32)).astype(np.float32)
+    _, d2 = oracle.knn_f32(w["map"], src_t, 1)
+    n_want = int((d2[:, 0] <= np.float32(gate)).sum())
+    assert 0 < n_want < w["scan"].shape[0]                      # the gate does cut something off
+    for make in (lambda: VgicpRegister(), lambda: LoamRegister(), lambda: NdtRegister()):
+        reg = make()
+        pose = w["init"].copy()
+        reg.scan2Map(w["scan"], w["map"], pose)                  # align.cpp:144 ... then :150 scores against the same target
+        got, n_in = reg.fitnessGated(w["scan"], T, gate)
+        assert n_in == n_want
+        np.testing.assert_allclose(got, want, rtol=1e-6)
+        far = np.eye(4); far[:3, 3] = [0.0, 0.0, 500.0]
+        assert reg.fitnessGated(w["scan"], far, 1.0) == (-1.0, 0)
