@@ -206,7 +206,7 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
     a->result = h->result_dev;
     a->ablate = h->prm.reserved[0];
     a->coresident = h->prm.reserved[4] == 1;
-    if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 128) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
+    if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 192) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
     if (h->prm.reserved[3] == 1 && h->timeline.reserve((size_t)(std::max(1, h->prm.loam_iters) + 1) * kMaxPartials * kTimelineSlots * sizeof(unsigned long long)) == hipSuccess)
         a->timeline = h->timeline.as<unsigned long long>();
     a->use_tile = h->use_tile;

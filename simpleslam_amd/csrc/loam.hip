@@ -34,13 +34,23 @@ static constexpr bool kAblation = false;
 #endif
 
 
+
 // ------------------------------------------------------------------------------
-// per-lane exact 5-NN on the grid
+// exact nearest neighbours on the grid
+//
+// The reference asks nanoflann for the 5 nearest map points of every scan point (LoamRegister.cpp:47-72).  Here a search
+// keeps the kNb = 8 nearest: five feed the plane fit, the other three are what lets the temporal-coherence cache below
+// survive a Gauss-Newton step (on a voxel-filtered map the 5th and 6th neighbour are often a few millimetres apart -- the
+// 5th and the 9th are a lattice shell apart).
 // ------------------------------------------------------------------------------
-struct Knn5 {
-    double d[5];
-    uint32_t idx[5];   // original target index (filled once the search is over)
-    uint32_t pos[5];   // position in the cell-sorted array; 0xffffffff = empty slot (sentinel)
+static constexpr int kNb = 8;
+static constexpr uint32_t kNoPos = 0xffffffffu;
+static constexpr uint32_t kKeyEmpty = 0xffffffffu;
+
+struct Nb8 {                 // the neighbours of one query in (distance, original index) order
+    double d[kNb];           // exact squared distance, nanoflann's accumulation order; +inf: empty slot
+    uint32_t idx[kNb];       // original target index; 0xffffffff: empty
+    float x[kNb], y[kNb], z[kNb];
 };
 
 // (d, idx) lexicographic order, branch-free: distance ties are broken on the original index
@@ -48,320 +58,289 @@ __device__ __forceinline__ bool knn_less(double d, uint32_t i, double d2, uint32
     return (d < d2) | ((d == d2) & (i < i2));
 }
 
-// Hot-path insertion: a branch-free bubble pass through the sorted list, ordered by distance alone (one
-// v_min/v_max/v_cmp and two selects per slot).  The value that falls off the end -- the candidate itself when
-// it does not belong -- is returned: it bounds the "6th neighbour" from below.  Exact distance ties, which
-// need the original-index tie-break, are detected after the search and redone by knn5_resolve_ties.
-// (Written as min/max dataflow on purpose: hipcc turns nested ?: chains here into ~16 divergent branches.)
-__device__ __forceinline__ void knn_bubble(Knn5& s, double& t, uint32_t& tpos) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const bool lt = t < s.d[k];
-        const double lo = fmin(s.d[k], t), hi = fmax(s.d[k], t);
-        const uint32_t plo = lt ? tpos : s.pos[k], phi = lt ? s.pos[k] : tpos;
-        s.d[k] = lo; s.pos[k] = plo;
-        t = hi; tpos = phi;
-    }
+// nanoflann L2_Simple_Adaptor::evalMetric order (nanoflann.hpp:523-535), double distances on float coordinates
+__device__ __forceinline__ double sqdist(double qx, double qy, double qz, float px, float py, float pz) {
+    const double dx = qx - (double)px, dy = qy - (double)py, dz = qz - (double)pz;
+    double d = dx * dx;
+    d += dy * dy;
+    d += dz * dz;
+    return d;
 }
 
-// Per-block LDS scratch of the search: the 9 row ranges of every lane.
-struct KnnShared {
-    uint32_t rs[9][256];
-    uint32_t re[9][256];
+// 19-comparator sorting network on (distance, index) with the coordinates as payload
+__device__ __forceinline__ void nb8_sort(Nb8& s) {
+#define CSWAP(i, j) { const bool sw = knn_less(s.d[j], s.idx[j], s.d[i], s.idx[i]); \
+        const double di = s.d[i], dj = s.d[j]; s.d[i] = sw ? dj : di; s.d[j] = sw ? di : dj; \
+        const uint32_t ii = s.idx[i], ij = s.idx[j]; s.idx[i] = sw ? ij : ii; s.idx[j] = sw ? ii : ij; \
+        const float xi = s.x[i], xj = s.x[j]; s.x[i] = sw ? xj : xi; s.x[j] = sw ? xi : xj; \
+        const float yi = s.y[i], yj = s.y[j]; s.y[i] = sw ? yj : yi; s.y[j] = sw ? yi : yj; \
+        const float zi = s.z[i], zj = s.z[j]; s.z[i] = sw ? zj : zi; s.z[j] = sw ? zi : zj; }
+    CSWAP(0, 1) CSWAP(2, 3) CSWAP(4, 5) CSWAP(6, 7) CSWAP(0, 2) CSWAP(1, 3) CSWAP(4, 6) CSWAP(5, 7) CSWAP(1, 2) CSWAP(5, 6)
+    CSWAP(0, 4) CSWAP(3, 7) CSWAP(1, 5) CSWAP(2, 6) CSWAP(1, 4) CSWAP(3, 6) CSWAP(2, 4) CSWAP(3, 5) CSWAP(3, 4)
+#undef CSWAP
+}
+
+__device__ __forceinline__ void nb8_set(Nb8& s, int j, const float4 p, bool real, double qx, double qy, double qz) {
+    const float inf = __uint_as_float(0x7f800000u);
+    s.x[j] = real ? p.x : inf; s.y[j] = real ? p.y : inf; s.z[j] = real ? p.z : inf;
+    s.idx[j] = real ? __float_as_uint(p.w) : 0xffffffffu;
+    const double d = sqdist(qx, qy, qz, p.x, p.y, p.z);
+    s.d[j] = (real && d == d) ? d : __longlong_as_double(0x7ff0000000000000ll);
+}
+
+// Per-block LDS scratch of the search: the non-empty row runs {start, end} of every lane's 3x3x3 block, compacted;
+// entry 9 (and every entry past a lane's last run) is {0, 0}.
+struct KnnRuns {
+    uint2 run[10][256];
 };
 
-// Rows of the 3x3 (y,z) neighbourhood in the order centre, faces, corners, so that the lower
-// bound on a row's distance prunes late rows.  4-bit code per row: (dy+1) | (dz+1) << 2.
+// Rows of the 3x3 (y,z) neighbourhood, centre first.  4-bit code per row: (dy+1) | (dz+1) << 2.
 static constexpr unsigned long long kRowOrder = 0xA82091645ull;
 __device__ __forceinline__ constexpr int row_dy(int r) { return (int)((kRowOrder >> (4 * r)) & 3) - 1; }
 __device__ __forceinline__ constexpr int row_dz(int r) { return (int)((kRowOrder >> (4 * r + 2)) & 3) - 1; }
 
-struct KnnQuery {
-    double qx, qy, qz;          // query (a float widened to double)
-    double ylo, yhi, zlo, zhi;  // distance to the faces of the query's cell
-    double l6;                  // lower bound of the squared distance of every point NOT in the top 5
-    int ablate;                 // profiling aid: bit4 skip candidates (loads only), bit5 skip insertion
-};
-
-__device__ __forceinline__ double row_bound(const KnnQuery& q, int r) {
-    const unsigned code = (unsigned)((kRowOrder >> (4 * r)) & 15);
-    const int dy = (int)(code & 3) - 1, dz = (int)(code >> 2) - 1;
-    const double gy = dy < 0 ? q.ylo : (dy > 0 ? q.yhi : 0.0);
-    const double gz = dz < 0 ? q.zlo : (dz > 0 ? q.zhi : 0.0);
-    // every point of the row is at least sqrt(gy^2+gz^2) away (same rounding order as d below)
-    return gy * gy + gz * gz;
-}
-
-// One candidate.  No single-precision pre-screen: with 64 independent searches in lockstep some
-// lane nearly always needs the exact distance, so the screen would only add instructions.
-__device__ __forceinline__ void knn_consider(Knn5& s, KnnQuery& q, const float4 p, uint32_t pos, bool valid) {
-    const double dx = q.qx - (double)p.x, dy = q.qy - (double)p.y, dz = q.qz - (double)p.z;
-    double d = dx * dx;      // nanoflann L2_Simple_Adaptor::evalMetric order (nanoflann.hpp:523-535)
-    d += dy * dy;
-    d += dz * dz;
-    // slots past the end of the run (and NaN distances) become +inf: the pass below is then a no-op
-    double t = (valid && d == d) ? d : __longlong_as_double(0x7ff0000000000000ll);
-    uint32_t tpos = pos;
-    if (kAblation && (q.ablate & 32)) { q.l6 = t < q.l6 ? t : q.l6; return; }
-    knn_bubble(s, t, tpos);
-    // what fell off bounds the 6th neighbour (an evicted sentinel is not a point: it bounds nothing)
-    const double out = tpos == 0xffffffffu ? q.l6 : t;
-    q.l6 = fmin(q.l6, out);
-}
-
-struct KnnCursor { int r; uint32_t j, e; };
-
-// move the cursor to the next row that still has candidates (rows whose lower bound already
-// exceeds the current 5th distance are skipped; the bound only shrinks, so this is safe ahead of time)
-__device__ __forceinline__ bool knn_advance(KnnCursor& c, const KnnShared& sh, KnnQuery& q, const Knn5& s, int tid) {
-    while (c.j >= c.e) {
-        if (++c.r > 8) { c.r = 9; c.j = c.e = 0u; return false; }
-        c.j = sh.rs[c.r][tid];
-        c.e = sh.re[c.r][tid];
-        const double b = row_bound(q, c.r);
-        // Skipping needs only b > d4.  The extra ~0.1 m of radius keeps the lower bound l6 of the "6th
-        // neighbour" (which a skipped row caps at b) ~0.05 m above the 5th distance so that the next
-        // iteration's temporal-coherence test to succeed once the pose update is small.
-        const float r4 = sqrtf((float)s.d[4]);
-        const double thresh = s.d[4] + (double)(0.1f * r4 + 0.0025f);   // (r + 0.05)^2 - r^2
-        if (b > thresh) { c.j = c.e; q.l6 = b < q.l6 ? b : q.l6; }   // skipped points are at least sqrt(b) away
-    }
-    return true;
-}
-
-// Up to kChunk consecutive candidates of a lane's stream: [a, a + an) from the current run, then [b, b + bn) from the
-// next eligible one.
-struct KnnPair { uint32_t a, an, b, bn; };
-
-__device__ __forceinline__ uint32_t knn_pair_pos(const KnnPair& p, int i) {
-    const uint32_t o = (uint32_t)i - p.an;                      // wraps for i < an
-    return (uint32_t)i < p.an ? p.a + (uint32_t)i : (o < p.bn ? p.b + o : p.a);     // slots past the end re-read a valid point
-}
-
-template <int kChunk>
-__device__ __forceinline__ bool knn_next(KnnCursor& c, const KnnShared& sh, KnnQuery& q, const Knn5& s, int tid, KnnPair& out) {
-    out.a = 0u; out.an = 0u; out.b = 0u; out.bn = 0u;
-    if (c.r > 8) return false;
-    if (c.j >= c.e && !knn_advance(c, sh, q, s, tid)) return false;
-    out.a = c.j;
-    out.an = min(c.e - c.j, (uint32_t)kChunk);
-    c.j += out.an;
-    if (out.an < (uint32_t)kChunk && knn_advance(c, sh, q, s, tid)) {      // the run ended inside the chunk: continue in the next one
-        out.b = c.j;
-        out.bn = min(c.e - c.j, (uint32_t)kChunk - out.an);
-        c.j += out.bn;
-    }
-    return true;
-}
-
-// Rare path: exact distance ties.  Plain sequential scan of the 3x3x3 block with the full
-// (distance, original index) order; kept out of line so that it costs the hot path nothing.
+// Rare path, out of line: plain sequential scan of the 3x3x3 block with the full (distance, original index) order, for the
+// queries whose screened list could not be proven (ties at the edge of the list, or more candidates than the key format
+// holds).  Returns the kNb nearest and the exact squared distance of the next one (max_sq if there is none inside the gate).
 // (The grid geometry is passed by value: handing over a reference to the kernel's GridHeader would force that copy
-// into scratch memory -- seven vector loads, seven scratch stores and a memory round trip in EVERY launch.)
-__device__ __noinline__ void knn5_resolve_ties(double org_x, double org_y, double org_z, double inv_cell, uint32_t dim0, uint32_t dim1,
-                                               const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                               double qx, double qy, double qz, double max_sq, Knn5& s) {
-    double d5[5]; uint32_t i5[5], p5[5];
-    for (int j = 0; j < 5; ++j) { d5[j] = max_sq; i5[j] = 0xffffffffu; p5[j] = 0xffffffffu; }
+// into scratch memory in EVERY launch.)
+__device__ __noinline__ void knn8_exact(double org_x, double org_y, double org_z, double inv_cell, uint32_t dim0, uint32_t dim1,
+                                        const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                        double qx, double qy, double qz, double max_sq, uint32_t pos_out[kNb], double* next_sq) {
+    double d9[kNb + 1]; uint32_t i9[kNb + 1], p9[kNb + 1];
+    for (int j = 0; j <= kNb; ++j) { d9[j] = max_sq; i9[j] = 0xffffffffu; p9[j] = kNoPos; }
     const int cx = (int)floor((qx - org_x) * inv_cell), cy = (int)floor((qy - org_y) * inv_cell), cz = (int)floor((qz - org_z) * inv_cell);
     for (int r = 0; r < 9; ++r) {
         const uint32_t key = ((uint32_t)(cz + r / 3 - 1) * dim1 + (uint32_t)(cy + r % 3 - 1)) * dim0 + (uint32_t)cx;
         for (uint32_t j = cell_start[key - 1]; j < cell_start[key + 2]; ++j) {
             const float4 p = pts[j];
-            const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
-            double d = dx * dx; d += dy * dy; d += dz * dz;
+            const double d = sqdist(qx, qy, qz, p.x, p.y, p.z);
             const uint32_t idx = __float_as_uint(p.w);
-            if (!knn_less(d, idx, d5[4], i5[4])) continue;
-            int k = 4;
-            while (k > 0 && knn_less(d, idx, d5[k - 1], i5[k - 1])) { d5[k] = d5[k - 1]; i5[k] = i5[k - 1]; p5[k] = p5[k - 1]; --k; }
-            d5[k] = d; i5[k] = idx; p5[k] = j;
+            if (!knn_less(d, idx, d9[kNb], i9[kNb])) continue;
+            int k = kNb;
+            while (k > 0 && knn_less(d, idx, d9[k - 1], i9[k - 1])) { d9[k] = d9[k - 1]; i9[k] = i9[k - 1]; p9[k] = p9[k - 1]; --k; }
+            d9[k] = d; i9[k] = idx; p9[k] = j;
         }
     }
-    for (int j = 0; j < 5; ++j) { s.d[j] = d5[j]; s.idx[j] = i5[j]; s.pos[j] = p5[j]; }
+    for (int j = 0; j < kNb; ++j) pos_out[j] = p9[j];
+    *next_sq = d9[kNb];
 }
 
-// kChunk, a template parameter below = candidates per lane per step: 10 in the default kernel (8 / 10 / 12 / 14 measured: 3 349 / 3 386 / 3 379 / 3 363
-// scans/s on one box), 4 in the two-waves-per-SIMD
-// variant (the sorted array is padded by 16 entries, GridIndex::build)
-
-// Exact 5 nearest target points with squared distance <= max_sq (ties on the original
-// index), searching the 3x3x3 cell block as 9 contiguous x-runs.  Returns false when the
-// query lies outside the searchable grid.  On return s.d[4] < max_sq  <=>  the reference's
-// gate pointSearchSqDis[4] < mKdtreeMaxSearchDist (LoamRegister.cpp:59) passes.
+// ------------------------------------------------------------------------------
+// Per-lane search: one lane streams the candidates of its query's 3x3x3 block (9 contiguous x-runs) ONCE, as a flat
+// sequence, and keeps the kNb smallest 32-bit keys
+//     key = (float distance bits, low bits cleared) | sequence number of the candidate in that stream
+// Two instructions per list slot (v_min_u32 / v_max_u32) instead of the five a (double distance, position) pair costs,
+// float arithmetic for the distance, and nothing else per candidate but the cursor of the stream.  The float distance is a
+// SCREEN: d~ differs from the exact double distance by < 1e-6 relative, the cleared bits by 2^-(23 - id bits).  What is
+// exact: a candidate that did not make the list has key >= the list's last key, hence an exact distance
+//     >= LB = float(last key, low bits cleared) * (1 - 1e-6).
+// The owner recomputes the kNb listed candidates in double, sorts them by (distance, index) and accepts the five nearest
+// iff the fifth is strictly nearer than LB (nothing outside the list can tie with it or beat it); otherwise, a handful of
+// queries per million, the out-of-line exact scan decides.  LB also bounds every target point that is not in the list,
+// which is what the temporal cache needs.
 //
-// Memory-level parallelism is explicit: the 18 range loads of a query are issued together, and
-// candidates stream in chunks of kChunk float4 loads with the next chunk already in flight.
-template <int kChunk>
-__device__ __forceinline__ bool knn5_grid(const GridHeader& h, const float4* __restrict__ pts,
-                                          const uint32_t* __restrict__ cell_start, double qx, double qy, double qz,
-                                          double max_sq, Knn5& s, KnnShared& sh, bool active, double* l6_out, bool keep,
-                                          double seed_bound, int ablate, unsigned long long* tl = nullptr, uint32_t part = 0u, uint32_t parts_log2 = 0u) {
-    // parts_log2 > 0: this lane takes the part-th of 2^parts_log2 equal slices of every row run; the caller merges the
-    // lists of a query's lanes (and only then looks for distance ties).
+// part / parts_log2: this lane takes the part-th of 2^parts_log2 equal slices of the stream; the caller merges the lists.
+// Returns 0: query outside the grid (no candidate can pass the gate), 1: keys valid, 2: more candidates than the key format
+// numbers (the caller falls back to the exact scan).
+// ------------------------------------------------------------------------------
+struct KnnCursor { uint32_t j, e, k; uint2 nx; };
+
+__device__ __forceinline__ uint32_t knn_cursor_step(KnnCursor& c, const KnnRuns& sh, int tid) {
+    const uint32_t pos = c.j;
+    const uint32_t j1 = c.j + 1u;
+    const bool adv = j1 >= c.e;
+    c.k += adv ? 1u : 0u;
+    c.j = adv ? c.nx.x : j1;
+    c.e = adv ? c.nx.y : c.e;
+    c.nx = sh.run[min(c.k + 1u, 9u)][tid];
+    return pos;
+}
+
+template <int kGroup>
+__device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                        float qxf, float qyf, float qzf, float gate_f, bool active, KnnRuns& sh, uint32_t part, uint32_t parts_log2,
+                                        uint32_t key[kNb], uint32_t* idmask_out, unsigned long long* tl) {
     const int tid = threadIdx.x;
-    if (!keep) {
-        // Empty slots are sentinels (index 0xffffffff) at an upper bound of the 5th distance: the gate
-        // radius, or -- when five real points are known to lie within seed_bound (the previous iteration's
-        // neighbours) -- that tighter radius, which lets the row bounds prune from the first row on.
-        // Every true neighbour has d <= bound and a smaller index than the sentinel, so it displaces one.
-        // (distance-only compares: a point exactly AT the seed radius must still enter, so the sentinels sit one
-        // ulp above it; at the gate radius itself entering or not is immaterial -- the gate d5 < max_sq fails)
-        const double b0 = seed_bound < max_sq ? __longlong_as_double(__double_as_longlong(seed_bound) + 1) : max_sq;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { s.d[j] = b0; s.idx[j] = 0xffffffffu; s.pos[j] = 0xffffffffu; }
-    }
+    for (int j = 0; j < kNb; ++j) key[j] = kKeyEmpty;
+    *idmask_out = 0u;
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
     // cell coordinates (exact: q is a float widened to double, origin a multiple of cell)
     const double rx = qx - h.origin[0], ry = qy - h.origin[1], rz = qz - h.origin[2];
     const double fx = floor(rx * h.inv_cell), fy = floor(ry * h.inv_cell), fz = floor(rz * h.inv_cell);
     // queries in the outermost cell (or beyond, or NaN) are >= one cell away from every point
     const bool inside = active && (fx >= 1.0 && fx <= (double)(h.dims[0] - 2) && fy >= 1.0 && fy <= (double)(h.dims[1] - 2) &&
                                    fz >= 1.0 && fz <= (double)(h.dims[2] - 2));
+    uint32_t n_runs = 0, total = 0;
     if (inside) {
         const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
         uint32_t ra[9], rb[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {   // 18 independent loads in flight
-            const uint32_t key = ((uint32_t)(cz + row_dz(r)) * (uint32_t)h.dims[1] + (uint32_t)(cy + row_dy(r))) * (uint32_t)h.dims[0] + (uint32_t)cx;
-            ra[r] = cell_start[key - 1]; rb[r] = cell_start[key + 2];
+            const uint32_t ck = ((uint32_t)(cz + row_dz(r)) * (uint32_t)h.dims[1] + (uint32_t)(cy + row_dy(r))) * (uint32_t)h.dims[0] + (uint32_t)cx;
+            ra[r] = cell_start[ck - 1]; rb[r] = cell_start[ck + 2];
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            const uint32_t len = rb[r] - ra[r];
-            sh.rs[r][tid] = ra[r] + (uint32_t)(((uint64_t)len * part) >> parts_log2);
-            sh.re[r][tid] = ra[r] + (uint32_t)(((uint64_t)len * (part + 1u)) >> parts_log2);
+            if (rb[r] > ra[r]) { sh.run[n_runs][tid] = make_uint2(ra[r], rb[r]); ++n_runs; total += rb[r] - ra[r]; }
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 9; ++r) { sh.rs[r][tid] = 0u; sh.re[r][tid] = 0u; }
     }
-    KnnQuery q;
-    q.qx = qx; q.qy = qy; q.qz = qz;
-    q.ylo = ry - fy * h.cell; q.yhi = (fy + 1.0) * h.cell - ry;
-    q.zlo = rz - fz * h.cell; q.zhi = (fz + 1.0) * h.cell - rz;
-    q.l6 = max_sq;   // points outside the 3x3x3 block are >= one cell (>= sqrt(max_sq)) away
-    q.ablate = ablate;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) if ((uint32_t)r >= n_runs) sh.run[r][tid] = make_uint2(0u, 0u);
     if (tl) tl[8] = wall_clock64();       // row ranges in LDS
     // (each lane reads back only what it wrote itself: no barrier needed)
-    // A chunk = the next kChunk candidates of this lane's stream, taken from the rest of the current row run and, when
-    // that is shorter, from the head of the next eligible row (a run holds ~5 points on average: chunks cut at every run
-    // end were ~45 % empty slots, and an empty slot costs as much as a real candidate).  Slot i reads a + i or
-    // b + (i - an): straight-line code, no per-slot cursor logic.
-    KnnCursor cur{-1, 0u, 0u};
-    KnnPair pc, pn;
-    bool has = knn_next<kChunk>(cur, sh, q, s, tid, pc);
-    float4 c[kChunk];
+    const uint32_t bits = 32u - (uint32_t)__clz((int)(total | 1u));
+    const uint32_t idmask = (1u << bits) - 1u;
+    *idmask_out = idmask;
+    const bool too_many = bits > 16u;
+    const uint32_t s0 = (uint32_t)(((uint64_t)total * part) >> parts_log2), s1 = (uint32_t)(((uint64_t)total * (part + 1u)) >> parts_log2);
+    const uint32_t n_mine = too_many ? 0u : s1 - s0;
+    // position the cursor at flat index s0
+    KnnCursor cur;
+    {
+        uint32_t k = 0, rem = s0;
+        if (parts_log2) {
 #pragma unroll
-    for (int i = 0; i < kChunk; ++i) c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has) {
-#pragma unroll
-        for (int i = 0; i < kChunk; ++i) c[i] = pts[knn_pair_pos(pc, i)];
+            for (int t = 0; t < 9; ++t) {
+                const uint2 r = sh.run[t][tid];
+                const uint32_t len = r.y - r.x;
+                const bool skip = (uint32_t)t == k && (uint32_t)t < n_runs && rem >= len;
+                rem -= skip ? len : 0u; k += skip ? 1u : 0u;
+            }
+        }
+        const uint2 r0 = sh.run[min(k, 9u)][tid];
+        cur.k = k; cur.j = r0.x + rem; cur.e = r0.y; cur.nx = sh.run[min(k + 1u, 9u)][tid];
     }
-    if (tl) { float t_ = 0.f; for (int i = 0; i < kChunk; ++i) t_ += c[i].x; if (t_ == 1.2345e38f) q.l6 = 0; tl[9] = wall_clock64(); }   // first chunk arrived
-    while (has) {
-        const bool has_n = knn_next<kChunk>(cur, sh, q, s, tid, pn);     // sees the list before this chunk's insertions: bounds only shrink
-        float4 n[kChunk];
+    // wave-uniform number of groups
+    uint32_t nmax = n_mine;
 #pragma unroll
-        for (int i = 0; i < kChunk; ++i) n[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_n) {
+    for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, m, 64));
+    const uint32_t groups = __builtin_amdgcn_readfirstlane((nmax + (uint32_t)kGroup - 1u) / (uint32_t)kGroup);
+    float4 c[kGroup];
+    if (groups) {
 #pragma unroll
-            for (int i = 0; i < kChunk; ++i) n[i] = pts[knn_pair_pos(pn, i)];
+        for (int u = 0; u < kGroup; ++u) {
+            const uint32_t pos = knn_cursor_step(cur, sh, tid);
+            c[u] = pts[(uint32_t)u < n_mine ? pos : 0u];
+        }
+    }
+    if (tl) { float t_ = 0.f; if (groups) { for (int u = 0; u < kGroup; ++u) t_ += c[u].x; } if (t_ == 1.2345e38f) key[0] = 0u; tl[9] = wall_clock64(); }   // first group arrived
+    for (uint32_t g = 0; g < groups; ++g) {
+        float4 n[kGroup];
+        if (g + 1u < groups) {
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const uint32_t pos = knn_cursor_step(cur, sh, tid);
+                n[u] = pts[(g + 1u) * (uint32_t)kGroup + (uint32_t)u < n_mine ? pos : 0u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) n[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < kChunk; ++i) {
-            if (kAblation && (q.ablate & 16)) { q.l6 += (double)c[i].x; }
-            else knn_consider(s, q, c[i], knn_pair_pos(pc, i), (uint32_t)i < pc.an + pc.bn);
+        for (int u = 0; u < kGroup; ++u) {
+            const uint32_t seq = g * (uint32_t)kGroup + (uint32_t)u;
+            const float dx = qxf - c[u].x, dy = qyf - c[u].y, dz = qzf - c[u].z;
+            float d = dx * dx;
+            d = __builtin_fmaf(dy, dy, d);
+            d = __builtin_fmaf(dz, dz, d);
+            uint32_t t = (__float_as_uint(d) & ~idmask) | (s0 + seq);
+            t = (seq < n_mine && d <= gate_f) ? t : kKeyEmpty;      // beyond the end of this lane's stream, beyond the gate, or NaN
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) { const uint32_t lo = min(key[k], t), hi = max(key[k], t); key[k] = lo; t = hi; }
         }
 #pragma unroll
-        for (int i = 0; i < kChunk; ++i) c[i] = n[i];
-        pc = pn; has = has_n;
+        for (int u = 0; u < kGroup; ++u) c[u] = n[u];
     }
-    *l6_out = q.l6;
     if (tl) tl[10] = wall_clock64();      // candidate stream done
-    if (inside && parts_log2 == 0u) {
-        // detect exact distance ties (inside the list, or between its last entry and anything left out); those rare
-        // queries are redone with the index tie-break.  The original indices are NOT fetched here: the owner of the
-        // query reads the five points anyway (coordinates for the plane fit) and takes the index from the same 16 bytes
-        // -- one memory round trip instead of two.
-        bool tie = false;
+    return !inside ? 0 : (too_many ? 2 : 1);
+}
+
+// sequence number of a candidate in the lane's stream -> position in the cell-sorted array (the lane's run table is still in LDS)
+__device__ __forceinline__ void knn_decode(const KnnRuns& sh, int tid, const uint32_t key[kNb], uint32_t idmask, uint32_t pos[kNb]) {
+    uint2 r[9];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) s.idx[j] = 0xffffffffu;
-        if (s.pos[4] != 0xffffffffu) {
-            tie = (q.l6 == s.d[4]) | (s.d[0] == s.d[1]) | (s.d[1] == s.d[2]) | (s.d[2] == s.d[3]) | (s.d[3] == s.d[4]);
+    for (int t = 0; t < 9; ++t) r[t] = sh.run[t][tid];
+#pragma unroll
+    for (int j = 0; j < kNb; ++j) {
+        uint32_t rem = key[j] & idmask, p = kNoPos;
+        bool found = key[j] == kKeyEmpty;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t len = r[t].y - r[t].x;
+            const bool in = !found && rem < len;
+            p = in ? r[t].x + rem : p;
+            found = found || in;
+            rem -= found ? 0u : len;
         }
-        if (tie) {
-            Knn5 fixed;     // a separate object: only this rare path lives in scratch memory
-            knn5_resolve_ties(h.origin[0], h.origin[1], h.origin[2], h.inv_cell, (uint32_t)h.dims[0], (uint32_t)h.dims[1], pts, cell_start, qx, qy, qz,
-                              max_sq, fixed);
-            s = fixed;
-        }
+        pos[j] = p;
     }
-    return inside;
+}
+
+// squared-distance bound of everything that is not in a screened list (see knn_scan)
+__device__ __forceinline__ double knn_list_bound(const uint32_t key[kNb], uint32_t idmask) {
+    if (key[kNb - 1] == kKeyEmpty) return __longlong_as_double(0x7ff0000000000000ll);   // every candidate inside the gate is in the list
+    return (double)__uint_as_float(key[kNb - 1] & ~idmask) * (1.0 - 1e-6);
 }
 
 // ------------------------------------------------------------------------------
 // Temporal coherence between Gauss-Newton iterations (exact, not approximate).
-// After a full search we keep, per scan point: the query position q0, the sorted-array
-// positions of its 5 neighbours and L6, a lower bound of the squared distance from q0 to
-// every OTHER target point.  At the next iteration the query has moved by delta = |q - q0|.
-// For any other point p: |p - q| >= |p - q0| - delta >= sqrt(L6) - delta, so if the farthest of
-// the 5 cached neighbours is strictly closer to q than that, the cached set IS the exact
-// 5-NN set of q and only its order has to be recomputed.  Otherwise the full search runs.
+// After a search we keep, per scan point: the query position q0, its kNb nearest map points (coordinates and original
+// indices) and L, a lower bound of the distance from q0 to every OTHER target point.  At a later iteration the query has
+// moved by delta = |q - q0|.  For any other point p: |p - q| >= |p - q0| - delta >= L - delta, so if the fifth nearest of
+// the kept points is strictly closer to q than that, the five nearest of the kept points ARE the exact 5-NN of q.
+// Otherwise the search runs again.  The plane through the five (which does not depend on the query) is kept with the
+// indices it was fitted to and reused while the five and their order stay the same.
 // ------------------------------------------------------------------------------
-struct NnCacheEntry {          // 128 bytes per scan point
-    float4 nb[5];              // the 5 neighbours in (distance, index) order: x y z | original index bits
+struct NnCacheEntry {          // 192 bytes per scan point = 12 x 16 (fetched by LDS-DMA)
+    float4 nb[kNb];            // x y z | original index bits; +inf coordinates and index 0xffffffff: empty slot
     float q0[3];               // query position of the SEARCH that produced the entry (never moved afterwards: a bound
-                               // anchored there is at least as tight as one chained through the iterations, and a
-                               // hit then writes nothing back)
-    float l6;                  // lower bound (rounded down) of the DISTANCE from q0 to every OTHER target point
-    double x[3];               // plane through them, A x = -1 (depends only on nb and their order)
-    uint32_t flags;            // bit0: entry valid (5 real neighbours)  bit1: x valid  bit2: plane passed its validity gate
-    uint32_t pad;
+                               // anchored there is at least as tight as one chained through the iterations)
+    float l9;                  // lower bound (rounded down) of the DISTANCE from q0 to every target point not in nb
+    double x[3];               // plane A x = -1 through the points pidx, in that order (LoamRegister.cpp:29-35)
+    uint32_t pidx[5];
+    uint32_t flags;            // bit0: entry valid  bit1: x valid  bit2: plane passed its validity gate
 };
-static_assert(sizeof(NnCacheEntry) == 128, "cache entry layout");
+static_assert(sizeof(NnCacheEntry) == 192, "cache entry layout");
+static constexpr int kEntryVec = sizeof(NnCacheEntry) / 16;
 
-// Distances from the new query to the cached neighbours; returns true when they are proven to be the exact
-// 5-NN (see above).  *ordered: they are still in (distance, index) order, so the cached plane is reusable bit for bit.
-__device__ __forceinline__ bool knn5_from_cache(const NnCacheEntry& ce, double qx, double qy, double qz, Knn5& s, double A[5][3],
-                                                bool* ordered) {
+// Distances from the new query to the kept points, put in (distance, index) order.  Returns true when the first five are
+// proven to be the exact 5-NN (see above).  *moved: the order of the kept points changed (the entry is rewritten so that the
+// next iteration finds it sorted).
+__device__ __forceinline__ bool knn_from_cache(const NnCacheEntry& ce, double qx, double qy, double qz, Nb8& s, bool* moved) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < kNb; ++j) {
         const float4 p = ce.nb[j];
-        A[j][0] = (double)p.x; A[j][1] = (double)p.y; A[j][2] = (double)p.z;
-        const double dx = qx - A[j][0], dy = qy - A[j][1], dz = qz - A[j][2];
-        double d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        s.d[j] = d; s.idx[j] = __float_as_uint(p.w); s.pos[j] = (uint32_t)j;   // pos = slot in the entry
+        s.x[j] = p.x; s.y[j] = p.y; s.z[j] = p.z; s.idx[j] = __float_as_uint(p.w);
+        const double d = sqdist(qx, qy, qz, p.x, p.y, p.z);
+        s.d[j] = d == d ? d : __longlong_as_double(0x7ff0000000000000ll);      // (an empty slot holds +inf coordinates)
     }
+    // the usual case late in the loop: the five are still the five, in order -- then the network is skipped by the whole wave
     bool ord = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ord = ord & !knn_less(s.d[j + 1], s.idx[j + 1], s.d[j], s.idx[j]);
-    *ordered = ord;
-    double r5sq = s.d[4];
-    if (!ord) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r5sq = fmax(r5sq, s.d[j]);
+    for (int j = 5; j < kNb; ++j) ord = ord & !knn_less(s.d[j], s.idx[j], s.d[4], s.idx[4]);
+    *moved = false;
+    if (!__all(ord)) {
+        uint32_t before[kNb];
+#pragma unroll
+        for (int j = 0; j < kNb; ++j) before[j] = s.idx[j];
+        nb8_sort(s);
+        bool mv = false;
+#pragma unroll
+        for (int j = 0; j < kNb; ++j) mv = mv | (before[j] != s.idx[j]);
+        *moved = mv;
     }
-    // |p - q| >= |p - q0| - |q - q0| >= l6 - delta for every other target point p.  Double precision: the stored bound
-    // loses at most one float ulp, so only 5th/6th-neighbour gaps below ~1e-7 m fail to be proven.
+    // |p - q| >= |p - q0| - |q - q0| >= l9 - delta for every other target point p.  Double precision: the stored bound
+    // loses at most one float ulp.
     const double ex = qx - (double)ce.q0[0], ey = qy - (double)ce.q0[1], ez = qz - (double)ce.q0[2];
     const double delta = sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-12) + 1e-13;
-    const double slack = (double)ce.l6 - delta;
-    return slack > 0.0 && r5sq < slack * slack * (1.0 - 1e-12);
+    const double slack = (double)ce.l9 - delta;
+    return s.idx[4] != 0xffffffffu && slack > 0.0 && s.d[4] < slack * slack * (1.0 - 1e-12);
 }
 
-// 9-comparator sorting network on (distance, index) with the neighbour coordinates as payload
-__device__ __forceinline__ void knn_sort5(Knn5& s, double A[5][3]) {
-#define CSWAP(i, j) { const bool sw = knn_less(s.d[j], s.idx[j], s.d[i], s.idx[i]); \
-        const double di = s.d[i], dj = s.d[j]; s.d[i] = sw ? dj : di; s.d[j] = sw ? di : dj; \
-        const uint32_t ii = s.idx[i], ij = s.idx[j]; s.idx[i] = sw ? ij : ii; s.idx[j] = sw ? ii : ij; \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c) { const double ai = A[i][c], aj = A[j][c]; A[i][c] = sw ? aj : ai; A[j][c] = sw ? ai : aj; } }
-    CSWAP(0, 1) CSWAP(3, 4) CSWAP(2, 4) CSWAP(2, 3) CSWAP(0, 3) CSWAP(0, 2) CSWAP(1, 4) CSWAP(1, 3) CSWAP(1, 2)
-#undef CSWAP
-}
-
-// Rare path: exact distance ties.  Plain sequential scan of the 3x3x3 block with the full
-// (distance, original index) order; kept out of line so that it costs the hot path nothing.
 // ------------------------------------------------------------------------------
 // plane fit: Eigen::ColPivHouseholderQR<Matrix<double,5,3>>::solve(-1) restated
 // (LoamRegister.cpp:29-35), all indices static so everything stays in registers.
@@ -479,25 +458,26 @@ __device__ __forceinline__ void plane_qr_solve(double a[5][3], double x[3]) {
     }
 }
 
+
 // ------------------------------------------------------------------------------
-// Wave-cooperative exact 5-NN of ONE query: lanes = candidates.  Used when only a handful of queries of a
-// block still need a search (late Gauss-Newton iterations): the per-lane search above is a chain of a dozen
-// dependent memory round trips whether 1 or 64 lanes are busy, this one is three (ranges, points, done).
+// Wave-cooperative exact search of ONE query: lanes = candidates.  Used when only a handful of queries of a
+// block still need a search (late Gauss-Newton iterations): the per-lane search above is a chain of dependent memory
+// round trips whether 1 or 64 lanes are busy, this one is three (ranges, points, done).
 // Every candidate of the 3x3x3 block gets its exact (distance, index) key; a candidate's rank is the number
 // of smaller keys, counted against the wave's table in LDS -- no ordering between lanes is needed.
-// All 64 lanes call it with the same query.  tab: >= kWaveTab entries of this wave.  Returns false when the
+// All 64 lanes call it with the same query.  tab: >= kWaveTab + 16 entries of this wave.  Returns false when the
 // block holds more candidates than the table (the caller then falls back to the per-lane search).
 // ------------------------------------------------------------------------------
 struct WaveCand { double d; uint32_t idx, pos; };
-static constexpr int kWaveTab = 280;     // 4 waves x (280 + 8 result slots) x 16 B = the 18 KB of KnnShared, which this path reuses
+static constexpr int kWaveTab = 280;     // 4 waves x (280 + 16 result slots) x 16 B = 18.5 KB of the 20 KB of KnnRuns, which this path reuses
 
-__device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                          double qx, double qy, double qz, double max_sq, double seed_sq, WaveCand* tab, Knn5& out,
-                                          double* l6_out, bool* inside_out) {
+__device__ __forceinline__ bool knn8_wave(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                          double qx, double qy, double qz, double max_sq, double seed_sq, WaveCand* tab, uint32_t pos_out[kNb],
+                                          double* next_sq, bool* inside_out) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) { out.d[j] = max_sq; out.idx[j] = 0xffffffffu; out.pos[j] = 0xffffffffu; }
-    *l6_out = max_sq;
+    for (int j = 0; j < kNb; ++j) pos_out[j] = kNoPos;
+    *next_sq = max_sq;
     const double rx = qx - h.origin[0], ry = qy - h.origin[1], rz = qz - h.origin[2];
     const double fx = floor(rx * h.inv_cell), fy = floor(ry * h.inv_cell), fz = floor(rz * h.inv_cell);
     const bool inside = (fx >= 1.0 && fx <= (double)(h.dims[0] - 2) && fy >= 1.0 && fy <= (double)(h.dims[1] - 2) && fz >= 1.0 &&
@@ -520,25 +500,22 @@ __device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __r
     uint32_t r_start[9], r_excl[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) { r_start[r] = __shfl(rs, r, 64); r_excl[r] = __shfl(incl - len, r, 64); }
-    // Every lane computes the exact keys of its candidates.  Only those within seed_sq -- an upper bound of the 5th
-    // distance (five known points lie inside it; max_sq when nothing is known) -- can be among the five nearest: they are
+    // Every lane computes the exact keys of its candidates.  Only those within seed_sq -- an upper bound of the kNb-th
+    // distance (kNb known points lie inside it; max_sq when nothing is known) -- can be among the kNb nearest: they are
     // compacted into the table and ranked among themselves (a handful instead of ~100); the others only bound the
-    // "6th neighbour" from below through their minimum.
+    // next neighbour from below through their minimum.
     uint32_t n_in = 0;                 // wave-uniform
     double out_min = max_sq;
     for (uint32_t c0 = 0; c0 < total; c0 += 64) {
         const uint32_t c = c0 + (uint32_t)lane;
         bool in = false;
-        WaveCand w; w.d = max_sq; w.idx = 0xffffffffu; w.pos = 0xffffffffu;
+        WaveCand w; w.d = max_sq; w.idx = 0xffffffffu; w.pos = kNoPos;
         if (c < total) {
             uint32_t pos = 0;
 #pragma unroll
             for (int r = 0; r < 9; ++r) if (c >= r_excl[r]) pos = r_start[r] + (c - r_excl[r]);
             const float4 p = pts[pos];
-            const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
-            double d = dx * dx;
-            d += dy * dy;
-            d += dz * dz;
+            const double d = sqdist(qx, qy, qz, p.x, p.y, p.z);
             w.d = d; w.idx = __float_as_uint(p.w); w.pos = pos;
             in = d <= seed_sq;
             if (!in) out_min = fmin(out_min, d);
@@ -559,16 +536,16 @@ __device__ __forceinline__ bool knn5_wave(const GridHeader& h, const float4* __r
             const WaveCand o = tab[j];
             rank += knn_less(o.d, o.idx, me.d, me.idx) ? 1u : 0u;
         }
-        if (rank < 6) { tab[kWaveTab + rank] = me; }       // six result slots behind the table
+        if (rank <= (uint32_t)kNb) { tab[kWaveTab + rank] = me; }       // kNb + 1 result slots behind the table
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if ((uint32_t)j < n_in) { const WaveCand w = tab[kWaveTab + j]; out.d[j] = w.d; out.idx[j] = w.idx; out.pos[j] = w.pos; }
+    for (int j = 0; j < kNb; ++j) {
+        if ((uint32_t)j < n_in) pos_out[j] = tab[kWaveTab + j].pos;
     }
-    double l6 = out_min;
-    if (n_in > 5) l6 = fmin(l6, tab[kWaveTab + 5].d);
-    *l6_out = fmin(max_sq, l6);
+    double nx = out_min;
+    if (n_in > (uint32_t)kNb) nx = fmin(nx, tab[kWaveTab + kNb].d);
+    *next_sq = fmin(max_sq, nx);
     return true;
 }
 
@@ -582,11 +559,15 @@ struct MissExchange {
     uint32_t count, fallback;
     uint32_t list[256];                  // owner thread of the m-th posted query (order immaterial)
     float qx[256], qy[256], qz[256];     // query (float-valued)
-    double seed[256];                    // upper bound of the 5th distance
-    double l6[256];
-    uint32_t searched[256];
+    double seed[256];                    // upper bound of the kNb-th squared distance (max_sq when nothing is known)
     union {
-        struct { double d[5][256]; uint32_t pos[5][256]; uint32_t idx[5][256]; } res;   // by owner
+        struct {
+            uint32_t pos[kNb][256];      // by owner: positions of the listed candidates in the cell-sorted array
+            double bound[256];           // by owner: squared-distance bound of every target point not listed
+            uint32_t state[256];         // by owner: 0 no candidates / outside, 1 screened list (to be proven), 2 exact list, 3 redo exactly
+            uint32_t keys[kNb][256];     // by worker thread: partial lists of the lanes that share a query
+            uint32_t idmask[256];
+        } res;
         double rows[8 * kRowStride];     // later: [component][point] rows of the normal equations
     } u;
 };
@@ -596,10 +577,10 @@ struct MissExchange {
 // 4 outside this rank's query tile / no point);  row[0..5] = s*[n ; p x n], row[6] = s*d
 // Called by all threads of the block together (it contains barriers).
 // ------------------------------------------------------------------------------
-template <int kChunk>
+template <int kGroup>
 __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h, const double* __restrict__ pose,
                                           float sx, float sy, float sz, bool valid, const NnCacheEntry& ce_in, bool have_entry,
-                                          KnnShared& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how,
+                                          KnnRuns& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how,
                                           bool* escaped, unsigned long long* tl) {
     const double ox = (double)sx, oy = (double)sy, oz = (double)sz;
     // LoamRegister.cpp:126-130: Isometry3d * Vector4d in f64, then cast to f32
@@ -624,25 +605,28 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
                    ((cm & 2) && fy <= (double)kPad) || ((cm & 16) && fy >= (double)(h.dims[1] - kPad - 1)) ||
                    ((cm & 4) && fz <= (double)kPad) || ((cm & 32) && fz >= (double)(h.dims[2] - kPad - 1));
     }
-    Knn5 s;
-    double A[5][3];
-    bool searched = false, ordered = false;
+    Nb8 s;
+    bool moved = false;
     const bool have_seed = have_entry && active && (ce_in.flags & 1u);
-    if (have_seed) searched = knn5_from_cache(ce_in, qx, qy, qz, s, A, &ordered);
-    const bool hit = searched;
-    double l6 = 0.0;
+    bool hit = false;
+    if (have_seed) hit = knn_from_cache(ce_in, qx, qy, qz, s, &moved);
     const int tid = threadIdx.x;
     // ---- post the queries that need a search ----
-    const bool miss = active && !hit && !(kAblation && (a.ablate & 1));
+    const bool miss = active && !hit;
     if (tid == 0) ex.count = 0;
     __syncthreads();
     if (miss) {
         const uint32_t m = atomicAdd(&ex.count, 1u);
         ex.list[m] = (uint32_t)tid;
         ex.qx[tid] = px; ex.qy[tid] = py; ex.qz[tid] = pz;
-        // cached neighbours that could not be proven final still bound the 5th distance from above
+        // kept points that could not be proven final still bound the kNb-th distance from above (when all kNb are real)
         double sb = a.c.knn_max_sq;
-        if (have_seed) { sb = s.d[0]; for (int j = 1; j < 5; ++j) sb = fmax(sb, s.d[j]); }
+        if (have_seed) {
+            double mx = s.d[0];        // (+inf as soon as one slot is empty)
+#pragma unroll
+            for (int j = 1; j < kNb; ++j) mx = fmax(mx, s.d[j]);
+            sb = fmin(sb, mx);
+        }
         ex.seed[tid] = sb;
     }
     __syncthreads();
@@ -656,116 +640,112 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             if (tid == 0) ex.fallback = 0;
             __syncthreads();
             const int wave = tid >> 6;
-            WaveCand* tab = reinterpret_cast<WaveCand*>(&sh) + (size_t)wave * (kWaveTab + 8);
+            WaveCand* tab = reinterpret_cast<WaveCand*>(&sh) + (size_t)wave * (kWaveTab + 16);
             for (uint32_t m = wave; m < n_miss; m += 4) {
                 const uint32_t owner = ex.list[m];
-                Knn5 r;
-                double rl6 = 0.0;
+                uint32_t rp[kNb];
+                double nxt = 0.0;
                 bool ins = false;
-                const bool done = knn5_wave(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
-                                            a.c.knn_max_sq, ex.seed[owner], tab, r, &rl6, &ins);
+                const bool done = knn8_wave(h, a.grid.pts, a.grid.cell_start, (double)ex.qx[owner], (double)ex.qy[owner], (double)ex.qz[owner],
+                                            a.c.knn_max_sq, ex.seed[owner], tab, rp, &nxt, &ins);
                 if (!done) { if ((tid & 63) == 0) ex.fallback = 1; }
                 else if ((tid & 63) == 0) {
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) { ex.u.res.d[j][owner] = r.d[j]; ex.u.res.pos[j][owner] = r.pos[j]; ex.u.res.idx[j][owner] = r.idx[j]; }
-                    ex.l6[owner] = rl6; ex.searched[owner] = ins ? 1u : 0u;
+                    for (int j = 0; j < kNb; ++j) ex.u.res.pos[j][owner] = rp[j];
+                    ex.u.res.bound[owner] = nxt; ex.u.res.state[owner] = ins ? 2u : 0u;
                 }
             }
             __syncthreads();
-            dense = ex.fallback != 0;               // a cell block too crowded for the wave table: redo all of them densely
+            dense = ex.fallback != 0;               // a cell block too crowded for the wave table: redo all of them per lane
             __syncthreads();
         }
         if (n_miss && dense) {
-            // A block with few misses would leave three of its four waves idle while one wave walks whole row runs: up to 64
+            // A block with few misses would leave three of its four waves idle while one wave walks whole streams: up to 64
             // (128) posted queries are searched by four (two) lanes each, in different waves, every lane taking its slice of
-            // each row run; the lists are merged through LDS.  Ties are looked for after the merge, on the complete list.
+            // the query's candidate stream; the lists are merged through LDS.
             const uint32_t pl2 = n_miss <= 64u ? 2u : (n_miss <= 128u ? 1u : 0u);
             const uint32_t per = 256u >> pl2;                          // lanes per part
             const uint32_t m = (uint32_t)tid & (per - 1u), part = (uint32_t)tid >> (8u - pl2);
             const bool worker = m < n_miss;
             const uint32_t owner = worker ? ex.list[m] : 0u;
-            Knn5 r;
-            double rl6 = 0.0;
-            const double oqx = (double)ex.qx[owner], oqy = (double)ex.qy[owner], oqz = (double)ex.qz[owner];
-            bool ok = knn5_grid<kChunk>(h, a.grid.pts, a.grid.cell_start, oqx, oqy, oqz, a.c.knn_max_sq, r, sh, worker, &rl6, false,
-                                        worker ? ex.seed[owner] : a.c.knn_max_sq, a.ablate, tl, part, pl2);
+            uint32_t key[kNb], idmask = 0u;
+            const float gate_f = __double2float_ru(a.c.knn_max_sq * (1.0 + 1e-5));      // every candidate inside the gate has a float distance <= this
+            const int rc = knn_scan<kGroup>(h, a.grid.pts, a.grid.cell_start, ex.qx[owner], ex.qy[owner], ex.qz[owner], gate_f, worker, sh, part, pl2, key,
+                                            &idmask, tl);
             if (pl2) {
                 if (worker && part) {
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) { ex.u.res.d[j][tid] = r.d[j]; ex.u.res.pos[j][tid] = r.pos[j]; }
-                    ex.l6[tid] = rl6;
+                    for (int j = 0; j < kNb; ++j) ex.u.res.keys[j][tid] = key[j];
                 }
                 __syncthreads();
                 if (worker && !part) {
                     for (uint32_t q = 1; q < (1u << pl2); ++q) {
                         const uint32_t t2 = m + q * per;
-                        rl6 = fmin(rl6, ex.l6[t2]);
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            double t = ex.u.res.d[j][t2];
-                            uint32_t tp = ex.u.res.pos[j][t2];
-                            if (tp == 0xffffffffu) t = __longlong_as_double(0x7ff0000000000000ll);     // an empty slot is not a point
-                            knn_bubble(r, t, tp);
-                            if (tp != 0xffffffffu) rl6 = fmin(rl6, t);        // what fell off bounds the 6th neighbour
-                        }
-                    }
-                    if (ok) {
+                        for (int j = 0; j < kNb; ++j) {
+                            uint32_t t = ex.u.res.keys[j][t2];
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) r.idx[j] = 0xffffffffu;
-                        bool tie = false;
-                        if (r.pos[4] != 0xffffffffu) tie = (rl6 == r.d[4]) | (r.d[0] == r.d[1]) | (r.d[1] == r.d[2]) | (r.d[2] == r.d[3]) | (r.d[3] == r.d[4]);
-                        if (tie) {
-                            Knn5 fixed;
-                            knn5_resolve_ties(h.origin[0], h.origin[1], h.origin[2], h.inv_cell, (uint32_t)h.dims[0], (uint32_t)h.dims[1], a.grid.pts,
-                                              a.grid.cell_start, oqx, oqy, oqz, a.c.knn_max_sq, fixed);
-                            r = fixed;
+                            for (int k = 0; k < kNb; ++k) { const uint32_t lo = min(key[k], t), hi = max(key[k], t); key[k] = lo; t = hi; }
                         }
                     }
                 }
-                __syncthreads();          // every partial list has been read: the slots may now take final results (indexed by owner)
+                __syncthreads();          // every partial list has been read: the union may now take final results (indexed by owner)
             }
             if (worker && !part) {
+                uint32_t rp[kNb];
+                knn_decode(sh, tid, key, idmask, rp);
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { ex.u.res.d[j][owner] = r.d[j]; ex.u.res.pos[j][owner] = r.pos[j]; ex.u.res.idx[j][owner] = r.idx[j]; }
-                ex.l6[owner] = rl6; ex.searched[owner] = ok ? 1u : 0u;
+                for (int j = 0; j < kNb; ++j) ex.u.res.pos[j][owner] = rp[j];
+                ex.u.res.bound[owner] = knn_list_bound(key, idmask);
+                ex.u.res.state[owner] = rc == 0 ? 0u : (rc == 2 ? 3u : 1u);
             }
         }
     }
     __syncthreads();
     if (tl) tl[3] = wall_clock64();
-    bool real5 = hit;     // five real neighbours present
+    bool searched = hit;
+    double bound_sq = 0.0;      // (miss) squared-distance bound of every target point not in s
     if (miss) {
+        uint32_t rp[kNb];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { s.d[j] = ex.u.res.d[j][tid]; s.pos[j] = ex.u.res.pos[j][tid]; s.idx[j] = ex.u.res.idx[j][tid]; }
-        l6 = ex.l6[tid];
-        searched = ex.searched[tid] != 0;
-        real5 = searched && s.pos[4] != 0xffffffffu;
-        if (searched) {
+        for (int j = 0; j < kNb; ++j) rp[j] = ex.u.res.pos[j][tid];
+        bound_sq = ex.u.res.bound[tid];
+        uint32_t state = ex.u.res.state[tid];
+        searched = state != 0u;
+        float4 p8[kNb];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const float4 p = a.grid.pts[s.pos[j] != 0xffffffffu ? s.pos[j] : 0u];
-                A[j][0] = (double)p.x; A[j][1] = (double)p.y; A[j][2] = (double)p.z;
-                s.idx[j] = s.pos[j] != 0xffffffffu ? __float_as_uint(p.w) : 0xffffffffu;
-            }
+        for (int j = 0; j < kNb; ++j) p8[j] = a.grid.pts[(searched && rp[j] != kNoPos) ? rp[j] : 0u];
+#pragma unroll
+        for (int j = 0; j < kNb; ++j) nb8_set(s, j, p8[j], searched && state != 3u && rp[j] != kNoPos, qx, qy, qz);
+        nb8_sort(s);
+        // a screened list is final when its fifth entry is strictly nearer than everything that is not listed
+        const bool proven = state == 2u || (state == 1u && (s.idx[4] == 0xffffffffu ? !(bound_sq < a.c.knn_max_sq) : s.d[4] < bound_sq));
+        if (searched && !proven) {
+            double nxt;
+            knn8_exact(h.origin[0], h.origin[1], h.origin[2], h.inv_cell, (uint32_t)h.dims[0], (uint32_t)h.dims[1], a.grid.pts, a.grid.cell_start, qx, qy, qz,
+                       a.c.knn_max_sq, rp, &nxt);
+            for (int j = 0; j < kNb; ++j) nb8_set(s, j, a.grid.pts[rp[j] != kNoPos ? rp[j] : 0u], rp[j] != kNoPos, qx, qy, qz);
+            nb8_sort(s);
+            bound_sq = nxt;
         }
-    } else if (hit && !ordered) {
-        knn_sort5(s, A);          // same set, new order
+        bound_sq = fmin(bound_sq, a.c.knn_max_sq);      // points outside the 3x3x3 block are >= one cell (>= sqrt(max_sq)) away
     }
     __syncthreads();   // ex.u.rows is written next
     *how = hit ? 1 : (miss ? 2 : 0);
+    const bool real5 = searched && s.idx[4] != 0xffffffffu;     // five real neighbours present
 
-    // ---- plane through the 5 neighbours (LoamRegister.cpp:29-45): reused from the cache when the neighbours
-    // and their order are unchanged, since it does not depend on the query ----
+    // ---- plane through the 5 neighbours (LoamRegister.cpp:29-45): reused from the cache when the five and their order are
+    // the ones it was fitted to, since it does not depend on the query ----
     double x[3] = {0, 0, 0};
     bool plane_ok = false;
-    const bool reuse = hit && ordered && (ce_in.flags & 2u);
-    // a search that comes back with the cached neighbours in the cached order (the bound was too weak, the answer is
-    // the same) can take the cached plane as well; only the anchor of the entry moves
-    bool same_set = miss && real5 && have_seed && (ce_in.flags & 2u);
+    bool reuse = real5 && have_seed && (ce_in.flags & 2u);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) same_set = same_set && (s.idx[j] == __float_as_uint(ce_in.nb[j].w));
+    for (int j = 0; j < 5; ++j) reuse = reuse && (s.idx[j] == ce_in.pidx[j]);
     const bool gate_knn = real5 && (s.d[4] < a.c.knn_max_sq);      // LoamRegister.cpp:59
-    if (reuse || same_set) {
+    double A[5][3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { A[j][0] = (double)s.x[j]; A[j][1] = (double)s.y[j]; A[j][2] = (double)s.z[j]; }
+    if (reuse) {
         x[0] = ce_in.x[0]; x[1] = ce_in.x[1]; x[2] = ce_in.x[2];
         plane_ok = (ce_in.flags & 4u) != 0;
     } else if (real5 && !(kAblation && (a.ablate & 2))) {
@@ -788,19 +768,24 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         a.nn_cache[qi].flags = 0;
     }
     if (a.nn_cache && active) {
-        if (reuse) {
-            // neighbours, order and plane unchanged: the entry stays as it is
-        } else {
-            NnCacheEntry ce;
+        float4* const dst = reinterpret_cast<float4*>(a.nn_cache + qi);
+        if (miss || moved) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) ce.nb[j] = make_float4((float)A[j][0], (float)A[j][1], (float)A[j][2], __uint_as_float(s.idx[j]));
-            ce.x[0] = x[0]; ce.x[1] = x[1]; ce.x[2] = x[2];
-            // a hit whose order changed keeps the anchor of its search
-            ce.q0[0] = hit ? ce_in.q0[0] : px; ce.q0[1] = hit ? ce_in.q0[1] : py; ce.q0[2] = hit ? ce_in.q0[2] : pz;
-            ce.l6 = hit ? ce_in.l6 : __double2float_rd(sqrt(l6) * (1.0 - 1e-15));
-            ce.flags = (real5 ? 1u : 0u) | ((real5 && !(kAblation && (a.ablate & 2))) ? 2u : 0u) | (plane_ok ? 4u : 0u);
-            ce.pad = 0;
-            a.nn_cache[qi] = ce;
+            for (int j = 0; j < kNb; ++j) dst[j] = make_float4(s.x[j], s.y[j], s.z[j], __uint_as_float(s.idx[j]));
+        }
+        if (miss) {
+            // the anchor of the entry: this search's query position and what it proved about everything it did not list
+            dst[kNb] = make_float4(px, py, pz, __double2float_rd(sqrt(bound_sq) * (1.0 - 1e-15)));
+        }
+        if (miss || !reuse) {
+            union { struct { double x[3]; uint32_t pidx[5]; uint32_t flags; } t; float4 v[3]; } tail;
+            tail.t.x[0] = x[0]; tail.t.x[1] = x[1]; tail.t.x[2] = x[2];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) tail.t.pidx[j] = s.idx[j];
+            const bool x_valid = real5 && !(kAblation && (a.ablate & 2));
+            tail.t.flags = (searched ? 1u : 0u) | (x_valid ? 2u : 0u) | (plane_ok ? 4u : 0u);
+#pragma unroll
+            for (int f = 0; f < 3; ++f) dst[kNb + 1 + f] = tail.v[f];
         }
     }
     if (tl) tl[4] = wall_clock64();
@@ -844,7 +829,7 @@ __device__ __forceinline__ void lds_dma16(const float4* src, float4* lds_wave_ba
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "m0", "memory");
 }
 
-// pre_src / pre_dst: this lane's 128-byte neighbour-cache entry and the wave's slice of the LDS staging area.
+// pre_src / pre_dst: this lane's 192-byte neighbour-cache entry and the wave's slice of the LDS staging area.
 __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 */, Prologue* sh, unsigned long long* tl = nullptr,
                               const float4* pre_src = nullptr, float4* pre_dst = nullptr) {
     const LoamState* prev = &a.state[(k + 1) & 1];
@@ -902,9 +887,9 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     // equations are solved.  Issued from inline asm on purpose: the compiler's wait-count bookkeeping treats an LDS-DMA
     // in flight as "wait for everything" at every barrier and at every use of any other load; the consumer waits by hand.
     if (pre_dst) {
-        const float4* src = pre_src ? pre_src : reinterpret_cast<const float4*>(a.partials) + (size_t)t * 8;   // harmless address
+        const float4* src = pre_src ? pre_src : reinterpret_cast<const float4*>(a.partials) + (size_t)t * kEntryVec;   // harmless address
 #pragma unroll
-        for (int f = 0; f < 8; ++f) lds_dma16(src + f, pre_dst + f * 256);
+        for (int f = 0; f < kEntryVec; ++f) lds_dma16(src + f, pre_dst + f * 256);
     }
     // (the tests of the previous state come only now: placed before the loads above they made the compiler sink the
     // partial-sum loads below the branch, i.e. two dependent round trips instead of one)
@@ -1013,21 +998,20 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
 // ------------------------------------------------------------------------------
 // the iteration kernel
 // ------------------------------------------------------------------------------
-// kChunk / kWavesPerSimd: <8, 1> is the default (fastest for one scan at a time: 255 VGPRs + AGPRs, one wave per SIMD --
-// which is all that 65 536 queries give anyway); <4, 2> fits two waves per SIMD (245 VGPRs, 50 KB LDS) so that the blocks
-// of ANOTHER handle's launch can share the CUs: ~3 % slower alone, ~25 % more scans/s with several handles in flight
-// (pcr_params.reserved[4] = 1).
-template <int kChunk, int kWavesPerSimd>
+// kGroup = candidates in flight per lane of the per-lane search.  <8, 1> is the default (one wave per SIMD -- which is all
+// that 65 536 queries give anyway); <4, 2> fits two waves per SIMD so that the blocks of ANOTHER handle's launch can share the
+// CUs: a little slower alone, more scans/s with several handles in flight (pcr_params.reserved[4] = 1).
+template <int kGroup, int kWavesPerSimd>
 __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const LoamArgs a, const int k) {
     __shared__ double sh_sum[8 * 32];
     __shared__ Prologue sh_pro;
-    // The staging area of the prefetched cache entries (32 KB, dead once every lane has read its entry) shares its
-    // LDS with the search scratch and the miss exchange (48 KB, first written after that): 51 KB per block instead of
-    // 83 KB, so that two blocks -- e.g. of two scans on two streams -- fit on a CU.
-    struct SearchLds { KnnShared knn; MissExchange ex; };
-    static_assert(sizeof(SearchLds) >= 8 * 256 * sizeof(float4), "the staging area must fit into the search scratch");
-    __shared__ __attribute__((aligned(16))) unsigned char sh_ov[sizeof(SearchLds)];
-    KnnShared& sh_knn = reinterpret_cast<SearchLds*>(sh_ov)->knn;
+    // The staging area of the prefetched cache entries (48 KB, dead once every lane has read its entry) shares its
+    // LDS with the search scratch and the miss exchange (first written after that), so that two blocks -- e.g. of two scans
+    // on two streams -- fit on a CU.
+    struct SearchLds { KnnRuns knn; MissExchange ex; };
+    constexpr size_t kStage = (size_t)kEntryVec * 256 * sizeof(float4);
+    __shared__ __attribute__((aligned(16))) unsigned char sh_ov[sizeof(SearchLds) > kStage ? sizeof(SearchLds) : kStage];
+    KnnRuns& sh_knn = reinterpret_cast<SearchLds*>(sh_ov)->knn;
     MissExchange& sh_ex = reinterpret_cast<SearchLds*>(sh_ov)->ex;   // also holds the rows: [component][point] s*J (6), s*d, accepted flag
     double* const sh_rows = sh_ex.u.rows;
     const int tid = threadIdx.x;
@@ -1038,7 +1022,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
     if ((gridDim.x & 7u) == 0) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // Everything the first round needs from memory is requested before/inside the prologue, so that the scan point and
     // the 128-byte neighbour-cache entry arrive while the previous iteration's normal equations are being solved.
-    // The entry goes straight to LDS ([field][thread], 32 KB): held in registers it was spilled to AGPRs, which made
+    // The entry goes straight to LDS ([field][thread], 48 KB): held in registers it was spilled to AGPRs, which made
     // the wave wait for it before the prologue had even started.
     float4* const sh_pre = reinterpret_cast<float4*>(sh_ov);
     const GridHeader h = *a.grid.hdr;      // uniform: scalar loads, in flight during the prologue
@@ -1085,7 +1069,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         int how = 0;
         bool esc = false;
         float sx = pre_x, sy = pre_y, sz = pre_z;
-        union { NnCacheEntry e; float4 v[8]; } ce;
+        union { NnCacheEntry e; float4 v[kEntryVec]; } ce;
         ce.e.flags = 0;
         if (base == blk * 256) {
             // EVERY wave waits for its own LDS-DMA, also one without a single valid query (its lanes fetched a dummy address):
@@ -1094,7 +1078,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
             if (use_cache) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (use_cache && valid) {
 #pragma unroll
-                for (int f = 0; f < 8; ++f) ce.v[f] = sh_pre[f * 256 + tid];
+                for (int f = 0; f < kEntryVec; ++f) ce.v[f] = sh_pre[f * 256 + tid];
             }
             __syncthreads();          // the staging area is about to be reused by the search scratch and the exchange
         } else {                      // later rounds of a grid-stride launch
@@ -1105,7 +1089,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
                 if (use_cache) ce.e = a.nn_cache[q];
             }
         }
-        const int st = loam_point<kChunk>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, &esc, base == blk * 256 ? tl : nullptr);
+        const int st = loam_point<kGroup>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, &esc, base == blk * 256 ? tl : nullptr);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const size_t oi = (size_t)q;
             if (a.dbg_status) a.dbg_status[oi] = (int8_t)st;
@@ -1199,11 +1183,11 @@ uint32_t loam_grid_blocks(uint32_t n_src) {
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (start && stop) {
         if (a.coresident) hipExtLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);
-        else hipExtLaunchKernelGGL((loam_iterate_kernel<10, 1>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);
+        else hipExtLaunchKernelGGL((loam_iterate_kernel<8, 1>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);
         return hipGetLastError();
     }
     if (a.coresident) hipLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(a.n_partials), dim3(256), 0, s, a, k);
-    else hipLaunchKernelGGL((loam_iterate_kernel<10, 1>), dim3(a.n_partials), dim3(256), 0, s, a, k);
+    else hipLaunchKernelGGL((loam_iterate_kernel<8, 1>), dim3(a.n_partials), dim3(256), 0, s, a, k);
     return hipGetLastError();
 }
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s) {
