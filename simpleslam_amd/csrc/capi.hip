@@ -216,7 +216,8 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
 int build_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
     double cell = 1.0;
     if (h->method == kLoam) cell = grid_cell_for(h->prm.loam_knn_max_sq);
-    hipError_t e = h->grid.build(d_dst, n_dst, stride_floats, cell, h->stream, &h->err, 0.0, 0, h->clamp.use ? &h->clamp : nullptr);
+    // (the bounding box of the previous target is tried first: GridIndex::hint_ok)
+    hipError_t e = h->grid.build(d_dst, n_dst, stride_floats, cell, h->stream, &h->err, 0.0, 0, h->clamp.use ? &h->clamp : nullptr, h->method == kLoam);
     if (e != hipSuccess) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     return 0;
@@ -280,8 +281,13 @@ int settle_loam_index(pcr_handle* h, const float* d_src, size_t n_src, size_t st
         GridHeader hdr;
         H_TRY(hipMemcpyAsync(&hdr, h->grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
+        if (hdr.stale) {      // the box taken over from the previous target does not hold this one: fresh box, padded from now on
+            h->grid.hint_margin = 8;
+            if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
+            continue;
+        }
         const int ov = check_grid_overflow(h, hdr.overflow, hdr.n_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
-        if (ov == 0) return 0;
+        if (ov == 0) { h->grid.confirm(); return 0; }
         if (ov == 1) return 1;
     }
     return fail(h, "target index could not be sized");
@@ -368,9 +374,16 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
             continue;
         }
         if (!shard) {
+            if (r.grid_stale) {      // the box taken over from the previous target does not hold this one: fresh box, padded from now on
+                h->grid.hint_margin = 8;
+                if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
+                index_timed = false;
+                continue;
+            }
             int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
             if (ov == 1) return 1;
             if (ov == 2) { index_timed = false; continue; }
+            if (!h->clamp.use) h->grid.confirm();
         }
         memcpy(pose, r.pose, 16 * sizeof(double));
         if (converged) *converged = r.converged;
@@ -477,6 +490,7 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
             if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0) != hipSuccess) return 1;
+            if (l == 0 && hdr0_out) H_TRY(lv[l]->enqueue_density(h->stream));
             H_TRY(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
         H_TRY(hipStreamSynchronize(h->stream));
@@ -561,8 +575,8 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     // with cell^2, and ~10 points per cell put ~4 K candidates into the 27-cell block (measured optimum).  (0.5 m voxels over a 0.5 m-spaced
     // map: cell 1.25 m, 0.74 -> 0.50 ms for 1 M points, the extra index build included.)
     const GridIndex* cov_grid = &h->grid;
-    if (cov_levels(n_dst) == 1 && n_dst > 0 && h->cov_hdr0.sum_sq > 0.f) {
-        const double occ = (double)h->cov_hdr0.sum_sq / (double)n_dst;
+    if (cov_levels(n_dst) == 1 && n_dst > 0 && grid_sum_sq(h->cov_hdr0) > 0.0) {
+        const double occ = grid_sum_sq(h->cov_hdr0) / (double)n_dst;
         const double scale = std::min(8.0, sqrt(10.0 / std::max(occ, 1e-3)));
         if (scale >= 1.3) {
             if (settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * scale)) return 1;

@@ -10,6 +10,7 @@
 // Everything is enqueued on one stream with no host synchronisation; the grid
 // geometry lives in a device-side GridHeader that the later kernels read.
 #include "pcr_internal.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace pcr {
@@ -35,7 +36,7 @@ __device__ inline float wave_max(float v) {
 __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
                                                                float* __restrict__ partials, uint32_t* __restrict__ ticket,
                                                                GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode,
-                                                               const ClampBox clamp) {
+                                                               const ClampBox clamp, int margin_xy) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     // eight independent loads in flight per lane (a 1 M-point cloud is 16-32 MB: this pass should run at HBM speed)
     constexpr int kU = 8;
@@ -102,9 +103,9 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         GridHeader h;
         h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n; h.shift = shift;
         h.empty = 0; h.overflow = 0;
-        h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0; h.sum_sq = 0.f;
+        h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0; h.sum_sq = 0.f; h.sum_sq_u = 0ull;
         h.min_b[0] = h.min_b[1] = h.min_b[2] = 0;
-        h.clamped = (clamp.use && !pcl_mode) ? 1 : 0; h.cut_mask = 0;
+        h.clamped = (clamp.use && !pcl_mode) ? 1 : 0; h.cut_mask = 0; h.stale = 0; h.pad2_ = 0;
         double nc = 1.0;
         for (int d = 0; d < 3; ++d) {
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
                 continue;
             }
             double clo = floor((double)lo / cell - shift), chi = floor((double)hi / cell - shift);
+            if (d < 2 && !h.empty) { clo -= margin_xy; chi += margin_xy; }      // room for the next cloud (see GridIndex::hint_ok)
             h.org[d] = clo - kPad;
             h.origin[d] = (clo - kPad + shift) * cell;
             double dim = chi - clo + 1.0 + 2.0 * kPad;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
     }
 }
 
-__device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key) {
+__device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key, bool* outside = nullptr) {
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) return false;
     if (h.pcl_mode) {
         // ijk = static_cast<int>(std::floor(p * inverse_leaf_size) - static_cast<float>(min_b))   (voxel_grid.hpp)
@@ -154,11 +156,23 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
     // cell index = floor(x / cell) - org.  For a power-of-two cell (LOAM) x / cell is exact and this
     // equals floor((x - origin) / cell); for any other edge (VGICP/NDT resolutions) it is the single
     // definition every kernel uses, so a point and its queries always agree on the cell.
-    const double fx = floor((double)x / h.cell - h.shift) - h.org[0];
-    const double fy = floor((double)y / h.cell - h.shift) - h.org[1];
-    const double fz = floor((double)z / h.cell - h.shift) - h.org[2];
-    if (h.clamped && !(fx >= (double)kPad && fx < (double)(h.dims[0] - kPad) && fy >= (double)kPad && fy < (double)(h.dims[1] - kPad) &&
-                       fz >= (double)kPad && fz < (double)(h.dims[2] - kPad))) return false;      // outside the region of interest
+    double fx, fy, fz;
+    if (h.inv_cell * h.cell == 1.0 && (__double_as_longlong(h.cell) & 0x000fffffffffffffll) == 0) {
+        // a power-of-two edge (every LOAM index): x * (1 / cell) IS x / cell, without three double divisions per point
+        fx = floor((double)x * h.inv_cell - h.shift) - h.org[0];
+        fy = floor((double)y * h.inv_cell - h.shift) - h.org[1];
+        fz = floor((double)z * h.inv_cell - h.shift) - h.org[2];
+    } else {
+        fx = floor((double)x / h.cell - h.shift) - h.org[0];
+        fy = floor((double)y / h.cell - h.shift) - h.org[1];
+        fz = floor((double)z / h.cell - h.shift) - h.org[2];
+    }
+    if (!(fx >= (double)kPad && fx < (double)(h.dims[0] - kPad) && fy >= (double)kPad && fy < (double)(h.dims[1] - kPad) &&
+          fz >= (double)kPad && fz < (double)(h.dims[2] - kPad))) {
+        // outside the region of interest of a clamped index -- or outside a box taken over from the previous build
+        if (outside) *outside = true;
+        return false;
+    }
     const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
     *key = (cz * (uint32_t)h.dims[1] + cy) * (uint32_t)h.dims[0] + cx;
     return true;
@@ -300,7 +314,299 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
     }
 }
 
+
+// ======================================================================================================================
+// Tiled build path (cell tables up to kMaxBins << kMaxTileShift cells): a two-level counting sort with NO global atomic
+// per point.  The one-level path above spends half its time in a million returning atomics on scattered counters, which
+// this multi-XCD part executes at the memory side at ~25 G/s whatever their scope.  Here:
+//   bin    (grid_bin_kernel)    points -> tile = key >> shift (<= kMaxBins tiles of 2^shift consecutive cells); a block
+//                               histograms 4096 points at a time in LDS (LDS atomics return the rank inside the chunk) and
+//                               claims room in each tile it touched with ONE global atomic: a few dozen per 4096 points for
+//                               a cloud stored in any spatially coherent order, <= kMaxBins in the worst case.
+//   place  (grid_place_kernel)  every block scans the tile counters (<= 32 KB, redundantly: no extra launch) and moves each
+//                               point to its slot of its tile: the cloud grouped by tile, 16 B read + 16 B written per point.
+//   tile   (grid_tile_kernel)   one block per tile: histogram of the tile's cells in LDS, exclusive scan -> cell_start of
+//                               those cells (every cell of the table is written exactly once: no scan pass over the table, no
+//                               clearing), points to their final position.  16 B read + 16 B written per point.
+// The order of the points inside a cell depends on the arrival order of LDS atomics, as it depended on the order of the
+// global ones before: nothing downstream may depend on it, and nothing does (searches break distance ties on the
+// original index in .w; voxel statistics are fixed-point sums).
+// ======================================================================================================================
+static constexpr int kBinStride = 16;                  // counters 64 bytes apart: memory-side atomics on one line serialise
+static constexpr int kBinPer = 16;                    // points per thread and chunk of the bin kernel
+static constexpr int kBinChunk = 256 * kBinPer;       // points a block histograms at a time
+
+template <bool kVec>
+__device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i, uint32_t stride, float& x, float& y, float& z) {
+    if (kVec) { const float4 v = *reinterpret_cast<const float4*>(pts + i * stride); x = v.x; y = v.y; z = v.z; }
+    else { const float* p = pts + i * stride; x = p[0]; y = p[1]; z = p[2]; }
+}
+
+// dynamic LDS: max_bins counters (max_bins = tiles the cell table's capacity can make: host-known)
+template <bool kVec>
+__global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
+                                                       uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    uint32_t* const hist = dyn_lds;
+    const GridHeader h = *hdr;
+    if (h.overflow || h.empty) return;
+    for (uint32_t b = threadIdx.x; b < max_bins; b += 256) hist[b] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t c0 = blockIdx.x * kBinChunk; c0 < n; c0 += gridDim.x * kBinChunk) {
+        uint32_t bin[kBinPer], loc[kBinPer];
+        bool first[kBinPer];
+        float px[kBinPer], py[kBinPer], pz[kBinPer];
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) {      // all loads of the chunk in flight
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) {
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            uint32_t key;
+            bin[u] = 0xffffffffu; loc[u] = 0u;
+            bool outside = false;
+            if (i < n && point_key(h, px[u], py[u], pz[u], &key, &outside)) bin[u] = key >> shift;
+            if (outside && !h.clamped) hdr->stale = 1;      // (only a box reused from the previous build can be too small)
+            // one LDS atomic per RUN of equal tiles in consecutive lanes (a cloud stored in a spatially coherent order puts
+            // whole waves into one tile: 64 same-address atomics would serialise)
+            const uint32_t prev = __shfl_up(bin[u], 1, 64);
+            const bool leader = lane == 0 || prev != bin[u];
+            const unsigned long long lead = __ballot(leader);
+            const unsigned long long below = lead & (~0ull >> (63 - lane));
+            const int start = 63 - __clzll(below);
+            const unsigned long long above = lane == 63 ? 0ull : (lead >> (lane + 1)) << (lane + 1);
+            const int end = above ? __ffsll((long long)above) - 1 : 64;
+            uint32_t base = 0;
+            if (leader && bin[u] != 0xffffffffu) base = atomicAdd(&hist[bin[u]], (uint32_t)(end - start));
+            first[u] = leader && bin[u] != 0xffffffffu && base == 0u;      // this lane opened the tile in this chunk
+            base = __shfl(base, start, 64);
+            loc[u] = base + (uint32_t)(lane - start);
+        }
+        __syncthreads();
+        // the lane that opened a tile claims room for all the chunk's points of that tile: one global atomic per (chunk, tile)
+        uint32_t cnt[kBinPer], got[kBinPer];
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) cnt[u] = first[u] ? hist[bin[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) got[u] = first[u] ? atomicAdd(&bin_count[(size_t)bin[u] * kBinStride], cnt[u]) : 0u;      // (all in flight together)
+        __syncthreads();      // every count has been read
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) if (first[u]) hist[bin[u]] = got[u];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) {
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            if (i < n) slot[i] = bin[u] != 0xffffffffu ? hist[bin[u]] + loc[u] : 0xffffffffu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) if (first[u]) hist[bin[u]] = 0u;      // ready for the next chunk
+        __syncthreads();
+    }
+}
+
+// exclusive scan of the tile counters into LDS (every block, redundantly); sh_start[nbins] = total
+__device__ inline void scan_bins_to_lds(const uint32_t* __restrict__ bin_count, uint32_t nbins, uint32_t* sh_start, uint32_t* sh4) {
+    // thread t owns the counters [t * per, t * per + per)
+    const uint32_t per = (nbins + 255u) / 256u;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; ++j) if (b0 + j < nbins) sum += bin_count[(size_t)(b0 + j) * kBinStride];
+    uint32_t total;
+    uint32_t off = block_exclusive_scan_256(sum, &total, sh4);
+    for (uint32_t j = 0; j < per; ++j) {
+        if (b0 + j < nbins) { sh_start[b0 + j] = off; off += bin_count[(size_t)(b0 + j) * kBinStride]; }      // (L1 hit)
+    }
+    if (threadIdx.x == 255) sh_start[nbins] = total;
+    __syncthreads();
+}
+
+template <bool kVec>
+__global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, const GridHeader* __restrict__ hdr,
+                                                         const uint32_t* __restrict__ bin_count, const uint32_t* __restrict__ slot,
+                                                         uint32_t* __restrict__ bin_start, float4* __restrict__ tiled, int shift) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    uint32_t* const sh_start = dyn_lds;      // max_bins + 1 entries
+    __shared__ uint32_t sh4[4];
+    const GridHeader h = *hdr;
+    if (h.overflow || h.empty) return;
+    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
+    constexpr int kPer = 4;
+    float px[kPer], py[kPer], pz[kPer];
+    uint32_t sl[kPer];
+    // the first chunk's points are requested BEFORE the scan of the tile counters: two independent memory round trips overlap
+    uint32_t c0 = blockIdx.x * (256 * kPer);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const uint32_t i = c0 + u * 256 + threadIdx.x;
+        load_xyz<kVec>(pts, i < n ? i : 0u, stride, px[u], py[u], pz[u]);
+        sl[u] = i < n ? slot[i] : 0xffffffffu;
+    }
+    scan_bins_to_lds(bin_count, nbins, sh_start, sh4);
+    if (blockIdx.x == 0) {      // the tile kernel wants the starts too
+        for (uint32_t b = threadIdx.x; b <= nbins; b += 256) bin_start[b] = sh_start[b];
+    }
+    for (; c0 < n; c0 += gridDim.x * (256 * kPer)) {
+        if (c0 != blockIdx.x * (256 * kPer)) {
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const uint32_t i = c0 + u * 256 + threadIdx.x;
+                load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
+                sl[u] = i < n ? slot[i] : 0xffffffffu;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            uint32_t key;
+            if (sl[u] != 0xffffffffu && point_key(h, px[u], py[u], pz[u], &key))
+                tiled[sh_start[key >> shift] + sl[u]] = make_float4(px[u], py[u], pz[u], __uint_as_float(i));
+        }
+    }
+}
+
+// One block per tile.  Dynamic LDS: the tile's cell histogram (2^shift counters).  A tile of up to 256 * kTilePer points
+// is held in registers between the two passes (all its loads in flight at once); a larger one goes through the generic loop
+// (ranks parked in global scratch).
+static constexpr int kTilePer = 16;
+
+__global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
+                                                        uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
+                                                        float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    uint32_t* const hist = dyn_lds;                    // 1 << shift
+    __shared__ uint32_t sh4[4];
+    __shared__ unsigned long long sh_sq[4];
+    const GridHeader h = *hdr_in;
+    if (h.overflow || h.empty) return;
+    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
+    const uint32_t S = 1u << shift;
+    for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) {
+        const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
+        const uint64_t cell0 = (uint64_t)tile << shift;
+        const bool small = np <= 256u * kTilePer;      // block-uniform
+        float4 p[kTilePer];
+        uint32_t cr[kTilePer];
+        if (small) {
+#pragma unroll
+            for (int u = 0; u < kTilePer; ++u) {      // all loads in flight, issued before anything waits
+                const uint32_t j = u * 256u + threadIdx.x;
+                if (u * 256u < np) p[u] = tiled[p0 + (j < np ? j : 0u)];
+            }
+        }
+        for (uint32_t c = threadIdx.x * 4u; c < S; c += 1024u) *reinterpret_cast<uint4*>(hist + c) = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;      // the counters are left zeroed: the state the next build expects
+        __syncthreads();
+        if (small) {
+#pragma unroll
+            for (int u = 0; u < kTilePer; ++u) {
+                const uint32_t j = u * 256u + threadIdx.x;
+                cr[u] = 0u;
+                if (j < np) {
+                    uint32_t key = 0;
+                    point_key(h, p[u].x, p[u].y, p[u].z, &key);
+                    const uint32_t c = key - (uint32_t)cell0;
+                    cr[u] = (c << 18) | atomicAdd(&hist[c], 1u);          // c < 2^13, rank < 4096 <= 2^18
+                }
+            }
+        } else {
+            for (uint32_t j0 = 0; j0 < np; j0 += 256u * kTilePer) {      // chunks of 4096 points, their loads in flight together
+#pragma unroll
+                for (int u = 0; u < kTilePer; ++u) { const uint32_t j = j0 + u * 256u + threadIdx.x; p[u] = tiled[p0 + (j < np ? j : 0u)]; }
+#pragma unroll
+                for (int u = 0; u < kTilePer; ++u) {
+                    const uint32_t j = j0 + u * 256u + threadIdx.x;
+                    if (j < np) {
+                        uint32_t key = 0;
+                        point_key(h, p[u].x, p[u].y, p[u].z, &key);
+                        scratch_rank[p0 + j] = atomicAdd(&hist[key - (uint32_t)cell0], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the tile's counters -> cell_start (+ sum of count^2, the density estimate of the header)
+        unsigned long long sq = 0;
+        uint32_t carry = 0;
+        for (uint32_t cb = 0; cb < S; cb += 1024) {
+            const uint32_t c = cb + threadIdx.x * 4;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < S) v = *reinterpret_cast<const uint4*>(hist + c);
+            sq += (unsigned long long)v.x * v.x + (unsigned long long)v.y * v.y + (unsigned long long)v.z * v.z + (unsigned long long)v.w * v.w;
+            uint32_t tot;
+            const uint32_t o = block_exclusive_scan_256(v.x + v.y + v.z + v.w, &tot, sh4) + carry;
+            __syncthreads();      // sh4 is reused by the next round
+            if (c < S) {
+                const uint4 st = make_uint4(o, o + v.x, o + v.x + v.y, o + v.x + v.y + v.z);
+                *reinterpret_cast<uint4*>(hist + c) = st;                                     // hist now holds the offsets inside the tile
+                const uint64_t g = cell0 + c;
+                if (g + 3 <= h.n_cells) *reinterpret_cast<uint4*>(cell_start + g) = make_uint4(p0 + st.x, p0 + st.y, p0 + st.z, p0 + st.w);
+                else {
+                    const uint32_t e[4] = {p0 + st.x, p0 + st.y, p0 + st.z, p0 + st.w};
+                    for (int k = 0; k < 4; ++k) if (g + k <= h.n_cells) cell_start[g + k] = e[k];      // (entry n_cells = number of indexed points)
+                }
+            }
+            carry += tot;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+        if ((threadIdx.x & 63) == 0) sh_sq[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        // (one 8-byte store per tile; thousands of blocks adding into one header word serialise at the memory side for ~45 us)
+        if (threadIdx.x == 0) tile_sq[tile] = sh_sq[0] + sh_sq[1] + sh_sq[2] + sh_sq[3];
+        if (small) {
+#pragma unroll
+            for (int u = 0; u < kTilePer; ++u) {
+                const uint32_t j = u * 256u + threadIdx.x;
+                if (j < np) sorted[p0 + hist[cr[u] >> 18] + (cr[u] & 0x3ffffu)] = p[u];
+            }
+        } else {
+            for (uint32_t j0 = 0; j0 < np; j0 += 256u * kTilePer) {
+#pragma unroll
+                for (int u = 0; u < kTilePer; ++u) {
+                    const uint32_t j = j0 + u * 256u + threadIdx.x;
+                    p[u] = tiled[p0 + (j < np ? j : 0u)];
+                    cr[u] = scratch_rank[p0 + (j < np ? j : 0u)];
+                }
+#pragma unroll
+                for (int u = 0; u < kTilePer; ++u) {
+                    const uint32_t j = j0 + u * 256u + threadIdx.x;
+                    if (j < np) {
+                        uint32_t key = 0;
+                        point_key(h, p[u].x, p[u].y, p[u].z, &key);
+                        sorted[p0 + hist[key - (uint32_t)cell0] + cr[u]] = p[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// sum of count^2 over the cells = sum of the tiles' sums -> header (only VGICP's choice of a search cell reads it)
+__global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restrict__ hdr, const unsigned long long* __restrict__ tile_sq, int shift) {
+    __shared__ unsigned long long sh[4];
+    if (hdr->overflow || hdr->empty) return;
+    const uint32_t nbins = (uint32_t)(hdr->n_cells >> shift) + 1u;
+    unsigned long long s = 0;
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) s += tile_sq[b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) hdr->sum_sq_u = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // ---- host side ----------------------------------------------------------------------
+hipError_t GridIndex::enqueue_density(hipStream_t s) {
+    if (tiled_shift < 0) return hipSuccess;      // the atomic build path leaves its estimate in header.sum_sq
+    hipLaunchKernelGGL(grid_density_kernel, dim3(1), dim3(256), 0, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), tiled_shift);
+    return hipGetLastError();
+}
+
 hipError_t DeviceBuf::reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
     release();
@@ -318,6 +624,7 @@ void DeviceBuf::release() {
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
     bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
+    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release();
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -346,8 +653,9 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 #define PCR_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { if (err) *err = std::string(#x) + ": " + hipGetErrorString(_e); return _e; } } while (0)
 
 hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift,
-                            int pcl_mode, const ClampBox* clamp) {
+                            int pcl_mode, const ClampBox* clamp, bool allow_hint) {
     valid = false;
+    const bool force_atomic_path = getenv("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
     PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
@@ -373,8 +681,57 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     if (clamp) cb = *clamp;
     const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
     const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);
-    hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
-                       ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode, cb);
+    // tile size: see below
+    int tshift = 8;
+    while (((uint64_t)cell_capacity >> tshift) + 2 > 2048 && tshift < 11) ++tshift;
+    if (const char* e = getenv("PCR_TILE_SHIFT")) tshift = atoi(e);      // (development: tile size sweep)
+    while (((uint64_t)cell_capacity >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
+    const bool tiled_path = tshift <= kMaxTileShift && !force_atomic_path;
+    const bool reuse_header = allow_hint && hint_ok && tiled_path && !pcl_mode && shift == 0.0 && !cb.use && hint_cell == cell && tiled_shift == tshift;
+    hint_ok = false;      // until the host has seen this build's header (confirm())
+    used_hint = reuse_header;
+    hint_cell = cell;
+    if (!reuse_header)
+        hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
+                           ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode, cb,
+                           (allow_hint && !pcl_mode && shift == 0.0 && !cb.use) ? hint_margin : 0);
+    // Tile size from the CAPACITY of the cell table (the device-side cell count never exceeds it: a larger box is an overflow):
+    // ~2048 tiles when the table allows it -- 8 KB of LDS counters per block in the bin kernel, tiles of a few hundred to a few
+    // thousand points -- never more than kMaxBins.
+    if (tiled_path) {
+        const uint32_t max_bins = (uint32_t)(((uint64_t)cell_capacity >> tshift) + 2);
+        PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
+        PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
+        PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));
+        tiled_shift = tshift;
+        if (!bin_count.p) {
+            PCR_TRY(bin_count.reserve(((size_t)kMaxBins + 64) * kBinStride * sizeof(uint32_t)));
+            PCR_TRY(hipMemsetAsync(bin_count.p, 0, bin_count.cap, s));      // builds expect and leave the counters zeroed
+        }
+        const bool vec = (stride_floats % 4 == 0) && ((uintptr_t)d_pts % 16 == 0);
+        const int bin_blocks = (int)std::min<size_t>(2048, (n + kBinChunk - 1) / kBinChunk ? (n + kBinChunk - 1) / kBinChunk : 1);
+        const int place_blocks = (int)std::min<size_t>(2048, (n + 1023) / 1024 ? (n + 1023) / 1024 : 1);
+        const int tile_blocks = (int)max_bins;
+        const size_t bin_lds = (size_t)max_bins * 4, place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
+        if (vec) {
+            hipLaunchKernelGGL(grid_bin_kernel<true>, dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
+                               ranks.as<uint32_t>(), tshift, max_bins);
+            hipLaunchKernelGGL(grid_place_kernel<true>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
+                               ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
+        } else {
+            hipLaunchKernelGGL(grid_bin_kernel<false>, dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
+                               ranks.as<uint32_t>(), tshift, max_bins);
+            hipLaunchKernelGGL(grid_place_kernel<false>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
+                               ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
+        }
+        hipLaunchKernelGGL(grid_tile_kernel, dim3(tile_blocks), dim3(256), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), bin_start.as<uint32_t>(),
+                           bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift);
+        PCR_TRY(hipGetLastError());
+        n_points = n;
+        valid = true;
+        return hipSuccess;
+    }
+    tiled_shift = -1;
     hipLaunchKernelGGL(grid_count_kernel, dim3(pt_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(),
                        cell_count.as<uint32_t>(), keys.as<uint32_t>(), ranks.as<uint32_t>());
     const int scan_blocks = (int)((cell_capacity + kScanTile - 1) / kScanTile);

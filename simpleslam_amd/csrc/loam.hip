@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(256) void loam_finalize_kernel(const LoamArgs a, co
         for (int i = 0; i < 16; ++i) r->pose[i] = T[i];
         r->converged = cur->converged; r->iters_run = cur->iters_run; r->fail = cur->fail;
         r->grid_overflow = a.grid.hdr->overflow; r->grid_empty = a.grid.hdr->empty; r->grid_cells = a.grid.hdr->n_cells;
+        r->grid_stale = a.grid.hdr->stale; r->pad2 = 0;
         // completion marker: the host polls this word of host-mapped memory, so everything above has to be visible first
         __threadfence_system();
         __hip_atomic_store(&r->pad, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -36,11 +36,16 @@ struct GridHeader {
     float inv_leaf_f;
     int32_t min_b[3];
     int32_t too_fine;        // pcl_mode: more than INT_MAX voxels ("Leaf size is too small", voxel_grid.hpp)
-    float sum_sq;            // sum over the cells of count^2 (written by the scan): sum_sq / points = occupancy of the cell a
-                             // point lives in, averaged over the points -- the density estimate behind the choice of a search cell
+    float sum_sq;            // sum over the cells of count^2 (written by the scan of the atomic build path): sum_sq / points =
+                             // occupancy of the cell a point lives in, averaged over the points -- the density estimate behind the
+                             // choice of a search cell.  The tiled build path accumulates the same sum exactly in sum_sq_u.
     int32_t clamped;         // the box was cut to a region of interest (ClampBox): points outside it are not indexed
     int32_t cut_mask;        // clamped: bit d = the lower face of axis d was cut (target points lie beyond it), bit 3 + d = the upper
+    unsigned long long sum_sq_u;
+    int32_t stale;           // the header was reused from the previous build (bounding-box hint) and a point of the new cloud lies
+    int32_t pad2_;           // outside its box: the index is incomplete, the caller rebuilds with a fresh box
 };
+__host__ __device__ inline double grid_sum_sq(const GridHeader& h) { return h.sum_sq_u ? (double)h.sum_sq_u : (double)h.sum_sq; }
 
 // Region of interest for an index whose full bounding box cannot be tabulated (a far outlier in the cloud): see capi.hip
 struct ClampBox { double lo[3], hi[3]; int32_t use, pad_; };
@@ -84,6 +89,7 @@ struct LoamResult {          // written by the finalize launch into host-mapped 
     double pose[16];         // after T2SE3
     int32_t converged, iters_run, fail, grid_overflow, grid_empty, pad;
     uint64_t grid_cells;     // cells the target needs (to grow the table on overflow)
+    int32_t grid_stale, pad2;
 };
 
 struct LoamTrace {           // per consumed linearisation
@@ -135,8 +141,21 @@ struct DeviceBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+static constexpr int kMaxBins = 8192;    // tiles of the tiled build path (grid_index.hip): one 32 KB LDS histogram
+static constexpr int kMaxTileShift = 13; // a tile's cells are histogrammed in LDS too
+
 struct GridIndex {
     DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header, keys, ranks, ticket;
+    DeviceBuf tiled, bin_count, bin_start, tile_sq;      // tiled build path: points grouped by tile, points per tile, first point of every tile, sum of count^2 per tile
+    int tiled_shift = -1;                       // log2(cells per tile) of the last build when it took the tiled path
+    // Bounding-box hint: a build whose header the host has seen to be good (confirm()) lets the NEXT build of the same kind skip
+    // the bounding-box pass and reuse that header -- a sub-map changes by a key frame at a time.  The bin kernel checks every
+    // point against the box; one outside sets header.stale and the caller rebuilds with a fresh (and from then on padded) box.
+    bool hint_ok = false;
+    double hint_cell = 0.0;
+    int hint_margin = 0;                        // cells added around a fresh box in x and y (0 until a hint has failed once)
+    bool used_hint = false;                     // the last build() reused the header
+    void confirm() { hint_ok = valid && tiled_shift >= 0; }
     size_t cell_capacity = 0;   // entries available in cell_count / cell_start
     size_t n_points = 0;
     bool valid = false;
@@ -146,9 +165,11 @@ struct GridIndex {
     // Enqueue the build of the index over n points (device pointer, stride in floats).
     // No host synchronisation unless the cell table must grow.  cell = grid edge.
     hipError_t build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s,
-                     std::string* err, double shift = 0.0, int pcl_mode = 0, const ClampBox* clamp = nullptr);
+                     std::string* err, double shift = 0.0, int pcl_mode = 0, const ClampBox* clamp = nullptr, bool allow_hint = false);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
+    // header.sum_sq_u <- sum over the cells of count^2 (enqueued; VGICP reads it back with the header)
+    hipError_t enqueue_density(hipStream_t s);
     void release();
 };
 

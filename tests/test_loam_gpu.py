@@ -537,3 +537,41 @@ def test_cut_index_is_widened_when_a_query_reaches_its_edge(gpu, world_small):
     po, co, _ = oracle.loam_scan2map(w["scan"], m, w["init"])
     dt, dr = synth.pose_error(p, po)
     assert co == c_ref and dt < 1e-9 and dr < 1e-9
+
+
+def test_bounding_box_of_the_previous_target_is_a_hint_not_a_promise(gpu, world_small):
+    """scan2Map rebuilds the index on every call (LoamRegister.cpp:110) but first tries the previous target's bounding box
+    instead of measuring the new cloud's (one pass over the map saved).  Every point is checked against that box while it is
+    binned; a target that has grown past it is indexed again with a box of its own -- the answer is that of a fresh handle."""
+    w = world_small
+    reg = LoamRegister()
+    fresh = lambda m, p0: (lambda r, p: (r.scan2Map(w["scan"], m, p), p))(LoamRegister(), p0.copy())
+    c0, p_ref = fresh(w["map"], w["init"])
+    for _ in range(3):                                             # same target again and again: the hint holds
+        p = w["init"].copy()
+        assert reg.scan2Map(w["scan"], w["map"], p) == c0
+        np.testing.assert_array_equal(p, p_ref)
+    assert reg.stats()["attempts"] == 1
+    # the target moves / grows out of the old box: points 40 m beyond it in x and y, and some below it
+    extra = w["map"][:2000].copy()
+    extra[:, 0] += w["map"][:, 0].max() - w["map"][:, 0].min() + 40.0
+    extra[:1000, 1] -= 55.0
+    extra[1000:, 2] -= 9.0
+    grown = np.ascontiguousarray(np.vstack([w["map"], extra]))
+    c1, p1_ref = fresh(grown, w["init"])
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], grown, p) == c1
+    assert reg.stats()["attempts"] == 2                           # the stale box was noticed and the call redone
+    np.testing.assert_array_equal(p, p1_ref)
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], grown, p) == c1
+    assert reg.stats()["attempts"] == 1
+    np.testing.assert_array_equal(p, p1_ref)
+    # back to the smaller cloud: it fits the larger box, which only leaves cells empty
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], w["map"], p) == c0
+    assert reg.stats()["attempts"] == 1
+    np.testing.assert_array_equal(p, p_ref)
+    # an empty target inside a hinted box is still an empty target
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], np.zeros((0, 4), np.float32), p) is False
