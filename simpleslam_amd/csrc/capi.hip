@@ -315,14 +315,21 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
                     GridHeader dh;
                     memset(&dh, 0, sizeof dh);
                     dh.overflow = 1; dh.empty = 1; dh.cell = dh.inv_cell = 1.0; dh.n_cells = 1;
-                    if (h->dummy_grid.reserve(sizeof dh) != hipSuccess || hipMemcpy(h->dummy_grid.p, &dh, sizeof dh, hipMemcpyHostToDevice) != hipSuccess)
+                    // (the header is followed by a few zero words that stand in for the cell table and the point array)
+                    if (h->dummy_grid.reserve(sizeof dh + 1024) != hipSuccess || hipMemset(h->dummy_grid.p, 0, sizeof dh + 1024) != hipSuccess ||
+                        hipMemcpy(h->dummy_grid.p, &dh, sizeof dh, hipMemcpyHostToDevice) != hipSuccess)
                         return fail(h, rank_err + " (and no memory for the stand-in header: the other ranks of this call will hang)");
                 }
             }
         }
         LoamArgs a;
         fill_loam_args(h, &a, d_src, n_src, stride_floats, pose);
-        if (rank_fail) { a.grid.hdr = h->dummy_grid.as<GridHeader>(); a.grid.pts = nullptr; a.grid.cell_start = nullptr; a.rank_fail = 1; a.nn_cache = nullptr; }
+        if (rank_fail) {
+            a.grid.hdr = h->dummy_grid.as<GridHeader>();
+            a.grid.pts = reinterpret_cast<const float4*>(h->dummy_grid.as<char>() + 512);
+            a.grid.cell_start = reinterpret_cast<const uint32_t*>(h->dummy_grid.as<char>() + 512);
+            a.rank_fail = 1; a.nn_cache = nullptr;
+        }
         if (shard) a.reduced = h->host_ar ? h->red_dev : h->loam_reduced.as<double>();
         h->result_host->pad = 0;
         if (h->profile >= 1 && !index_timed) { H_TRY(hipEventRecord(h->ev_start, h->stream)); H_TRY(hipEventRecord(h->ev_index, h->stream)); }

@@ -157,33 +157,45 @@ __device__ __forceinline__ uint32_t knn_cursor_step(KnnCursor& c, const KnnRuns&
     return pos;
 }
 
-template <int kGroup>
-__device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                        float qxf, float qyf, float qzf, float gate_f, bool active, KnnRuns& sh, uint32_t part, uint32_t parts_log2,
-                                        uint32_t key[kNb], uint32_t* idmask_out, unsigned long long* tl) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < kNb; ++j) key[j] = kKeyEmpty;
-    *idmask_out = 0u;
+// The 18 range look-ups of a query's 3x3x3 block.  A lane that will search its OWN query requests them as soon as it knows that
+// its cached neighbours do not hold (the round trip then overlaps the posting of the misses).
+struct KnnRanges { uint32_t ra[9], rb[9]; bool inside; };
+
+__device__ __forceinline__ void knn_ranges_issue(const GridHeader& h, const uint32_t* __restrict__ cell_start, float qxf, float qyf, float qzf, bool active,
+                                                 KnnRanges& g) {
     const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
     // cell coordinates (exact: q is a float widened to double, origin a multiple of cell)
     const double rx = qx - h.origin[0], ry = qy - h.origin[1], rz = qz - h.origin[2];
     const double fx = floor(rx * h.inv_cell), fy = floor(ry * h.inv_cell), fz = floor(rz * h.inv_cell);
     // queries in the outermost cell (or beyond, or NaN) are >= one cell away from every point
-    const bool inside = active && (fx >= 1.0 && fx <= (double)(h.dims[0] - 2) && fy >= 1.0 && fy <= (double)(h.dims[1] - 2) &&
-                                   fz >= 1.0 && fz <= (double)(h.dims[2] - 2));
+    g.inside = active && (fx >= 1.0 && fx <= (double)(h.dims[0] - 2) && fy >= 1.0 && fy <= (double)(h.dims[1] - 2) &&
+                          fz >= 1.0 && fz <= (double)(h.dims[2] - 2));
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {   // 18 independent loads in flight
+        uint32_t ck = ((uint32_t)(cz + row_dz(r)) * (uint32_t)h.dims[1] + (uint32_t)(cy + row_dy(r))) * (uint32_t)h.dims[0] + (uint32_t)cx;
+        ck = g.inside ? ck : 1u;      // the others read the first entries of the table (unconditional loads; never outside it)
+        g.ra[r] = cell_start[ck - 1]; g.rb[r] = cell_start[ck + 2];
+    }
+}
+
+template <int kGroup>
+__device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                        float qxf, float qyf, float qzf, float gate_f, bool active, KnnRuns& sh, uint32_t part, uint32_t parts_log2,
+                                        uint32_t key[kNb], uint32_t* idmask_out, unsigned long long* tl, const KnnRanges* pre = nullptr) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kNb; ++j) key[j] = kKeyEmpty;
+    *idmask_out = 0u;
+    KnnRanges g;
+    if (pre) g = *pre;
+    else knn_ranges_issue(h, cell_start, qxf, qyf, qzf, active && !h.empty && !h.overflow, g);
+    const bool inside = g.inside && active;
     uint32_t n_runs = 0, total = 0;
     if (inside) {
-        const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-        uint32_t ra[9], rb[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {   // 18 independent loads in flight
-            const uint32_t ck = ((uint32_t)(cz + row_dz(r)) * (uint32_t)h.dims[1] + (uint32_t)(cy + row_dy(r))) * (uint32_t)h.dims[0] + (uint32_t)cx;
-            ra[r] = cell_start[ck - 1]; rb[r] = cell_start[ck + 2];
-        }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            if (rb[r] > ra[r]) { sh.run[n_runs][tid] = make_uint2(ra[r], rb[r]); ++n_runs; total += rb[r] - ra[r]; }
+            if (g.rb[r] > g.ra[r]) { sh.run[n_runs][tid] = make_uint2(g.ra[r], g.rb[r]); ++n_runs; total += g.rb[r] - g.ra[r]; }
         }
     }
 #pragma unroll
@@ -259,22 +271,18 @@ __device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __res
 
 // sequence number of a candidate in the lane's stream -> position in the cell-sorted array (the lane's run table is still in LDS)
 __device__ __forceinline__ void knn_decode(const KnnRuns& sh, int tid, const uint32_t key[kNb], uint32_t idmask, uint32_t pos[kNb]) {
-    uint2 r[9];
+    // run t holds the sequence numbers [P_t, P_t + len_t): position = sequence number + (start_t - P_t) of the last run with P_t <= it
+    uint32_t P[9], off[9];
+    uint32_t acc = 0;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) r[t] = sh.run[t][tid];
+    for (int t = 0; t < 9; ++t) { const uint2 r = sh.run[t][tid]; P[t] = acc; off[t] = r.x - acc; acc += r.y - r.x; }
 #pragma unroll
     for (int j = 0; j < kNb; ++j) {
-        uint32_t rem = key[j] & idmask, p = kNoPos;
-        bool found = key[j] == kKeyEmpty;
+        const uint32_t seq = key[j] & idmask;
+        uint32_t o = off[0];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const uint32_t len = r[t].y - r[t].x;
-            const bool in = !found && rem < len;
-            p = in ? r[t].x + rem : p;
-            found = found || in;
-            rem -= found ? 0u : len;
-        }
-        pos[j] = p;
+        for (int t = 1; t < 9; ++t) o = seq >= P[t] ? off[t] : o;      // (the empty runs past the last real one have P_t = total > seq)
+        pos[j] = key[j] == kKeyEmpty ? kNoPos : seq + o;
     }
 }
 
@@ -613,6 +621,13 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     const int tid = threadIdx.x;
     // ---- post the queries that need a search ----
     const bool miss = active && !hit;
+    // (its row ranges are requested now, for the case that this lane ends up searching its own query: the round trip overlaps the
+    //  posting and the barriers)
+    KnnRanges own_ranges;
+    own_ranges.inside = false;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { own_ranges.ra[r] = 0u; own_ranges.rb[r] = 0u; }
+    if (__any(miss)) knn_ranges_issue(h, a.grid.cell_start, px, py, pz, miss, own_ranges);      // (wave-uniform: nothing is loaded in an all-hit wave)
     if (tid == 0) ex.count = 0;
     __syncthreads();
     if (miss) {
@@ -633,6 +648,9 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     if (tl) tl[2] = wall_clock64();
     // ---- the posted queries are searched: a few -> one wave per query (lanes = candidates); many -> thread m
     //      serves the m-th posted query (lanes = queries) ----
+    bool self = false;
+    uint32_t self_pos[kNb], self_state = 0u;
+    double self_bound = 0.0;
     {
         const uint32_t n_miss = ex.count;           // block-uniform
         bool dense = n_miss > (uint32_t)kSparseMisses;
@@ -659,11 +677,21 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             dense = ex.fallback != 0;               // a cell block too crowded for the wave table: redo all of them per lane
             __syncthreads();
         }
-        if (n_miss && dense) {
+        if (n_miss > 128u && dense) {
+            // more than half the block: every lane searches its OWN query (a compaction would not free a single wave), with the
+            // ranges it asked for before the barrier and without the trip through the exchange
+            self = true;
+            uint32_t key[kNb], idmask = 0u;
+            const float gate_f = __double2float_ru(a.c.knn_max_sq * (1.0 + 1e-5));      // every candidate inside the gate has a float distance <= this
+            const int rc = knn_scan<kGroup>(h, a.grid.pts, a.grid.cell_start, px, py, pz, gate_f, miss, sh, 0u, 0u, key, &idmask, tl, &own_ranges);
+            knn_decode(sh, tid, key, idmask, self_pos);
+            self_bound = knn_list_bound(key, idmask);
+            self_state = rc == 0 ? 0u : (rc == 2 ? 3u : 1u);
+        } else if (n_miss && dense) {
             // A block with few misses would leave three of its four waves idle while one wave walks whole streams: up to 64
             // (128) posted queries are searched by four (two) lanes each, in different waves, every lane taking its slice of
             // the query's candidate stream; the lists are merged through LDS.
-            const uint32_t pl2 = n_miss <= 64u ? 2u : (n_miss <= 128u ? 1u : 0u);
+            const uint32_t pl2 = n_miss <= 64u ? 2u : 1u;
             const uint32_t per = 256u >> pl2;                          // lanes per part
             const uint32_t m = (uint32_t)tid & (per - 1u), part = (uint32_t)tid >> (8u - pl2);
             const bool worker = m < n_miss;
@@ -708,9 +736,9 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     if (miss) {
         uint32_t rp[kNb];
 #pragma unroll
-        for (int j = 0; j < kNb; ++j) rp[j] = ex.u.res.pos[j][tid];
-        bound_sq = ex.u.res.bound[tid];
-        uint32_t state = ex.u.res.state[tid];
+        for (int j = 0; j < kNb; ++j) rp[j] = self ? self_pos[j] : ex.u.res.pos[j][tid];
+        bound_sq = self ? self_bound : ex.u.res.bound[tid];
+        uint32_t state = self ? self_state : ex.u.res.state[tid];
         searched = state != 0u;
         float4 p8[kNb];
 #pragma unroll
