@@ -72,6 +72,20 @@ def lib():
     return _lib
 
 
+def set_variant(which, value):
+    """Switch one of the two UNPINNED readings of the reference (see oracle_set_variant in loam_oracle.c) to its alternative:
+    which 0 = LOAM weight roots in double, 1 = NDT rotation() as Eigen's polar factor.  Measurement aid; default 0 = the reading the
+    HIP path implements."""
+    L = lib()
+    L.oracle_set_variant.argtypes = [C.c_int, C.c_int]
+    L.oracle_set_variant.restype = None
+    L.oracle_set_variant(int(which), int(value))
+    try:
+        _nd().oracle_set_variant  # same shared object
+    except Exception:
+        pass
+
+
 def _f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     assert a.ndim == 2 and a.shape[1] >= 3
@@ -220,8 +234,46 @@ def ref_lib():
         R.ref_kd_build.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         R.ref_kd_free.argtypes = [C.c_void_p]
         R.ref_kd_knn_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        for f in ("ref_kd_radius", "ref_kfs_radius", "ref_kfs_nearest", "ref_vov_knn"):
+            getattr(R, f).restype = C.c_size_t
+        R.ref_kd_radius.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        R.ref_kfs_radius.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_size_t]
+        R.ref_kfs_nearest.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        R.ref_vov_knn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _ref = R
     return _ref
+
+
+def ref_radius(pts, query, radius, sorted_=False):
+    """PointCloudKdtree::radiusSearch (pcl_adaptor.hpp:60-78) through the reference's nanoflann: indices and squared distances as returned."""
+    pts = _f32(pts)
+    R = ref_lib()
+    h = R.ref_kd_build(_p(pts), pts.shape[0], pts.shape[1])
+    q = np.ascontiguousarray(query, np.float64).reshape(3)
+    idx, d2 = np.zeros(pts.shape[0], np.uint64), np.zeros(pts.shape[0])
+    n = R.ref_kd_radius(h, _p(q), float(radius), int(sorted_), _p(idx), _p(d2), pts.shape[0])
+    R.ref_kd_free(h)
+    return idx[:n].astype(np.int64), d2[:n].copy()
+
+
+def ref_keyframes_radius(positions, query, radius):
+    """KeyFramesKdtree::radiusSearch (kfs_adaptor.hpp:57-75, compiled as it lies) as MapManager::updateMap calls it
+    (frontend/src/MapManager.cpp:176-177): key-frame indices in the order the tree returns them, squared distances."""
+    pos = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+    q = np.ascontiguousarray(query, np.float64).reshape(3)
+    idx, d2 = np.zeros(len(pos), np.uint64), np.zeros(len(pos))
+    n = ref_lib().ref_kfs_radius(_p(pos), len(pos), _p(q), float(radius), _p(idx), _p(d2), len(pos))
+    return idx[:n].astype(np.int64), d2[:n].copy()
+
+
+def ref_ring_key_knn(keys, query, k=10):
+    """VectorOfVectorsKdTree<., double, 20>::nearestKSearch (vov_adaptor.h, compiled as it lies; metric_L2) as
+    ScanContext::query calls it (backend/src/ScanContext.cpp:250)."""
+    keys = np.ascontiguousarray(keys, np.float64).reshape(-1, 20)
+    q = np.ascontiguousarray(query, np.float64).reshape(20)
+    idx, d2 = np.zeros(k, np.uint64), np.zeros(k)
+    n = ref_lib().ref_vov_knn(_p(keys), len(keys), _p(q), int(k), _p(idx), _p(d2))
+    return idx[:n].astype(np.int64), d2[:n].copy()
 
 
 def ref_knn(pts, queries_f32, k=5):

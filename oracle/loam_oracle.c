@@ -500,6 +500,15 @@ void oracle_loam_default_params(oracle_loam_params *p)
     p->pos_conv = (double)5e-3f; p->rot_conv = (double)5e-3f; p->iters = 8; p->early_exit = 1; p->threads = 1;
 }
 
+static int g_weight_roots_in_double = 0;
+extern int g_ndt_rotation_polar;
+/* which 0: LOAM weight roots in double; 1: NDT Transform::rotation() as the polar factor (Eigen) instead of the linear part */
+void oracle_set_variant(int which, int value)
+{
+    if (which == 0) g_weight_roots_in_double = value;
+    if (which == 1) g_ndt_rotation_polar = value;
+}
+
 /* Per-point evaluation.  status: 0 accepted, 1 k-NN gate, 2 plane gate,
  * 3 weight gate.  row[0..5] = s*[n ; p x n], row[6] = s*dist. */
 static int loam_point(const kd_tree *t, const float *sp, const double pose[16], const oracle_loam_params *prm,
@@ -526,8 +535,12 @@ static int loam_point(const kd_tree *t, const float *sp, const double pose[16], 
     /* LoamRegister.cpp:147-148: the squared range is float arithmetic; the two
      * roots are taken in float (sqrt(float) overload) -- see DESIGN.md */
     float r2 = sp[0] * sp[0] + sp[1] * sp[1] + sp[2] * sp[2];
-    float rr = sqrtf(sqrtf(r2));
-    double s = 1 - 0.9 * fabs(dist) / (double)rr;
+    /* `sqrt(sqrt(float))`, unqualified: with the float overloads of <cmath> visible both roots are taken in float (the
+     * reading used here and on the device); with only C's sqrt(double) visible they are taken in double.  The reference's
+     * include set decides and cannot be reproduced here: oracle_set_variant(0, 1) selects the other reading so that the
+     * difference can be MEASURED (scripts/quantify_unpinned.py). */
+    double rr = g_weight_roots_in_double ? sqrt(sqrt((double)r2)) : (double)sqrtf(sqrtf(r2));
+    double s = 1 - 0.9 * fabs(dist) / rr;
     if (!(s > prm->point_thresh)) return 3;
     double n[3] = {x[0] / xn, x[1] / xn, x[2] / xn}; /* _J_e_wrt_x */
     /* s * n^T [I | -p^]  = s * [n ; p x n]  (manifolds.hpp:63-68, matrix.hpp:13-18) */

@@ -508,6 +508,26 @@ static double step_length_mt(ndt_ctx *c, const double x[6], double dir[6], doubl
     return a_t;
 }
 
+int g_ndt_rotation_polar = 0;
+/* orthogonal polar factor U V^T of a 3x3 (Newton iteration X <- (X + X^-T) / 2 in double, rounded to float): what
+ * Eigen::Transform<float,3,Affine>::rotation() extracts by SVD.  Only used to MEASURE how much the documented deviation
+ * (rotation() taken as the linear part) can matter: the guess handed over is a rotation rounded to float. */
+static void polar_factor_f(const float R[9], float out[9])
+{
+    double X[9];
+    for (int i = 0; i < 9; ++i) X[i] = (double)R[i];
+    for (int it = 0; it < 12; ++it) {
+        const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
+        const double det = X[0] * c00 + X[1] * c01 + X[2] * c02;
+        /* inverse transpose = cofactor matrix / det */
+        const double C[9] = {c00, c01, c02,
+                             X[2] * X[7] - X[1] * X[8], X[0] * X[8] - X[2] * X[6], X[1] * X[6] - X[0] * X[7],
+                             X[1] * X[5] - X[2] * X[4], X[2] * X[3] - X[0] * X[5], X[0] * X[4] - X[1] * X[3]};
+        for (int i = 0; i < 9; ++i) X[i] = 0.5 * (X[i] + C[i] / det);
+    }
+    for (int i = 0; i < 9; ++i) out[i] = (float)X[i];
+}
+
 /* Matrix3f::eulerAngles(0,1,2) (Eigen 3.3/3.4), R row-major float */
 static void euler_xyz_f(const float R[9], float out[3])
 {
@@ -543,7 +563,10 @@ int oracle_ndt_scan2map(const float *src, size_t n_src, const float *dst, size_t
     memcpy(final_R, Rg, sizeof Rg); memcpy(final_t, tg, sizeof tg);
     if (!is_identity) transform_cloud_f(src, n_src, stride, Rg, tg, c.trans);
     else for (size_t i = 0; i < n_src; ++i) for (int d = 0; d < 3; ++d) c.trans[i * 3 + d] = src[i * stride + d];
-    float eul[3]; euler_xyz_f(Rg, eul);
+    float Rp[9];
+    memcpy(Rp, Rg, sizeof Rp);
+    if (g_ndt_rotation_polar) polar_factor_f(Rg, Rp);      /* Eigen's Transform<float,3,Affine>::rotation(): see oracle_set_variant */
+    float eul[3]; euler_xyz_f(Rp, eul);
     double p[6] = {tg[0], tg[1], tg[2], eul[0], eul[1], eul[2]}, delta_p[6], grad[6], hess[36];
     double score = compute_derivatives(g, src, n_src, stride, c.trans, p, &c.gc, 1, &c.ang, grad, hess); c.n_deriv++;
     int converged = 0, nr_it = 0;
