@@ -18,9 +18,9 @@ import oracle  # noqa: E402
 
 rng = np.random.default_rng(20261004)
 # ---- 5-NN without duplicates ----
-pts = np.unique(np.concatenate([rng.uniform(-20, 20, (22000, 3)), rng.normal(0, 3, (10000, 3))]).astype(np.float32), axis=0)
+pts = np.unique(np.concatenate([rng.uniform(-7, 7, (22000, 3)), rng.normal(0, 2, (10000, 3))]).astype(np.float32), axis=0)
 rng.shuffle(pts)
-q = np.concatenate([rng.uniform(-21, 21, (1536, 3)), pts[rng.integers(0, len(pts), 512)] + rng.normal(0, 5e-3, (512, 3))]).astype(np.float32)
+q = np.concatenate([rng.uniform(-8, 8, (1536, 3)), pts[rng.integers(0, len(pts), 512)] + rng.normal(0, 5e-3, (512, 3))]).astype(np.float32)
 pts4 = np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], 1)
 q4 = np.concatenate([q, np.zeros((len(q), 1), np.float32)], 1)
 idx, d2 = oracle.ref_knn(pts4, q4, 5)

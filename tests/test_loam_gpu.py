@@ -273,24 +273,8 @@ def test_golden_fixture(gpu):
     np.testing.assert_allclose(lin["rows"][acc], g["rows0"][acc], rtol=1e-12, atol=1e-14)
 
 
-def test_knn_against_reference_nanoflann_golden(gpu):
-    """The grid search returns the neighbours the reference's own nanoflann returns
-    (tests/golden/knn_nanoflann.npz, generated from the vendored nanoflann.hpp)."""
-    import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_nanoflann.npz"))
-    reg = LoamRegister()
-    reg.setTarget(g["points"])
-    lin = reg.linearize(g["queries"], np.eye(4), per_point=True)
-    d5 = g["d2"][:, 4]
-    found = lin["status"] != 1            # status 1 = fewer than 5 neighbours inside the 1 m gate
-    np.testing.assert_array_equal(found, d5 < 1.0)
-    same = lin["nn"][found] == g["idx"][found]
-    # differences only inside groups of exactly equal distance (the fixture holds duplicated points)
-    rows = np.nonzero(found)[0]
-    for r, c in zip(*np.nonzero(~same)):
-        gi = rows[r]
-        assert (g["d2"][gi] == g["d2"][gi, c]).sum() >= 2 or g["points"][lin["nn"][gi, c], :3].tolist() == g["points"][g["idx"][gi, c], :3].tolist()
-    assert same.mean() > 0.98
+# (the comparisons with the reference's own nanoflann -- 100 % on a duplicate-free cloud, tie groups only on the one with
+#  duplicates -- live in tests/test_reference_pins.py)
 
 
 def test_temporal_cache_is_exact(gpu, world_100k):
