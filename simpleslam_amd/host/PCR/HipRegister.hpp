@@ -82,6 +82,14 @@ public:
         return isConverge;
     }
     pcr_handle* handle() { return h_; }
+    // getFitnessScore of the reference's test/align.cpp:29-61: mean squared 1-NN distance (<= max_sq) of the source under `pose`
+    // against the target of the last registration; -1 when no point is that close
+    scalar_t gatedFitness(const PC_cPtr& src, const pose_t& pose, double max_sq = 1.0, int64_t* n_in = nullptr) {
+        double score = -1.0;
+        if (pcr_fitness_gated(h_, src->points.data(), src->size(), sizeof(PointXYZI), 0, pose.data(), max_sq, &score, n_in))
+            throw std::runtime_error(pcr_last_error(h_));
+        return score;
+    }
 
     // scan2Map with `dst` = the sub-map a SubMap keeps in HBM (the scan is uploaded, the map never leaves the device)
     bool scan2Map(const PC_cPtr& src, const class SubMap& dst, pose_t& res);
@@ -149,8 +157,16 @@ class VgicpRegister : public HipRegister {
 public:
     VgicpRegister() : HipRegister("vgicp") {}
     explicit VgicpRegister(const pcr_params& p) : HipRegister("vgicp", &p) {}
-    // the reference reconfigures an existing object; handles here are configured at creation
     static std::shared_ptr<VgicpRegister> makeForLC() { return std::make_shared<VgicpRegister>(lc_params()); }
+    // VgicpRegister::initForLC (VgicpRegister.cpp:21-28) on the live object, as LoopClosureManager's constructor calls it
+    // (backend/src/LoopClosureManager.cpp:21-22): 100 iterations, transformation epsilon 1e-6
+    void initForLC() {
+        pcr_params p;
+        if (pcr_get_params(h_, &p)) throw std::runtime_error(pcr_last_error(h_));
+        p.vgicp_max_iters = 100;
+        p.vgicp_trans_eps = 1e-6;
+        if (pcr_set_params(h_, &p)) throw std::runtime_error(pcr_last_error(h_));
+    }
     scalar_t getFitnessScore() override { return pcr_fitness(h_); }
 };
 

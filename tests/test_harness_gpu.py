@@ -88,3 +88,49 @@ def test_cpp_harness_submap_mode(gpu, tmp_path):
     pose_py = init.copy()
     reg.scan2MapSubmap(ds, sm, pose_py)
     np.testing.assert_array_equal(pose_cpp, pose_py)
+
+
+@pytest.mark.parametrize("method", ["loam", "vgicp", "ndt"])
+def test_align_harness_is_the_reference_align_cpp_flow(gpu, world_small, tmp_path, method):
+    """test/align.cpp: both clouds voxel-filtered at 0.1 m (:128-129), one scan2Map (:144), the gated fitness
+    score of :29-61, the final 4x4 -- through the C++ mirror, same numbers as the Python mirror doing the same steps."""
+    from simpleslam_amd import make_register
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "align_harness")
+    assert os.path.exists(exe), "align_harness not built (run __graft_entry__.build())"
+    w = world_small
+    w["map"].astype(np.float32).tofile(tmp_path / "target.f32")
+    w["scan"].astype(np.float32).tofile(tmp_path / "source.f32")
+    np.savetxt(tmp_path / "init_pose.txt", w["init"], fmt="%.17g")
+    out = subprocess.run([exe, str(tmp_path / "target.f32"), str(tmp_path / "source.f32"), method, str(tmp_path / "init_pose.txt")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    pose_cpp = np.array([[float(v) for v in ln.split()] for ln in lines[-4:]])
+    reg = make_register(method)
+    tgt, src = reg.voxelDownSample(w["map"], 0.1), reg.voxelDownSample(w["scan"], 0.1)
+    assert f"target cloud size: {tgt.shape[0]}" in lines and f"source cloud size: {src.shape[0]}" in lines
+    pose_py = w["init"].copy()
+    conv = reg.scan2Map(src, tgt, pose_py)
+    assert ("not converge!!" in lines) == (not conv)
+    np.testing.assert_array_equal(pose_cpp, pose_py)
+    fit, n_in = reg.fitnessGated(src, pose_py, 1.0)
+    got = [ln for ln in lines if ln.startswith("get fitness score:")][0]
+    assert f"({n_in} points within 1 m)" in got and abs(float(got.split()[3]) - fit) <= 1e-8 * max(1.0, abs(fit))
+    usage = subprocess.run([exe], capture_output=True, text=True)
+    assert usage.returncode == 0 and "usage: align" in usage.stderr            # align.cpp:66-69 returns 0 after the usage line
+    bad = subprocess.run([exe, str(tmp_path / "target.f32"), str(tmp_path / "source.f32"), "icp"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "no such method!!" in bad.stderr
+
+
+def test_kdtree_bench_reports_build_and_query_times(gpu, world_small, tmp_path):
+    """Counterpart of test/benchmark/kdtree.cpp:58-127 for the grid index: index build seconds and ns per exact 5-NN query."""
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "kdtree_bench")
+    assert os.path.exists(exe), "kdtree_bench not built (run __graft_entry__.build())"
+    w = world_small
+    w["map"].astype(np.float32).tofile(tmp_path / "map.f32")
+    out = subprocess.run([exe, str(tmp_path / "map.f32"), str(tmp_path / "map.f32"), "5"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    a, b = out.stdout.strip().splitlines()
+    assert a.startswith(f"grid index: {w['map'].shape[0]} points, build") and float(a.split()[-2]) > 0
+    assert f"{w['map'].shape[0]} queries" in b and "ns/query" in b
+    assert int(b.split()[-4]) > 0.8 * w["map"].shape[0]                         # most map points find 5 neighbours within 1 m among the map
