@@ -44,6 +44,29 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def timed_windows(step, barrier, steps, windows):
+    """`windows` back-to-back timed windows of exactly `steps` steps, each bracketed by barrier + synchronize -> seconds per window"""
+    out = []
+    for w in range(windows):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,13 +82,21 @@ def parse():
                     help="> 1: additionally time S independent handles (one HIP stream and one host thread each) registering "
                          "scans concurrently on the same GPU; reported as \"concurrent\", never as \"value\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=10.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=8.0, help="wall-clock bound of EACH CPU leg (per thread count / index flavour / method)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; value = the median window")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (vgicp) and configs[4] (ndt) lines embedded as \"extra\"")
+    ap.add_argument("--extra-steps", type=int, default=40)
     return ap.parse_args()
 
 
-def secondary(args):
+def secondary(args, method=None, steps=None, warmup=None, embedded=False):
     """configs[2] (pcr=vgicp, 0.5 m voxels, 65 536 x 1 M) and configs[4] (pcr=ndt, 1 m cells, 131 072 x 5 M) on one GPU:
-    same timing contract, target rebuilt on every call like the reference (fast_vgicp_impl.hpp:66-67; ndt_omp.h:276-283)."""
+    same timing contract, target rebuilt on every call like the reference (fast_vgicp_impl.hpp:66-67; ndt_omp.h:276-283).
+    Printed as the line of `--method vgicp|ndt`, or returned to be embedded as "extra" in the LOAM line (embedded=True: one GPU,
+    no process group of its own)."""
+    method = method or args.method
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     import torch
     import oracle
     from simpleslam_amd import VgicpRegister, NdtRegister, synth
@@ -73,6 +104,8 @@ def secondary(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     # replicas, as in main(): one process per GPU, each with the whole map and its own scans, no data-path collective
     rank, local_rank, world_size = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    if embedded:
+        rank, world_size = 0, 1
     rehearse = os.environ.get("PCR_BENCH_REHEARSE") == "1" and world_size > 1
     if rehearse:
         local_rank = local_rank % torch.cuda.device_count()
@@ -85,7 +118,7 @@ def secondary(args):
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
-    if args.method == "vgicp":
+    if method == "vgicp":
         cfg, n_map, kw, mk = 3, 1_000_000, {}, {}
         reg = VgicpRegister(device=local_rank, vgicp_resolution=0.5)
         pert = {}
@@ -119,7 +152,7 @@ def secondary(args):
         return pose
 
     reg.set_profile(0)
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
 
     def barrier():
@@ -127,23 +160,20 @@ def secondary(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    wins = timed_windows(step, barrier, steps, max(1, args.windows))
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+        t = torch.tensor(wins, dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        wins = [float(v) for v in t.tolist()]
+    elapsed = float(np.median(wins))
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
         return
-    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": args.steps * world_size / elapsed, "unit": "scans/s",
-           "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.method == "vgicp" else "f32",
+    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": steps * world_size / elapsed, "unit": "scans/s",
+           "n_gpus": world_size, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "windows_ms": [1e3 * v for v in wins],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if method == "vgicp" else "f32",
            "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
            "config": {"workload": workload, "scans_cycled": args.scans,
                       "parallelism": f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"}}
@@ -155,6 +185,7 @@ def secondary(args):
     ach = alg(scans[0].shape[0], n_map) / (idx_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                        "kernel": what, "target_prep_ms": idx_ms, "align_ms": sol_ms}
+    out["roofline"]["note"] = "target_prep_ms / align_ms come from a separate 8-scan pass with phase events (pcr_set_profile 1)"
     if not args.no_cpu_baseline and world_size == 1:      # the CPU leg is timed at N = 1 only
         n_done, t_cpu, et, er, nan_both, nan_one = 0, 0.0, [], [], 0, 0
         while n_done < 2 or (t_cpu < args.cpu_budget_s and n_done < args.scans):
@@ -168,12 +199,16 @@ def secondary(args):
                 continue
             dt, dr = synth.pose_error(pg, pref)
             et.append(dt); er.append(dr)
-        out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
                                "sample": f"{n_done} of the same scans through the oracle, {t_cpu:.1f} s wall, threads = {cores}"}
         out["pose_rmse_vs_cpu"] = {"trans_m": float(np.sqrt(np.mean(np.square(et)))) if et else None,
                                    "rot_rad": float(np.sqrt(np.mean(np.square(er)))) if er else None, "scans": len(et),
                                    # pclomp's line search can return NaN (ndt_omp_impl.hpp:773-932); both sides then agree on it
                                    "non_finite_on_both_sides": nan_both, "non_finite_on_one_side": nan_one}
+    if embedded:
+        del reg, d_map, d_scans
+        torch.cuda.empty_cache()
+        return out
     print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()
@@ -230,10 +265,13 @@ def main():
         tile = shard.tile_for_rank(map_np, rank, world_size)
         d_map = torch.from_numpy(tile.points).to(dev)
         reg.set_query_tile(tile.lo, tile.hi)
-        uid = [shard.unique_id() if rank == 0 else None]
-        if world_size > 1:
-            dist.broadcast_object_list(uid, src=0)
-        reg.comm_init(uid[0], rank, world_size)
+        if rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
+            reg.comm_init_host(shard.gloo_collective(), rank, world_size)
+        else:
+            uid = [shard.unique_id() if rank == 0 else None]
+            if world_size > 1:
+                dist.broadcast_object_list(uid, src=0)
+            reg.comm_init(uid[0], rank, world_size)
         d_scans = [torch.from_numpy(s).to(dev) for s in (synth.make_scan(world, j, seed=SEED + 2)[0] for j in range(args.scans))]
         inits = [synth.perturb(synth.scan_pose(world, j, SEED + 2), SEED + 2 + j) for j in range(args.scans)]
         scaling = "strong"
@@ -253,23 +291,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY args.steps steps per timed window, bracketed by barrier + synchronize; several windows back to back, the MAX over
+    # ranks of each, and the MEDIAN window is the one reported (a 200-step window is 50 ms: one stray host hiccup moves it by percent)
+    wins = timed_windows(step, barrier, args.steps, max(1, args.windows))
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+        t = torch.tensor(wins, dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        wins = [float(v) for v in t.tolist()]
+    elapsed = float(np.median(wins))
     units = args.steps * (1 if args.shard_map else world_size)
     value = units / elapsed
 
     out = {
         "metric": "scans/s (65 k-pt scan vs 1 M-pt submap, LOAM 10 iters) + pose RMSE vs CPU ref",
         "value": value, "unit": "scans/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+        "ms_per_step": 1e3 * elapsed / args.steps, "windows_ms": [1e3 * v for v in wins], "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
         "config": {"workload": f"pcr=loam, {N_SCAN}-pt 64-beam scan vs {args.map_points}-pt submap, {args.iters} GN iters, "
                                "early exit off, index rebuilt per call, inputs in HBM",
@@ -331,29 +367,64 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "index_build_us": 1e3 * idx_ms / reps,
                            "index_build_GBs": 32 * args.map_points / (idx_ms / reps * 1e-3) / 1e9 if idx_ms > 0 else None,
-                           "device_ms_per_scan": tot_ms / reps}
+                           # (this pass runs with an event pair around every launch -- pcr_set_profile(2) -- which stretches the call:
+                           #  it is NOT comparable with ms_per_step, which is timed without any event)
+                           "device_ms_per_scan_profiled": tot_ms / reps}
 
-        # ---- pose parity + CPU baseline: the oracle (a port) on this host's cores ----
+        # ---- pose parity + CPU baseline: the oracle (a port of the reference's loop, rebuilt kd-tree per call) on this host's
+        #      cores, at 1 thread, at the reference's default `cores` = 4 (config/params.json:5) and at all cores, plus the same
+        #      with the REFERENCE's own vendored nanoflann as the index when oracle/_ref was built ----
         if not args.no_cpu_baseline and not args.shard_map and world_size == 1:      # the CPU leg is timed at N = 1 only
             import oracle
             cores = host_cores()
-            prm = oracle.loam_params(iters=args.iters, early_exit=0, threads=cores)
-            n_done, t_cpu, et, er = 0, 0.0, [], []
-            while n_done < 4 * args.scans and (n_done < args.scans or t_cpu < args.cpu_budget_s):
-                j = n_done % args.scans
-                c0 = time.perf_counter()
-                ref, _, _ = oracle.loam_scan2map(scans[j], map_np, inits[j], prm)
-                t_cpu += time.perf_counter() - c0
-                if n_done < args.scans:          # pose parity on every distinct scan
-                    dt, dr = synth.pose_error(step(j), ref)
-                    et.append(dt); er.append(dr)
-                n_done += 1
-            out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port",
+
+            def cpu_leg(threads, budget, parity=False):
+                prm = oracle.loam_params(iters=args.iters, early_exit=0, threads=threads)
+                n_done, t_cpu, et, er = 0, 0.0, [], []
+                while n_done < 4 * args.scans and (n_done < (args.scans if parity else 2) or t_cpu < budget):
+                    j = n_done % args.scans
+                    c0 = time.perf_counter()
+                    ref, _, _ = oracle.loam_scan2map(scans[j], map_np, inits[j], prm)
+                    t_cpu += time.perf_counter() - c0
+                    if parity and n_done < args.scans:          # pose parity on every distinct scan
+                        dt, dr = synth.pose_error(step(j), ref)
+                        et.append(dt); er.append(dr)
+                    n_done += 1
+                return n_done, t_cpu, et, er
+
+            by_cores = {}
+            for th in sorted({1, min(4, cores), cores}):
+                if th == cores:
+                    continue
+                n_done, t_cpu, _, _ = cpu_leg(th, args.cpu_budget_s)
+                by_cores[str(th)] = {"value": n_done / t_cpu, "scans": n_done, "wall_s": t_cpu}
+            n_done, t_cpu, et, er = cpu_leg(cores, args.cpu_budget_s, parity=True)
+            by_cores[str(cores)] = {"value": n_done / t_cpu, "scans": n_done, "wall_s": t_cpu}
+            out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+                                   "index": "the port's own kd-tree (leaf 10, rebuilt per call)", "build": "gcc -O3 -fopenmp",
                                    "sample": f"{n_done} of the same scans (kd-tree rebuilt per call + {args.iters} iterations), "
-                                             f"{t_cpu:.1f} s wall, OpenMP threads = {cores}"}
+                                             f"{t_cpu:.1f} s wall, OpenMP threads = {cores}",
+                                   "by_cores": by_cores}
+            if oracle.ref_available():
+                try:
+                    oracle.use_reference_nanoflann(True)
+                    n2, t2, _, _ = cpu_leg(cores, args.cpu_budget_s)
+                    out["cpu_baseline"]["nanoflann_ref"] = {"value": n2 / t2, "scans": n2, "wall_s": t2, "cores": cores,
+                                                            "index": "nanoflann(_ref): the reference's vendored nanoflann.hpp, built per call (serial) + exact 5-NN"}
+                finally:
+                    oracle.use_reference_nanoflann(False)
             out["pose_rmse_vs_cpu"] = {"trans_m": float(np.sqrt(np.mean(np.square(et)))), "rot_rad": float(np.sqrt(np.mean(np.square(er)))),
                                        "max_trans_m": float(max(et)), "max_rot_rad": float(max(er)), "scans": len(et),
                                        "tolerance": "1e-4 m / 1e-4 rad"}
+        # ---- BASELINE configs[2] and configs[4] on the same card, embedded so that the driver's line carries them ----
+        if world_size == 1 and not args.shard_map and not args.no_extra:
+            del d_map_full, d_scans, d_map
+            out["extra"] = {}
+            for mth in ("vgicp", "ndt"):
+                try:
+                    out["extra"][mth] = secondary(args, method=mth, steps=args.extra_steps, warmup=5, embedded=True)
+                except Exception as e:      # noqa: BLE001 -- the headline line must survive a failure of a secondary one
+                    out["extra"][mth] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()

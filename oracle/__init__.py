@@ -244,6 +244,20 @@ def ref_lib():
     return _ref
 
 
+def use_reference_nanoflann(on=True):
+    """Let the LOAM restatement search through the REFERENCE's vendored nanoflann (oracle/_ref) instead of its own kd-tree: same
+    neighbours (up to the order of exact ties), the reference's own index cost.  Used by bench.py's cpu_baseline leg."""
+    L = lib()
+    L.oracle_set_knn_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_set_knn_backend.restype = None
+    if not on:
+        L.oracle_set_knn_backend(None, None, None)
+        return
+    R = ref_lib()
+    addr = lambda f: C.cast(f, C.c_void_p)
+    L.oracle_set_knn_backend(addr(R.ref_kd_build), addr(R.ref_kd_knn), addr(R.ref_kd_free))
+
+
 def ref_radius(pts, query, radius, sorted_=False):
     """PointCloudKdtree::radiusSearch (pcl_adaptor.hpp:60-78) through the reference's nanoflann: indices and squared distances as returned."""
     pts = _f32(pts)

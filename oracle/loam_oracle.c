@@ -62,7 +62,23 @@ typedef struct {
     int32_t *perm;
     kd_node *nodes;
     int32_t n_nodes, cap_nodes;
+    void *ext;        /* index of an external k-NN backend (oracle_set_knn_backend) in place of the tree above */
 } kd_tree;
+
+/* Optional external k-NN backend with the signatures of oracle/ref_nanoflann_shim.cpp (ref_kd_build / ref_kd_knn / ref_kd_free):
+ * the CPU baseline can then time the restatement on the REFERENCE's own vendored nanoflann (build per call + exact 5-NN), which is
+ * what SURVEY 8(d) asks the baseline to reflect.  NULLs restore the built-in tree. */
+static struct {
+    void *(*build)(const float *, size_t, size_t);
+    int (*knn)(void *, const double *, int, size_t *, double *);
+    void (*release)(void *);
+} g_knn_backend = {0, 0, 0};
+void oracle_set_knn_backend(void *build, void *knn, void *release)
+{
+    g_knn_backend.build = (void *(*)(const float *, size_t, size_t))build;
+    g_knn_backend.knn = (int (*)(void *, const double *, int, size_t *, double *))knn;
+    g_knn_backend.release = (void (*)(void *))release;
+}
 
 static inline double kd_coord(const kd_tree *t, int32_t i, int d)
 {
@@ -137,6 +153,7 @@ kd_tree *oracle_kd_build(const float *pts, size_t n, size_t stride_floats)
 {
     kd_tree *t = (kd_tree *)calloc(1, sizeof(kd_tree));
     t->pts = pts; t->stride = stride_floats; t->n = (int32_t)n;
+    if (g_knn_backend.build && g_knn_backend.knn && n) { t->ext = g_knn_backend.build(pts, n, stride_floats); return t; }
     t->perm = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
     for (int32_t i = 0; i < (int32_t)n; ++i) t->perm[i] = i;
     if (n) kd_build_rec(t, 0, (int32_t)n);
@@ -146,6 +163,7 @@ kd_tree *oracle_kd_build(const float *pts, size_t n, size_t stride_floats)
 void oracle_kd_free(kd_tree *t)
 {
     if (!t) return;
+    if (t->ext && g_knn_backend.release) g_knn_backend.release(t->ext);
     free(t->perm); free(t->nodes); free(t);
 }
 
@@ -205,6 +223,13 @@ static void kd_search_rec(const kd_tree *t, int32_t id, const double q[3], knn_s
 /* exact k-NN; returns number found (min(k, n)); outputs sorted ascending */
 int oracle_kd_knn(const kd_tree *t, const double q[3], int k, int32_t *idx_out, double *d_out)
 {
+    if (t->ext) {
+        size_t ii[32]; double dd[32];
+        const int kk = k > 32 ? 32 : k;
+        const int m = g_knn_backend.knn(t->ext, q, kk, ii, dd);
+        for (int i = 0; i < m; ++i) { idx_out[i] = (int32_t)ii[i]; d_out[i] = dd[i]; }
+        return m;
+    }
     knn_set s; s.k = k > 32 ? 32 : k; s.count = 0;
     if (t->n > 0) kd_search_rec(t, 0, q, &s);
     for (int i = 0; i < s.count; ++i) { idx_out[i] = s.idx[i]; d_out[i] = s.d[i]; }
@@ -519,7 +544,10 @@ static int loam_point(const kd_tree *t, const float *sp, const double pose[16], 
     float pm[3];
     for (int i = 0; i < 3; ++i) {
         double v = pose[0 * 4 + i] * ox + pose[1 * 4 + i] * oy + pose[2 * 4 + i] * oz + pose[3 * 4 + i] * 1.0;
-        pm[i] = (float)v;
+        /* through a volatile: gcc 11 -O3 (SLP vectoriser) otherwise drops this (double)(float) round trip, which the reference's
+         * pcl::PointXYZI pointInMap performs (F6) -- found by the GPU parity tests, pinned by test_rows_match_numpy_transcription */
+        volatile float rounded = (float)v;
+        pm[i] = rounded;
     }
     double q[3] = {(double)pm[0], (double)pm[1], (double)pm[2]};
     double nd[5];
