@@ -13,13 +13,14 @@ c = np.floor(m[:, :3] / 0.5).astype(np.int64); c -= c.min(0)
 order = np.lexsort((c[:, 0], c[:, 1], c[:, 2]))
 for name, mm in (("generator order", m), ("voxel-grid order", np.ascontiguousarray(m[order])), ("shuffled", np.ascontiguousarray(m[np.random.default_rng(1).permutation(len(m))]))):
     dm = torch.from_numpy(mm).cuda()
-    for sh in (None, 8, 9, 10, 11, 12, "atomic"):
+    for sh, per in ((None, 16), (10, 16), (11, 8), (10, 8), (11, 4), (10, 4), ("atomic", 16)):
         os.environ.pop("PCR_TILE_SHIFT", None); os.environ.pop("PCR_INDEX_ATOMIC", None)
+        os.environ["PCR_BIN_PER"] = str(per)
         if sh == "atomic": os.environ["PCR_INDEX_ATOMIC"] = "1"
         elif sh is not None: os.environ["PCR_TILE_SHIFT"] = str(sh)
         reg = LoamRegister(loam_iters=1, loam_early_exit=0)
         t = []
         for i in range(14):
             pose = T0.copy(); reg.scan2Map(ds, dm, pose); t.append(reg.stats()["index_ms"])
-        print(f"{name:18s} tile shift {str(sh):6s}: index build {np.median(t[4:]) * 1e3:7.1f} us")
+        print(f"{name:18s} tile shift {str(sh):6s} points/thread {per:2d}: index build {np.median(t[4:]) * 1e3:7.1f} us")
         del reg

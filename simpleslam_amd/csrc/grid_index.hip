@@ -333,8 +333,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
 // original index in .w; voxel statistics are fixed-point sums).
 // ======================================================================================================================
 static constexpr int kBinStride = 16;                  // counters 64 bytes apart: memory-side atomics on one line serialise
-static constexpr int kBinPer = 16;                    // points per thread and chunk of the bin kernel
-static constexpr int kBinChunk = 256 * kBinPer;       // points a block histograms at a time
+static constexpr int kBinPerDefault = 8;              // points per thread and chunk of the bin kernel
 
 template <bool kVec>
 __device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i, uint32_t stride, float& x, float& y, float& z) {
@@ -343,7 +342,7 @@ __device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i
 }
 
 // dynamic LDS: max_bins counters (max_bins = tiles the cell table's capacity can make: host-known)
-template <bool kVec>
+template <bool kVec, int kBinPer>
 __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
@@ -353,6 +352,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     for (uint32_t b = threadIdx.x; b < max_bins; b += 256) hist[b] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    constexpr uint32_t kBinChunk = 256u * kBinPer;      // points a block histograms at a time
     for (uint32_t c0 = blockIdx.x * kBinChunk; c0 < n; c0 += gridDim.x * kBinChunk) {
         uint32_t bin[kBinPer], loc[kBinPer];
         bool first[kBinPer];
@@ -709,21 +709,24 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
             PCR_TRY(hipMemsetAsync(bin_count.p, 0, bin_count.cap, s));      // builds expect and leave the counters zeroed
         }
         const bool vec = (stride_floats % 4 == 0) && ((uintptr_t)d_pts % 16 == 0);
-        const int bin_blocks = (int)std::min<size_t>(2048, (n + kBinChunk - 1) / kBinChunk ? (n + kBinChunk - 1) / kBinChunk : 1);
+        int bin_per = kBinPerDefault;
+        if (const char* e = getenv("PCR_BIN_PER")) bin_per = atoi(e);      // (development: chunk size sweep)
+        const size_t bin_chunk = (size_t)256 * bin_per;
+        const int bin_blocks = (int)std::min<size_t>(4096, (n + bin_chunk - 1) / bin_chunk ? (n + bin_chunk - 1) / bin_chunk : 1);
         const int place_blocks = (int)std::min<size_t>(2048, (n + 1023) / 1024 ? (n + 1023) / 1024 : 1);
         const int tile_blocks = (int)max_bins;
         const size_t bin_lds = (size_t)max_bins * 4, place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
-        if (vec) {
-            hipLaunchKernelGGL(grid_bin_kernel<true>, dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
-                               ranks.as<uint32_t>(), tshift, max_bins);
+#define PCR_LAUNCH_BIN(VEC, PER) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
+                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins)
+        if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8); else PCR_LAUNCH_BIN(true, 16); }
+        else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8); else PCR_LAUNCH_BIN(false, 16); }
+#undef PCR_LAUNCH_BIN
+        if (vec)
             hipLaunchKernelGGL(grid_place_kernel<true>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
                                ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
-        } else {
-            hipLaunchKernelGGL(grid_bin_kernel<false>, dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
-                               ranks.as<uint32_t>(), tshift, max_bins);
+        else
             hipLaunchKernelGGL(grid_place_kernel<false>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
                                ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
-        }
         hipLaunchKernelGGL(grid_tile_kernel, dim3(tile_blocks), dim3(256), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), bin_start.as<uint32_t>(),
                            bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift);
         PCR_TRY(hipGetLastError());
