@@ -1,12 +1,12 @@
-"""Condense gpurun_out/prof_r01 (scripts/profile_round.sh) into profiles/: the kernel statistics table, the
+"""Condense gpurun_out/prof_r02 (scripts/profile_round.sh) into profiles/: the kernel statistics table, the
 per-kernel PMC means, and profiles/loam_iterate_pmc.json (HBM bytes per launch of the dominant kernel,
 corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KiB... see below)."""
 import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r01")
+src = os.path.join(ROOT, "gpurun_out", "prof_r02")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs(dst, exist_ok=True)
 
 

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace statistics of the bench command and the HBM traffic
 # counters of the dominant kernel, each PMC group in its own pass (MI355X_MICROARCH.md, "HBM" / "rocprofv3 PMC").
-# Output under gpurun_out/prof_r01; the summaries are then copied into profiles/ by scripts/collect_profiles.py.
+# Output under gpurun_out/prof_r02; the summaries are then copied into profiles/ by scripts/collect_profiles.py.
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_r01
+OUT=$R/gpurun_out/prof_r02
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+ARGS="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra --windows 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -320,11 +320,12 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
 // per point.  The one-level path above spends half its time in a million returning atomics on scattered counters, which
 // this multi-XCD part executes at the memory side at ~25 G/s whatever their scope.  Here:
 //   bin    (grid_bin_kernel)    points -> tile = key >> shift (<= kMaxBins tiles of 2^shift consecutive cells); a block
-//                               histograms 4096 points at a time in LDS (LDS atomics return the rank inside the chunk) and
-//                               claims room in each tile it touched with ONE global atomic: a few dozen per 4096 points for
-//                               a cloud stored in any spatially coherent order, <= kMaxBins in the worst case.
-//   place  (grid_place_kernel)  every block scans the tile counters (<= 32 KB, redundantly: no extra launch) and moves each
-//                               point to its slot of its tile: the cloud grouped by tile, 16 B read + 16 B written per point.
+//                               histograms a chunk of 2048 points at a time in LDS (one LDS atomic per run of equal tiles in
+//                               consecutive lanes; it returns the rank inside the chunk) and claims room in each tile the chunk
+//                               touched with ONE global atomic (counters 64 bytes apart: memory-side atomics on one line
+//                               serialise).  The last block to finish scans the counters into bin_start.
+//   place  (grid_place_kernel)  moves each point to its slot of its tile: the cloud grouped by tile, 16 B read + 16 B written
+//                               per point.
 //   tile   (grid_tile_kernel)   one block per tile: histogram of the tile's cells in LDS, exclusive scan -> cell_start of
 //                               those cells (every cell of the table is written exactly once: no scan pass over the table, no
 //                               clearing), points to their final position.  16 B read + 16 B written per point.
@@ -344,7 +345,8 @@ __device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i
 // dynamic LDS: max_bins counters (max_bins = tiles the cell table's capacity can make: host-known)
 template <bool kVec, int kBinPer>
 __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
-                                                       uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins) {
+                                                       uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
+                                                       uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;
     const GridHeader h = *hdr;
@@ -406,31 +408,40 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         for (int u = 0; u < kBinPer; ++u) if (first[u]) hist[bin[u]] = 0u;      // ready for the next chunk
         __syncthreads();
     }
-}
-
-// exclusive scan of the tile counters into LDS (every block, redundantly); sh_start[nbins] = total
-__device__ inline void scan_bins_to_lds(const uint32_t* __restrict__ bin_count, uint32_t nbins, uint32_t* sh_start, uint32_t* sh4) {
-    // thread t owns the counters [t * per, t * per + per)
-    const uint32_t per = (nbins + 255u) / 256u;
+    // ---- the last block to finish turns the tile counters (64 bytes apart, written by device-scope atomics) into the compact
+    //      exclusive scan the next two kernels read: bin_start[0 .. nbins] ----
+    __shared__ uint32_t sh_last, sh4[4];
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's claims have been acknowledged (they returned values)
+        sh_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
+    const uint32_t per = (nbins + 255u) / 256u;      // <= kMaxBins / 256 = 32
     const uint32_t b0 = threadIdx.x * per;
+    uint32_t c[kMaxBins / 256];
+#pragma unroll
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j)      // all of a thread's counters requested before the first is used
+        c[j] = (j < per && b0 + j < nbins) ? __hip_atomic_load(&bin_count[(size_t)(b0 + j) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; ++j) if (b0 + j < nbins) sum += bin_count[(size_t)(b0 + j) * kBinStride];
+#pragma unroll
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j) sum += c[j];
     uint32_t total;
     uint32_t off = block_exclusive_scan_256(sum, &total, sh4);
-    for (uint32_t j = 0; j < per; ++j) {
-        if (b0 + j < nbins) { sh_start[b0 + j] = off; off += bin_count[(size_t)(b0 + j) * kBinStride]; }      // (L1 hit)
-    }
-    if (threadIdx.x == 255) sh_start[nbins] = total;
-    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j)
+        if (j < per && b0 + j < nbins) { bin_start[b0 + j] = off; off += c[j]; }
+    if (threadIdx.x == 255) bin_start[nbins] = total;
+    if (threadIdx.x == 0) *ticket = 0u;                        // ready for the next build
 }
 
 template <bool kVec>
 __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, const GridHeader* __restrict__ hdr,
                                                          const uint32_t* __restrict__ bin_count, const uint32_t* __restrict__ slot,
-                                                         uint32_t* __restrict__ bin_start, float4* __restrict__ tiled, int shift) {
+                                                         const uint32_t* __restrict__ bin_start, float4* __restrict__ tiled, int shift) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const sh_start = dyn_lds;      // max_bins + 1 entries
-    __shared__ uint32_t sh4[4];
     const GridHeader h = *hdr;
     if (h.overflow || h.empty) return;
     const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
@@ -445,10 +456,8 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
         load_xyz<kVec>(pts, i < n ? i : 0u, stride, px[u], py[u], pz[u]);
         sl[u] = i < n ? slot[i] : 0xffffffffu;
     }
-    scan_bins_to_lds(bin_count, nbins, sh_start, sh4);
-    if (blockIdx.x == 0) {      // the tile kernel wants the starts too
-        for (uint32_t b = threadIdx.x; b <= nbins; b += 256) bin_start[b] = sh_start[b];
-    }
+    for (uint32_t b = threadIdx.x; b <= nbins; b += 256) sh_start[b] = bin_start[b];      // (scanned by the last block of the bin kernel)
+    __syncthreads();
     for (; c0 < n; c0 += gridDim.x * (256 * kPer)) {
         if (c0 != blockIdx.x * (256 * kPer)) {
 #pragma unroll
@@ -717,7 +726,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const int tile_blocks = (int)max_bins;
         const size_t bin_lds = (size_t)max_bins * 4, place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
 #define PCR_LAUNCH_BIN(VEC, PER) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
-                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins)
+                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>())
         if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8); else PCR_LAUNCH_BIN(true, 16); }
         else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8); else PCR_LAUNCH_BIN(false, 16); }
 #undef PCR_LAUNCH_BIN
