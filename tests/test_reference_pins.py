@@ -146,3 +146,38 @@ def test_the_two_unpinnable_readings_are_bounded_by_measurement():
     assert a[1] == b[1] and a[2]["iterations"] == b[2]["iterations"]
     dt, dr = synth.pose_error(a[0], b[0])
     assert dt < 1e-5 and dr < 1e-6
+
+
+needs_ref = pytest.mark.skipif(not oracle.ref_available(), reason="oracle/_ref not built (needs /root/reference at build time)")
+
+
+@needs_ref
+def test_loam_oracle_on_reference_nanoflann():
+    """The LOAM restatement searching through the reference's own tree (oracle_set_knn_backend) instead of its kd-tree: same
+    poses bit for bit on a cloud without exact ties -- the k-NN stage of the oracle IS the reference's, not a look-alike."""
+    from simpleslam_amd import synth
+    world, m = synth.make_map(50_000, seed=77)
+    scan, T = synth.make_scan(world, 0, seed=77, beams=16, azimuths=512)
+    T0 = synth.perturb(T, 77)
+    prm = oracle.loam_params(iters=6, early_exit=0, threads=4)
+    own = oracle.loam_scan2map(scan, m, T0, prm)
+    try:
+        oracle.use_reference_nanoflann(True)
+        ref = oracle.loam_scan2map(scan, m, T0, prm)
+    finally:
+        oracle.use_reference_nanoflann(False)
+    np.testing.assert_array_equal(own[0], ref[0])
+    assert own[1] == ref[1]
+
+
+@needs_ref
+def test_reference_radius_search_is_the_strict_squared_distance_set(more):
+    """PointCloudKdtree::radiusSearch (pcl_adaptor.hpp:60-78): the set is { i : |p_i - q|^2 < r^2 } with the squared distances
+    nanoflann accumulates in double -- what oracle/submap_oracle.c and the gated fitness restate."""
+    pts = more["knn_points"]
+    for q in more["knn_queries"][:32, :3].astype(np.float64):
+        idx, d2 = oracle.ref_radius(pts, q, 0.75)
+        d = ((pts[:, :3].astype(np.float64) - q) ** 2)
+        full = d[:, 0] + d[:, 1] + d[:, 2]
+        np.testing.assert_array_equal(np.sort(idx), np.flatnonzero(full < 0.75 * 0.75))
+        np.testing.assert_array_equal(d2, full[idx])
