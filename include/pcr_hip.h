@@ -74,7 +74,9 @@ typedef struct pcr_params {
      *            several handles register scans concurrently on one GPU (their blocks can then share the CUs)
      *   [5] != 0: first margin, in millimetres, of the region a LOAM target too sparse for the dense index is cut to around the
      *            scan (default 10 m; it grows whenever a query reaches a cut face -- a test hook for that path: a negative value
-     *            cuts into the scan's own box, so that the first attempts must be widened) */
+     *            cuts into the scan's own box, so that the first attempts must be widened)
+     *   [6] = 1: NDT: drive the optimiser from the host (one round trip per evaluation pass) instead of on the device; the
+     *            path sharded handles always take.  Same state machine (csrc/ndt_opt.h), same result to rounding. */
     int32_t reserved[7];
 } pcr_params;
 

@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "pcr_internal.h"
+#include "ndt_opt.h"
 #include "small_math.h"
 
 using namespace pcr;
@@ -101,6 +102,12 @@ struct pcr_handle {
     DeviceBuf nd_slot, nd_vox, nd_count, nd_list, nd_partials;
     double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
     double* out48_dev = nullptr;
+    DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
+    NdtOut* nd_out_host = nullptr;       // host-mapped: its result and progress word
+    NdtOut* nd_out_dev = nullptr;
+    bool nd_grid_checked = false, nd_grid_bad = false;      // the device loop reported the state of the index header with its result
+    uint64_t nd_grid_cells = 0;
+    int nd_last_passes = 8;              // passes the previous alignment took: how many are enqueued up front
     bool nd_target_ready = false;
     int nd_iters = 0, nd_deriv = 0, nd_hess = 0;
     double nd_score = 0;
@@ -770,13 +777,18 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
 // NDT host driver: pclomp::NormalDistributionsTransform::computeTransformation
 // (ndt_omp_impl.hpp:81-171) with the More-Thuente line search (:649-932).
 // ---------------------------------------------------------------------------------
-int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
+// deferred: nothing is read back here -- the index is enqueued with the previous target's box as a hint and the cell table at its
+// current size; whether either was wrong (header.overflow / header.stale) comes back with the result of the alignment
+// (NdtOut), and the caller then prepares again the slow, checked way.  One host round trip less per scan.
+int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, bool deferred = false) {
     h->nd_target_ready = false;
     const double res = (double)(float)h->prm.ndt_resolution;     // resolution_ is a float (ndt_omp.h)
     if (!(res > 0)) return fail(h, "ndt_resolution must be positive");
     // the voxel lattice is VoxelGridCovariance's own (leaf index = floor(p * inverse_leaf) - min_b in float,
     // voxel_grid_covariance_omp_impl.hpp:218-220): GridHeader.pcl_mode, no pad cells
-    if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
+    if (deferred) {
+        if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true) != hipSuccess) return 1;
+    } else if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
     // setMinPointPerVoxel (pclomp/voxel_grid_covariance_omp.h:229-240): "Covariance calculation requires at least 3 points"
@@ -792,30 +804,7 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
 }
 
 namespace ndt_host {
-// Eigen::AngleAxisf(angle, Unit{X,Y,Z}).toRotationMatrix(), row-major
-void angle_axis(float angle, int axis, float R[9]) {
-    float ax[3] = {0, 0, 0}; ax[axis] = 1.0f;
-    const float s = sinf(angle), c = cosf(angle);
-    const float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
-    const float c1[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
-    float tmp;
-    tmp = c1[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
-    tmp = c1[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
-    tmp = c1[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
-    for (int d = 0; d < 3; ++d) R[d * 3 + d] = c1[d] * ax[d] + c;
-}
-void mul33(const float A[9], const float B[9], float C[9]) {
-    float o[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { float s = A[r * 3] * B[c]; s += A[r * 3 + 1] * B[3 + c]; s += A[r * 3 + 2] * B[6 + c]; o[r * 3 + c] = s; }
-    memcpy(C, o, sizeof o);
-}
-// Translation(x[0:3]) * Rx * Ry * Rz evaluated in float (ndt_omp_impl.hpp:146-149,827-830)
-void pose_from_p(const double x[6], NdtPose* T) {
-    float Rx[9], Ry[9], Rz[9], M[9];
-    angle_axis((float)x[3], 0, Rx); angle_axis((float)x[4], 1, Ry); angle_axis((float)x[5], 2, Rz);
-    mul33(Rx, Ry, M); mul33(M, Rz, T->R);
-    T->t[0] = (float)x[0]; T->t[1] = (float)x[1]; T->t[2] = (float)x[2];
-}
+using namespace ndt_opt;      // pose_from_p, angle_derivatives, svd6_solve, the line search: shared with the device (ndt_opt.h)
 // Matrix3f::eulerAngles(0, 1, 2)
 void euler_xyz(const float R[9], float out[3]) {
     const float pi = 3.14159265358979323846f;
@@ -827,87 +816,6 @@ void euler_xyz(const float R[9], float out[3]) {
     const float s1 = sinf(r0), c1 = cosf(r0);
     const float r2 = atan2f(s1 * R[2 * 3 + 0] - c1 * R[1 * 3 + 0], c1 * R[1 * 3 + 1] - s1 * R[2 * 3 + 1]);
     out[0] = -r0; out[1] = -r1; out[2] = -r2;
-}
-void angle_derivatives(const double p[6], NdtAngles* a) {
-    double cx, cy, cz, sx, sy, sz;
-    if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
-    if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
-    if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
-    const double J[8][3] = {
-        {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)}, {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},
-        {(-sy * cz), sy * sz, cy}, {sx * cy * cz, (-sx * cy * sz), sx * sy}, {(-cx * cy * cz), cx * cy * sz, (-cx * sy)},
-        {(-cy * sz), (-cy * cz), 0}, {(cx * cz - sx * sy * sz), (-cx * sz - sx * sy * cz), 0}, {(sx * cz + cx * sy * sz), (cx * sy * cz - sx * sz), 0}};
-    const double Hh[15][3] = {
-        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), sx * cy}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), (-cx * cy)},
-        {(cx * cy * cz), (-cx * cy * sz), (cx * sy)}, {(sx * cy * cz), (-sx * cy * sz), (sx * sy)},
-        {(-sx * cz - cx * sy * sz), (sx * sz - cx * sy * cz), 0}, {(cx * cz - sx * sy * sz), (-sx * sy * cz - cx * sz), 0},
-        {(-cy * cz), (cy * sz), (-sy)}, {(-sx * sy * cz), (sx * sy * sz), (sx * cy)}, {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},
-        {(sy * sz), (sy * cz), 0}, {(-sx * cy * sz), (-sx * cy * cz), 0}, {(cx * cy * sz), (cx * cy * cz), 0},
-        {(-cy * cz), (cy * sz), 0}, {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};
-    for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) { a->jd[r][c] = J[r][c]; a->j[r][c] = (float)J[r][c]; }
-    for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) { a->hd[r][c] = Hh[r][c]; a->h[r][c] = (float)Hh[r][c]; }
-    a->h[6][2] = (float)(sy);   // the float table (:384) writes (sy) where h_ang_d1_ (:362) has (-sy)
-}
-// JacobiSVD<Matrix6d>::solve: one-sided Jacobi, pseudo-inverse with Eigen's default threshold
-void svd6_solve(const double A_in[36], const double b[6], double x[6]) {
-    double U[6][6], V[6][6];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { U[i][j] = A_in[i * 6 + j]; V[i][j] = i == j; }
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < 5; ++p)
-            for (int q = p + 1; q < 6; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int k = 0; k < 6; ++k) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
-                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
-                rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int k = 0; k < 6; ++k) {
-                    const double up = U[k][p], uq = U[k][q]; U[k][p] = c * up - s * uq; U[k][q] = s * up + c * uq;
-                    const double vp = V[k][p], vq = V[k][q]; V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
-                }
-            }
-        if (!rotated) break;
-    }
-    double sig[6], smax = 0;
-    for (int j = 0; j < 6; ++j) { double s = 0; for (int k = 0; k < 6; ++k) s += U[k][j] * U[k][j]; sig[j] = sqrt(s); smax = std::max(smax, sig[j]); }
-    const double thr = 6.0 * 2.220446049250313e-16 * smax;
-    for (int i = 0; i < 6; ++i) x[i] = 0;
-    for (int j = 0; j < 6; ++j) {
-        if (!(sig[j] > thr)) continue;
-        double ub = 0;
-        for (int k = 0; k < 6; ++k) ub += (U[k][j] / sig[j]) * b[k];
-        for (int i = 0; i < 6; ++i) x[i] += V[i][j] * (ub / sig[j]);
-    }
-}
-bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
-    if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
-    else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
-    else if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
-    return true;
-}
-double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
-    if (f_t > f_l) {
-        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
-        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
-        return std::fabs(a_c - a_l) < std::fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
-    } else if (g_t * g_l < 0) {
-        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
-        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-        return std::fabs(a_c - a_t) >= std::fabs(a_s - a_t) ? a_c : a_s;
-    } else if (std::fabs(g_t) <= std::fabs(g_l)) {
-        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
-        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-        const double nx = std::fabs(a_c - a_t) < std::fabs(a_s - a_t) ? a_c : a_s;
-        const double lim = a_t + 0.66 * (a_u - a_t);
-        return a_t > a_l ? std::min(lim, nx) : std::max(lim, nx);
-    }
-    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = std::sqrt(z * z - g_t * g_u);
-    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
 }
 }  // namespace ndt_host
 
@@ -931,66 +839,15 @@ int ndt_derivatives(NdtRun* r, const double p[6], bool compute_hessian, double* 
     return 0;
 }
 
-int ndt_step_length(NdtRun* r, const double x[6], double dir[6], double step_init, double step_max, double step_min, double* score,
-                    double grad[6], double hess[36], double* a_out) {
-    using namespace ndt_host;
+// One evaluation pass of the host-driven loop: the kernel the controller asked for, the fold, the ranks' sum.
+int ndt_host_pass(NdtRun* r, const NdtCtl& c, double sums[43]) {
     pcr_handle* h = r->h;
-    double phi_0 = -*score, d_phi_0 = 0;
-    for (int i = 0; i < 6; ++i) d_phi_0 += grad[i] * dir[i];
-    d_phi_0 = -d_phi_0;
-    if (d_phi_0 >= 0) {
-        if (d_phi_0 == 0) { *a_out = 0; return 0; }
-        d_phi_0 *= -1;
-        for (int i = 0; i < 6; ++i) dir[i] *= -1;
-    }
-    const int max_it = 10;
-    int it = 0;
-    const double mu = 1.e-4, nu = 0.9;
-    double a_l = 0, a_u = 0;
-    double f_l = phi_0 - phi_0 - mu * d_phi_0 * a_l, g_l = d_phi_0 - mu * d_phi_0;
-    double f_u = phi_0 - phi_0 - mu * d_phi_0 * a_u, g_u = d_phi_0 - mu * d_phi_0;
-    bool interval_converged = (step_max - step_min) < 0, open_interval = true;
-    double a_t = step_init;
-    a_t = std::min(a_t, step_max);
-    a_t = std::max(a_t, step_min);
-    double x_t[6];
-    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
-    pose_from_p(x_t, &r->T);
-    if (ndt_derivatives(r, x_t, true, score, grad, hess)) return 1;
-    double phi_t = -*score, d_phi_t = 0;
-    for (int i = 0; i < 6; ++i) d_phi_t += grad[i] * dir[i];
-    d_phi_t = -d_phi_t;
-    double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
-    while (!interval_converged && it < max_it && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        if (open_interval) a_t = trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
-        else a_t = trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        a_t = std::min(a_t, step_max);
-        a_t = std::max(a_t, step_min);
-        for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
-        pose_from_p(x_t, &r->T);
-        if (ndt_derivatives(r, x_t, false, score, grad, hess)) return 1;
-        phi_t = -*score; d_phi_t = 0;
-        for (int i = 0; i < 6; ++i) d_phi_t += grad[i] * dir[i];
-        d_phi_t = -d_phi_t;
-        psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t; d_psi_t = d_phi_t - mu * d_phi_0;
-        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-            open_interval = false;
-            f_l = f_l + phi_0 - mu * d_phi_0 * a_l; g_l = g_l + mu * d_phi_0;
-            f_u = f_u + phi_0 - mu * d_phi_0 * a_u; g_u = g_u + mu * d_phi_0;
-        }
-        if (open_interval) interval_converged = update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
-        else interval_converged = update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        it++;
-    }
-    if (it && r->a.n_src) {   // computeHessian (:928-929), double precision, with the tables of the last pass
-        h->seq += 1.0;
-        H_TRY(ndt_launch_hessian(r->a, r->T, r->ang, h->out48_dev, h->stream, h->seq));
-        if (wait_result(h, &h->out48_host[47], h->seq)) return 1;
-        if (sharded(h) && ranks_allreduce(h, h->out48_host, 43)) return 1;
-        ++h->nd_hess;
-        for (int i = 0; i < 36; ++i) hess[i] = h->out48_host[7 + i];
-    }
-    *a_out = a_t;
+    h->seq += 1.0;
+    if (c.kind == kNdtPassHessian) H_TRY(ndt_launch_hessian(r->a, c.T, c.ang, h->out48_dev, h->stream, h->seq));
+    else H_TRY(ndt_launch_derivatives(r->a, c.T, c.ang, c.kind == kNdtPassDerivH ? 1 : 0, h->out48_dev, h->stream, h->seq));
+    if (wait_result(h, &h->out48_host[47], h->seq)) return 1;
+    if (sharded(h) && ranks_allreduce(h, h->out48_host, 43)) return 1;      // score, gradient, Hessian summed over the ranks' tiles
+    for (int i = 0; i < 43; ++i) sums[i] = h->out48_host[i];
     return 0;
 }
 
@@ -1003,7 +860,13 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         memset(h->out48_host, 0, 48 * sizeof(double));
         H_TRY(hipHostGetDevicePointer((void**)&h->out48_dev, h->out48_host, 0));
     }
+    if (!h->nd_out_host) {
+        H_TRY(hipHostMalloc((void**)&h->nd_out_host, sizeof(NdtOut), hipHostMallocMapped));
+        memset(h->nd_out_host, 0, sizeof(NdtOut));
+        H_TRY(hipHostGetDevicePointer((void**)&h->nd_out_dev, h->nd_out_host, 0));
+    }
     H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));
+    H_TRY(h->nd_ctl.reserve(sizeof(NdtCtl)));
     NdtRun r;
     r.h = h;
     r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)stride_floats;
@@ -1022,31 +885,75 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     // guess handed over as Matrix4f (NdtRegister.cpp:27)
     float G[16];
     for (int i = 0; i < 16; ++i) G[i] = (float)pose[i];
-    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) r.T.R[rr * 3 + c] = G[c * 4 + rr]; r.T.t[rr] = G[12 + rr]; }
-    NdtPose final_T = r.T;
+    NdtPose T0;
+    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) T0.R[rr * 3 + c] = G[c * 4 + rr]; T0.t[rr] = G[12 + rr]; }
     float eul[3];
-    euler_xyz(r.T.R, eul);     // Transform::rotation() taken as the linear part
-    double p[6] = {r.T.t[0], r.T.t[1], r.T.t[2], eul[0], eul[1], eul[2]}, delta_p[6], grad[6], hess[36], score = 0;
-    if (ndt_derivatives(&r, p, true, &score, grad, hess)) return 1;
-    bool conv = false;
-    int nr_it = 0;
-    while (!conv) {
-        double rhs[6];
-        for (int i = 0; i < 6; ++i) rhs[i] = -grad[i];
-        svd6_solve(hess, rhs, delta_p);
-        double nrm = 0;
-        for (int i = 0; i < 6; ++i) nrm += delta_p[i] * delta_p[i];
-        nrm = sqrt(nrm);
-        if (nrm == 0 || nrm != nrm) { conv = nrm == nrm; break; }
-        for (int i = 0; i < 6; ++i) delta_p[i] /= nrm;
-        double a_t = 0;
-        if (ndt_step_length(&r, p, delta_p, nrm, h->prm.ndt_step_size, h->prm.ndt_trans_eps / 2, &score, grad, hess, &a_t)) return 1;
-        nrm = a_t;
-        for (int i = 0; i < 6; ++i) delta_p[i] *= nrm;
-        final_T = r.T;
-        for (int i = 0; i < 6; ++i) p[i] += delta_p[i];
-        if (nr_it > h->prm.ndt_max_iters || (nr_it && fabs(nrm) < h->prm.ndt_trans_eps)) conv = true;
-        nr_it++;
+    euler_xyz(T0.R, eul);     // Transform::rotation() taken as the linear part
+    const double p0[6] = {T0.t[0], T0.t[1], T0.t[2], eul[0], eul[1], eul[2]};
+
+    NdtPose final_T = T0;
+    int conv = 0, nr_it = 0;
+    double score = 0;
+    // ---- device-resident loop: passes are enqueued ahead of the device, the host watches a progress word.  Not for sharded
+    // targets (every pass's sums cross the ranks through the host) and not when pcr_params.reserved[6] asks for the host loop ----
+    bool on_device = n_src > 0 && !sharded(h) && h->prm.reserved[6] == 0;
+    h->nd_grid_checked = false; h->nd_grid_bad = false;
+    if (on_device) {
+        NdtCtl* d_ctl = h->nd_ctl.as<NdtCtl>();
+        NdtOut* out = h->nd_out_host;
+        h->seq += 1.0;
+        const double seq = h->seq;
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream));
+        const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4;        // an iteration takes at most 1 + 10 + 1 passes
+        int enq = 0;
+        const int first = std::min(std::max(h->nd_last_passes, 3), 24);
+        for (; enq < first; ++enq) H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq));
+        const volatile double* f_seq = &out->seq;
+        const volatile double* f_prog = &out->progress;
+        long spins = 0;
+        bool finished = false;
+        while (!finished) {
+            if (*f_seq == seq) { finished = true; break; }
+            const double pr = *f_prog;
+            const int consumed = (pr >= seq * 4096.0 && pr < (seq + 1.0) * 4096.0) ? (int)(pr - seq * 4096.0) : 0;
+            if (enq - consumed < 3 && enq < limit) {
+                H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq)); ++enq;
+                H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq)); ++enq;
+                continue;
+            }
+            __builtin_ia32_pause();
+            if (++spins > 400000 || h->profile != 0) {          // a slow device (or a profiler): wait for what is queued, then look again
+                H_TRY(hipStreamSynchronize(h->stream));
+                if (*f_seq == seq) { finished = true; break; }
+                if (enq >= limit) return fail(h, "ndt: the optimiser did not finish within its pass budget");
+                spins = 0;
+                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq));
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h->nd_last_passes = out->passes;
+        if (getenv("PCR_NDT_TICKS")) fprintf(stderr, "ndt passes %d: fold %.2f us/pass, controller %.2f us/pass (decide %.2f, tables %.2f)\n", out->passes, out->ticks[0] * 0.01 / std::max(1, out->passes), out->ticks[1] * 0.01 / std::max(1, out->passes), out->ticks[2] * 0.01 / std::max(1, out->passes), out->ticks[3] * 0.01 / std::max(1, out->passes));
+        h->nd_grid_bad = out->grid_overflow || out->grid_stale;
+        h->nd_grid_cells = out->grid_cells;
+        h->nd_grid_checked = true;
+        if (h->nd_grid_bad) return 0;           // the caller prepares the target again and repeats the call
+        if (out->bail) on_device = false;       // the Newton system was (nearly) singular: the host loop below decides, with the SVD
+        else {
+            final_T = out->final_T; conv = out->conv; nr_it = out->nr_it; score = out->score;
+            h->nd_deriv = out->n_deriv; h->nd_hess = out->n_hess;
+        }
+    }
+    if (!on_device) {
+        NdtCtl c;
+        ctl_init(&c, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters);
+        double sums[43];
+        while (!c.done) {
+            if (n_src == 0) memset(sums, 0, sizeof sums);        // an empty scan: computeDerivatives sums nothing
+            else if (ndt_host_pass(&r, c, sums)) return 1;
+            ctl_step(&c, sums);
+        }
+        final_T = c.final_T; conv = c.conv; nr_it = c.nr_it; score = c.score;
+        h->nd_deriv = c.n_deriv; h->nd_hess = c.n_hess;
     }
     for (int i = 0; i < 16; ++i) pose[i] = 0;
     for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) pose[c * 4 + rr] = (double)final_T.R[rr * 3 + c]; pose[12 + rr] = (double)final_T.t[rr]; }
@@ -1086,9 +993,22 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     }
     if (h->method == kNdt) {
         // NdtRegister::scan2Map calls setInputTarget every time, which rebuilds the voxel grid (NdtRegister.cpp:23)
-        if (agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4))) return 1;
-        if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
-        if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
+        // Unsharded: the index is enqueued unchecked (previous box as a hint, cell table as it is) and the alignment's own result
+        // says whether that held; if not, once more with the checked build.
+        const bool try_deferred = !sharded(h) && n_src > 0 && h->prm.reserved[6] == 0;
+        double pose_in[16];
+        memcpy(pose_in, pose, sizeof pose_in);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool deferred = try_deferred && attempt == 0;
+            if (agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4, deferred))) return 1;
+            if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
+            if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
+            if (!deferred) break;
+            if (h->nd_grid_checked && !h->nd_grid_bad) { h->grid.confirm(); break; }
+            // the hint or the table size did not hold (or the device loop handed over to the host before it could tell): checked build
+            h->grid.hint_margin = 8;
+            memcpy(pose, pose_in, sizeof pose_in);
+        }
         if (h->profile >= 1) {
             H_TRY(hipEventRecord(h->ev_end, h->stream));
             H_TRY(hipEventSynchronize(h->ev_end));
@@ -1207,6 +1127,8 @@ void pcr_destroy(pcr_handle* h) {
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
+    if (h->nd_out_host) (void)hipHostFree(h->nd_out_host);
+    h->nd_ctl.release();
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
     h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->timeline.release();
     if (h->result_host) (void)hipHostFree(h->result_host);

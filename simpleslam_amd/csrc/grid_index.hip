@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
             }
             if (pcl_mode) {
                 // pcl::VoxelGrid::applyFilter: min_b = floor(min_p * inverse_leaf_size), float arithmetic throughout
-                const float flo = floorf(lo * h.inv_leaf_f), fhi = floorf(hi * h.inv_leaf_f);
+                float flo = floorf(lo * h.inv_leaf_f), fhi = floorf(hi * h.inv_leaf_f);
+                if (d < 2 && !h.empty && margin_xy) { flo -= (float)margin_xy; fhi += (float)margin_xy; }      // (NDT only, after a hint has failed: voxel membership does not depend on where the lattice starts)
                 const double dim = (double)fhi - (double)flo + 1.0;
                 h.min_b[d] = fabsf(flo) < 2.0e9f ? (int32_t)flo : 0;
                 h.org[d] = (double)flo; h.origin[d] = (double)flo * cell;
@@ -150,6 +151,10 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
         // ijk = static_cast<int>(std::floor(p * inverse_leaf_size) - static_cast<float>(min_b))   (voxel_grid.hpp)
         const int ix = (int)(floorf(x * h.inv_leaf_f) - (float)h.min_b[0]), iy = (int)(floorf(y * h.inv_leaf_f) - (float)h.min_b[1]),
                   iz = (int)(floorf(z * h.inv_leaf_f) - (float)h.min_b[2]);
+        if ((uint32_t)ix >= (uint32_t)h.dims[0] || (uint32_t)iy >= (uint32_t)h.dims[1] || (uint32_t)iz >= (uint32_t)h.dims[2]) {
+            if (outside) *outside = true;       // only possible with a box taken over from the previous build
+            return false;
+        }
         *key = ((uint32_t)iz * (uint32_t)h.dims[1] + (uint32_t)iy) * (uint32_t)h.dims[0] + (uint32_t)ix;
         return true;
     }
@@ -696,14 +701,14 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     if (const char* e = getenv("PCR_TILE_SHIFT")) tshift = atoi(e);      // (development: tile size sweep)
     while (((uint64_t)cell_capacity >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
     const bool tiled_path = tshift <= kMaxTileShift && !force_atomic_path;
-    const bool reuse_header = allow_hint && hint_ok && tiled_path && !pcl_mode && shift == 0.0 && !cb.use && hint_cell == cell && tiled_shift == tshift;
+    const bool reuse_header = allow_hint && hint_ok && tiled_path && hint_pcl == pcl_mode && hint_shift == shift && !cb.use && hint_cell == cell && tiled_shift == tshift;
     hint_ok = false;      // until the host has seen this build's header (confirm())
     used_hint = reuse_header;
-    hint_cell = cell;
+    hint_cell = cell; hint_shift = shift; hint_pcl = pcl_mode;
     if (!reuse_header)
         hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
                            ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode, cb,
-                           (allow_hint && !pcl_mode && shift == 0.0 && !cb.use) ? hint_margin : 0);
+                           (allow_hint && !cb.use) ? hint_margin : 0);
     // Tile size from the CAPACITY of the cell table (the device-side cell count never exceeds it: a larger box is an overflow):
     // ~2048 tiles when the table allows it -- 8 KB of LDS counters per block in the bin kernel, tiles of a few hundred to a few
     // thousand points -- never more than kMaxBins.

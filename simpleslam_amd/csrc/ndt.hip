@@ -12,6 +12,7 @@
 //      -> ndt_hessian_kernel
 //   N2/N4 Newton step + More-Thuente line search: host code in capi.hip.
 #include "pcr_internal.h"
+#include "ndt_opt.h"
 #include "small_math.h"
 
 namespace pcr {
@@ -255,10 +256,8 @@ __device__ __forceinline__ void ndt_block_reduce(double* sh /* [43][kNdtStride] 
 // N3: computeDerivatives
 // ------------------------------------------------------------------------------
 template <bool kHessian>
-__global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+__device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* sh, double* sh2) {
     constexpr int kComp = kHessian ? kNdtComp : 7;
-    __shared__ double sh[kNdtComp * kNdtStride];
-    __shared__ double sh2[2 * 64];
     const GridHeader h = *a.hdr;
     const float gauss_d2 = (float)a.d2;
     double acc = 0.0;
@@ -349,9 +348,7 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArg
 // ------------------------------------------------------------------------------
 // N5: computeHessian (double)
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
-    __shared__ double sh[kNdtComp * kNdtStride];
-    __shared__ double sh2[2 * 64];
+__device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* sh, double* sh2) {
     const GridHeader h = *a.hdr;
     double acc = 0.0;
     const uint32_t step = gridDim.x * kNdtBlock;
@@ -424,6 +421,126 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a,
     }
 }
 
+// the three evaluation kernels of the host-driven loop (pose and tables as kernel arguments)
+template <bool kHessian>
+__global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+    __shared__ double sh[kNdtComp * kNdtStride];
+    __shared__ double sh2[2 * 64];
+    ndt_derivatives_body<kHessian>(a, T, ang, sh, sh2);
+}
+__global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+    __shared__ double sh[kNdtComp * kNdtStride];
+    __shared__ double sh2[2 * 64];
+    ndt_hessian_body(a, T, ang, sh, sh2);
+}
+
+// ------------------------------------------------------------------------------
+// Device-resident optimiser: one PASS = ndt_pass_kernel (whatever the controller asked for: derivatives with or without
+// the Hessian, or computeHessian, at the pose it left in NdtCtl) + ndt_fold_ctl_kernel (fold of the partial sums and one step
+// of the state machine of ndt_opt.h).  The host enqueues passes ahead of the device and only watches a progress word; passes
+// enqueued beyond the end of the optimisation return at once.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNdtBlock) void ndt_pass_kernel(const NdtArgs a, const NdtCtl* __restrict__ ctl) {
+    __shared__ double sh[kNdtComp * kNdtStride];
+    __shared__ double sh2[2 * 64];
+    const int kind = ctl->kind;
+    if (kind == kNdtPassNone) return;
+    const NdtPose T = ctl->T;
+    if (kind == kNdtPassDerivH) ndt_derivatives_body<true>(a, T, ctl->ang, sh, sh2);
+    else if (kind == kNdtPassDeriv) ndt_derivatives_body<false>(a, T, ctl->ang, sh, sh2);
+    else ndt_hessian_body(a, T, ctl->ang, sh, sh2);
+}
+
+__global__ __launch_bounds__(64) void ndt_ctl_init_kernel(NdtCtl* __restrict__ ctl, const NdtPose T0, const double p0, const double p1, const double p2,
+                                                          const double p3, const double p4, const double p5, const double step_size,
+                                                          const double trans_eps, const int max_iters) {
+    if (threadIdx.x == 0) {
+        const double p[6] = {p0, p1, p2, p3, p4, p5};
+        ndt_opt::ctl_init(ctl, T0, p, step_size, trans_eps, max_iters);
+    }
+}
+
+static constexpr int kCtlWords = (int)((sizeof(NdtCtl) + 3) / 4);
+// One block of 768 threads.  Fold: a line-search pass carries 7 sums (score + gradient), the others 43; the threads are laid
+// out as [slice][component] with 8 or 48 components per slice, so that the 7-sum fold is a single round of loads (96 slices x
+// 11 blocks) instead of eight.  Controller: thread 0 takes the decisions (ndt_opt::ctl_decide), six lanes evaluate the six
+// sine/cosine pairs of the new pose at once, thread 0 fills the tables.
+__global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restrict__ partials, uint32_t nblocks, NdtCtl* __restrict__ ctl,
+                                                           const GridHeader* __restrict__ hdr, NdtOut* __restrict__ out, double seq) {
+    __shared__ double sh[96 * 8];                // = 16 * 48
+    __shared__ double sh_sums[48];
+    __shared__ double sh_sc[12];
+    __shared__ int sh_need;
+    __shared__ __attribute__((aligned(16))) uint32_t sh_ctl[kCtlWords];
+    if (ctl->done) return;                       // a pass enqueued beyond the end
+    const unsigned long long t_in = wall_clock64();
+    const int t = threadIdx.x;
+    const bool light = ctl->kind == kNdtPassDeriv;
+    const int cw = light ? 8 : 48, ns = 768 / cw;             // components per slice, slices
+    const int comp = t % cw, slice = t / cw;
+    // the controller's state to LDS (thread 0 then works at LDS latency instead of one memory round trip per field)
+    for (int w = t; w < kCtlWords; w += 768) sh_ctl[w] = reinterpret_cast<const uint32_t*>(ctl)[w];
+    double acc = 0.0;
+    for (uint32_t b0 = slice; b0 < nblocks; b0 += (uint32_t)ns * 12u) {
+        double v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) { const uint32_t b = b0 + (uint32_t)(ns * u); v[u] = b < nblocks ? partials[(size_t)b * 48 + comp] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc += v[u];
+    }
+    sh[slice * cw + comp] = acc;
+    __syncthreads();
+    if (t < 48) {
+        double v = 0.0;
+        if (t < cw) {
+            v = sh[t];
+            for (int s2 = 1; s2 < ns; ++s2) v += sh[s2 * cw + t];
+        }
+        sh_sums[t] = v;                          // (a light pass leaves the Hessian slots at zero: ctl_decide does not read them)
+    }
+    __syncthreads();
+    unsigned long long t_a = 0;
+    if (t == 0) {
+        t_a = wall_clock64();
+        sh_need = ndt_opt::ctl_decide(reinterpret_cast<NdtCtl*>(sh_ctl), sh_sums) ? 1 : 0;
+        reinterpret_cast<NdtCtl*>(sh_ctl)->ticks[2] += (uint32_t)(wall_clock64() - t_a);
+    }
+    __syncthreads();
+    if (sh_need) {
+        if (t < 6) {
+            double sc[2];
+            ndt_opt::trig_pair(reinterpret_cast<const NdtCtl*>(sh_ctl)->x_t, t, sc);
+            sh_sc[2 * t] = sc[0]; sh_sc[2 * t + 1] = sc[1];
+        }
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long t_c = wall_clock64();
+            ndt_opt::ctl_tables(reinterpret_cast<NdtCtl*>(sh_ctl), sh_sc);
+            reinterpret_cast<NdtCtl*>(sh_ctl)->ticks[3] += (uint32_t)(wall_clock64() - t_c);
+        }
+    }
+    if (t == 0) {
+        NdtCtl* c = reinterpret_cast<NdtCtl*>(sh_ctl);
+        const unsigned long long t_b = wall_clock64();
+        c->ticks[0] += (uint32_t)(t_a - t_in); c->ticks[1] += (uint32_t)(t_b - t_a);
+    }
+    __syncthreads();
+    for (int w = t; w < kCtlWords; w += 768) reinterpret_cast<uint32_t*>(ctl)[w] = sh_ctl[w];
+    if (t == 0) {
+        const NdtCtl* c = reinterpret_cast<const NdtCtl*>(sh_ctl);
+        if (c->done) {
+            out->final_T = c->final_T; out->score = c->score;
+            out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
+            for (int i = 0; i < 4; ++i) out->ticks[i] = c->ticks[i];
+            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->pad0 = 0; out->grid_cells = hdr->n_cells;
+            __threadfence_system();
+            __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            __hip_atomic_store(&out->progress, seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // fold per-block partials (48 doubles each) into 48 doubles, fixed order; 16 slices of 48 components, each
 // slice keeps 8 independent loads in flight
 // out lives in host-mapped memory: out[47] receives `seq` LAST (system-scope release), the word the host spins on
@@ -473,6 +590,17 @@ hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtA
     if (compute_hessian) hipLaunchKernelGGL((ndt_derivatives_kernel<true>), dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
     else hipLaunchKernelGGL((ndt_derivatives_kernel<false>), dim3(nb), dim3(kNdtBlock), 0, s, a, T, ang);
     hipLaunchKernelGGL(ndt_sum_partials_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_out48, seq);
+    return hipGetLastError();
+}
+
+hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s) {
+    hipLaunchKernelGGL(ndt_ctl_init_kernel, dim3(1), dim3(64), 0, s, d_ctl, T0, p[0], p[1], p[2], p[3], p[4], p[5], step_size, trans_eps, max_iters);
+    return hipGetLastError();
+}
+hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq) {
+    const uint32_t nb = ndt_blocks(a.n_src);
+    hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
+    hipLaunchKernelGGL(ndt_fold_ctl_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, a.hdr, d_out, seq);
     return hipGetLastError();
 }
 

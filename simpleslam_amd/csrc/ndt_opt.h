@@ -1,0 +1,379 @@
+// ndt_opt.h -- the NDT optimiser as a state machine that is fed one evaluation pass at a time.
+//
+// pclomp::NormalDistributionsTransform::computeTransformation (ndt_omp_impl.hpp:81-171) is a Newton iteration whose step
+// length comes from a More-Thuente line search (computeStepLengthMT, :735-932; trialValueSelectionMT :649-711,
+// updateIntervalMT :713-733).  Every decision it takes depends on 43 numbers -- score, gradient, Hessian -- summed over the
+// scan at one pose.  Here the loop is turned inside out: ndt_ctl_step() consumes the sums of the pass that has just run and
+// leaves in NdtCtl what the NEXT pass must evaluate (pose, angle tables, which of the three kernels), or `done`.
+// The same function runs
+//   * on the device, in the single-block kernel that folds a pass's partial sums (ndt.hip: ndt_fold_ctl_kernel), so that an
+//     alignment is a chain of launches with no host round trip;
+//   * on the host, for sharded targets, where the sums of every pass cross the ranks through a host collective (capi.hip).
+// Host and device differ in two places, both marked below: the libm behind sin/cos, and the 6x6 Newton solve (the host keeps the
+// restated JacobiSVD::solve; the device eliminates with partial pivoting and hands the call back to the host -- `bail` -- when the
+// pivots say that the pseudo-inverse of the SVD could differ from the inverse).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "pcr_internal.h"
+
+namespace pcr {
+
+#if defined(__HIPCC__)
+#define NDT_HD __host__ __device__
+#else
+#define NDT_HD
+#endif
+
+enum : int { kNdtPassDerivH = 0, kNdtPassDeriv = 1, kNdtPassHessian = 2, kNdtPassNone = 3 };
+enum : int { kNdtPhaseInit = 0, kNdtPhaseLsFirst = 1, kNdtPhaseLsLoop = 2, kNdtPhaseLsHess = 3 };
+
+struct NdtCtl {
+    // ---- what the next pass evaluates (read by the pass kernel) ----
+    NdtPose T;
+    NdtAngles ang;
+    int32_t kind, phase;
+    // ---- parameters ----
+    double step_size, trans_eps;
+    int32_t max_iters, pad0;
+    // ---- optimiser state ----
+    double p[6], dir[6], x_t[6], grad[6], hess[36], score;
+    double phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_t, step_min, step_max;
+    int32_t open_interval, interval_converged, it, nr_it, conv, n_deriv, n_hess, bail;
+    NdtPose final_T;
+    int32_t done, passes;
+    uint32_t ticks[4];      // profiling: 100 MHz ticks spent in fold / controller step / write-back, summed over the passes
+};
+
+// what the device-resident loop reports to the host (host-mapped memory; `seq` is written last)
+struct NdtOut {
+    NdtPose final_T;
+    double score;
+    int32_t conv, nr_it, n_deriv, n_hess, bail, passes, grid_overflow, grid_empty, grid_stale, pad0;
+    uint64_t grid_cells;
+    uint32_t ticks[4];
+    double progress;        // number of passes consumed so far (written after every pass: the host keeps the queue ahead of it)
+    double seq;             // == the call's sequence number once the loop has finished
+};
+
+namespace ndt_opt {
+
+NDT_HD inline double min_std(double a, double b) { return (b < a) ? b : a; }      // std::min / std::max, including what they do with NaN
+NDT_HD inline double max_std(double a, double b) { return (a < b) ? b : a; }
+
+// The six sine/cosine pairs a request needs, so that the device can evaluate them in six lanes at once:
+//   k = 0..2  the float angles of the pose, Eigen::AngleAxisf(float(x[3+k])) -> sinf / cosf (evaluated in double and rounded, which is
+//             the correctly rounded float in all but ~1e-9 of the cases on either libm)
+//   k = 3..5  the double angles of computeAngleDerivatives (ndt_omp_impl.hpp:289-312), with its small-angle shortcut
+// sc[2k] = sine, sc[2k+1] = cosine.
+NDT_HD inline void trig_pair(const double x[6], int k, double sc[2]) {
+    if (k < 3) {
+        const double a = (double)(float)x[3 + k];
+        sc[0] = (double)(float)sin(a); sc[1] = (double)(float)cos(a);
+    } else {
+        const double a = x[k];
+        if (fabs(a) < 10e-5) { sc[0] = 0.0; sc[1] = 1.0; } else { sc[0] = sin(a); sc[1] = cos(a); }
+    }
+}
+
+// Eigen::AngleAxisf(angle, Unit{X,Y,Z}).toRotationMatrix(), row-major, from the angle's sine and cosine
+NDT_HD inline void angle_axis(float s, float c, int axis, float R[9]) {
+    float ax[3] = {0, 0, 0};
+    ax[axis] = 1.0f;
+    const float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    const float c1[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+    float tmp;
+    tmp = c1[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+    tmp = c1[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+    tmp = c1[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) R[d * 3 + d] = c1[d] * ax[d] + c;
+}
+NDT_HD inline void mul33(const float A[9], const float B[9], float C[9]) {
+    float o[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { float s = A[r * 3] * B[c]; s += A[r * 3 + 1] * B[3 + c]; s += A[r * 3 + 2] * B[6 + c]; o[r * 3 + c] = s; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) C[i] = o[i];
+}
+// Translation(x[0:3]) * Rx * Ry * Rz evaluated in float (ndt_omp_impl.hpp:146-149,827-830)
+NDT_HD inline void pose_from_trig(const double x[6], const double sc[12], NdtPose* T) {
+    float Rx[9], Ry[9], Rz[9], M[9];
+    angle_axis((float)sc[0], (float)sc[1], 0, Rx); angle_axis((float)sc[2], (float)sc[3], 1, Ry); angle_axis((float)sc[4], (float)sc[5], 2, Rz);
+    mul33(Rx, Ry, M); mul33(M, Rz, T->R);
+    T->t[0] = (float)x[0]; T->t[1] = (float)x[1]; T->t[2] = (float)x[2];
+}
+// computeAngleDerivatives (ndt_omp_impl.hpp:289-395)
+NDT_HD inline void angle_tables_from_trig(const double sc[12], NdtAngles* a) {
+    const double sx = sc[6], cx = sc[7], sy = sc[8], cy = sc[9], sz = sc[10], cz = sc[11];
+    const double J[8][3] = {
+        {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)}, {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},
+        {(-sy * cz), sy * sz, cy}, {sx * cy * cz, (-sx * cy * sz), sx * sy}, {(-cx * cy * cz), cx * cy * sz, (-cx * sy)},
+        {(-cy * sz), (-cy * cz), 0}, {(cx * cz - sx * sy * sz), (-cx * sz - sx * sy * cz), 0}, {(sx * cz + cx * sy * sz), (cx * sy * cz - sx * sz), 0}};
+    const double Hh[15][3] = {
+        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), sx * cy}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), (-cx * cy)},
+        {(cx * cy * cz), (-cx * cy * sz), (cx * sy)}, {(sx * cy * cz), (-sx * cy * sz), (sx * sy)},
+        {(-sx * cz - cx * sy * sz), (sx * sz - cx * sy * cz), 0}, {(cx * cz - sx * sy * sz), (-sx * sy * cz - cx * sz), 0},
+        {(-cy * cz), (cy * sz), (-sy)}, {(-sx * sy * cz), (sx * sy * sz), (sx * cy)}, {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},
+        {(sy * sz), (sy * cz), 0}, {(-sx * cy * sz), (-sx * cy * cz), 0}, {(cx * cy * sz), (cx * cy * cz), 0},
+        {(-cy * cz), (cy * sz), 0}, {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};
+    // (fully unrolled: indexed with a loop variable the two tables would live in scratch memory on the device)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a->jd[r][c] = J[r][c]; a->j[r][c] = (float)J[r][c]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 15; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a->hd[r][c] = Hh[r][c]; a->h[r][c] = (float)Hh[r][c]; }
+    }
+    a->h[6][2] = (float)(sy);   // the float table (:384) writes (sy) where h_ang_d1_ (:362) has (-sy)
+}
+NDT_HD inline void pose_from_p(const double x[6], NdtPose* T) {
+    double sc[12];
+    for (int k = 0; k < 6; ++k) trig_pair(x, k, sc + 2 * k);
+    pose_from_trig(x, sc, T);
+}
+NDT_HD inline void angle_derivatives(const double p[6], NdtAngles* a) {
+    double sc[12];
+    for (int k = 0; k < 6; ++k) trig_pair(p, k, sc + 2 * k);
+    angle_tables_from_trig(sc, a);
+}
+
+// JacobiSVD<Matrix6d>::solve restated: one-sided Jacobi, pseudo-inverse with Eigen's default threshold
+NDT_HD inline void svd6_solve(const double A_in[36], const double b[6], double x[6]) {
+    double U[6][6], V[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { U[i][j] = A_in[i * 6 + j]; V[i][j] = i == j; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 6; ++k) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
+                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 6; ++k) {
+                    const double up = U[k][p], uq = U[k][q]; U[k][p] = c * up - s * uq; U[k][q] = s * up + c * uq;
+                    const double vp = V[k][p], vq = V[k][q]; V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sig[6], smax = 0;
+    for (int j = 0; j < 6; ++j) { double s = 0; for (int k = 0; k < 6; ++k) s += U[k][j] * U[k][j]; sig[j] = sqrt(s); smax = sig[j] > smax ? sig[j] : smax; }
+    const double thr = 6.0 * 2.220446049250313e-16 * smax;
+    for (int i = 0; i < 6; ++i) x[i] = 0;
+    for (int j = 0; j < 6; ++j) {
+        if (!(sig[j] > thr)) continue;
+        double ub = 0;
+        for (int k = 0; k < 6; ++k) ub += (U[k][j] / sig[j]) * b[k];
+        for (int i = 0; i < 6; ++i) x[i] += V[i][j] * (ub / sig[j]);
+    }
+}
+
+// Device flavour of the Newton solve: Gaussian elimination with partial pivoting (a single lane: ~1 us, where the 100-odd
+// dependent rotations of the Jacobi SVD take ~40).  For a matrix of full numerical rank both give A^-1 b to cond(A) * eps.  When a
+// pivot falls below 1e-9 of the largest entry -- or anything is not finite -- the SVD's pseudo-inverse may drop a direction
+// that elimination keeps: returns false and the caller hands the whole alignment to the host path.
+NDT_HD inline bool lu6_solve_guarded(const double A_in[36], const double b[6], double x[6]) {
+    double M[6][7];
+    double amax = 0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) { M[i][j] = A_in[i * 6 + j]; const double a = fabs(M[i][j]); amax = a > amax ? a : amax; }
+        M[i][6] = b[i];
+    }
+    if (!(amax > 0) || !(amax < 1e300)) return false;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        double best = fabs(M[k][k]);
+        for (int i = k + 1; i < 6; ++i) { const double a = fabs(M[i][k]); if (a > best) { best = a; piv = i; } }
+        if (!(best > 1e-9 * amax)) return false;
+        if (piv != k) for (int j = k; j < 7; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+        const double inv = 1.0 / M[k][k];
+        for (int i = k + 1; i < 6; ++i) {
+            const double f = M[i][k] * inv;
+            for (int j = k + 1; j < 7; ++j) M[i][j] -= f * M[k][j];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = M[i][6];
+        for (int j = i + 1; j < 6; ++j) s -= M[i][j] * x[j];
+        x[i] = s / M[i][i];
+    }
+    for (int i = 0; i < 6; ++i) if (!(fabs(x[i]) < 1e300)) return false;
+    return true;
+}
+
+// updateIntervalMT (:713-733)
+NDT_HD inline bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
+    if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
+    else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    else if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    return true;
+}
+// trialValueSelectionMT (:649-711)
+NDT_HD inline double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+    if (f_t > f_l) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+    } else if (g_t * g_l < 0) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+    } else if (fabs(g_t) <= fabs(g_l)) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        const double nx = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+        const double lim = a_t + 0.66 * (a_u - a_t);
+        return a_t > a_l ? min_std(lim, nx) : max_std(lim, nx);
+    }
+    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+// ---- the state machine -------------------------------------------------------------------------------------------------
+// Start: the first pass evaluates score, gradient and Hessian at the initial guess (computeTransformation :113-118).
+NDT_HD inline void ctl_init(NdtCtl* c, const NdtPose& T0, const double p0[6], double step_size, double trans_eps, int max_iters) {
+    c->T = T0; c->final_T = T0;
+    for (int i = 0; i < 6; ++i) { c->p[i] = p0[i]; c->dir[i] = 0; c->x_t[i] = p0[i]; c->grad[i] = 0; }
+    for (int i = 0; i < 36; ++i) c->hess[i] = 0;
+    angle_derivatives(p0, &c->ang);
+    c->kind = kNdtPassDerivH; c->phase = kNdtPhaseInit;
+    c->step_size = step_size; c->trans_eps = trans_eps; c->max_iters = max_iters; c->pad0 = 0;
+    c->score = 0; c->phi_0 = c->d_phi_0 = c->a_l = c->f_l = c->g_l = c->a_u = c->f_u = c->g_u = c->a_t = 0;
+    c->step_min = trans_eps / 2; c->step_max = step_size;
+    c->open_interval = 1; c->interval_converged = 0; c->it = 0; c->nr_it = 0; c->conv = 0; c->n_deriv = c->n_hess = 0; c->bail = 0;
+    c->done = 0; c->passes = 0;
+    for (int i = 0; i < 4; ++i) c->ticks[i] = 0;
+}
+
+// the pose and the angle tables of the next pass from the six sine/cosine pairs of x_t (trig_pair)
+NDT_HD inline void ctl_tables(NdtCtl* c, const double sc[12]) {
+    pose_from_trig(c->x_t, sc, &c->T);
+    angle_tables_from_trig(sc, &c->ang);
+}
+
+// `sums` = score, gradient[6], Hessian[36] of the pass that ctl->kind asked for.  Leaves the next request in *c (or done).
+// Returns true when the next pass evaluates at a NEW point x_t: the caller then owes ctl_tables() (the trigonometry is kept out
+// of this function so that the device can spread it over lanes).
+NDT_HD inline bool ctl_decide(NdtCtl* c, const double sums[43]) {
+    const double mu = 1.e-4, nu = 0.9;
+    const int max_it = 10;
+    if (c->done) return false;
+    c->passes += 1;
+    // ---- take the sums in ----
+    if (c->kind == kNdtPassHessian) {
+        c->n_hess += 1;
+        for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
+    } else {
+        c->n_deriv += 1;
+        c->score = sums[0];
+        for (int i = 0; i < 6; ++i) c->grad[i] = sums[1 + i];
+        for (int i = 0; i < 36; ++i) c->hess[i] = c->kind == kNdtPassDerivH ? sums[7 + i] : 0.0;      // (computeDerivatives zeroes it either way, :183)
+    }
+    bool line_search_over = false;
+    if (c->phase == kNdtPhaseLsFirst || c->phase == kNdtPhaseLsLoop) {
+        // computeStepLengthMT after updateDerivatives at x_t (:832-852 the first time, :880-926 inside the loop)
+        const double phi_t = -c->score;
+        double d_phi_t = 0;
+        for (int i = 0; i < 6; ++i) d_phi_t += c->grad[i] * c->dir[i];
+        d_phi_t = -d_phi_t;
+        const double psi_t = phi_t - c->phi_0 - mu * c->d_phi_0 * c->a_t, d_psi_t = d_phi_t - mu * c->d_phi_0;
+        if (c->phase == kNdtPhaseLsLoop) {
+            if (c->open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+                c->open_interval = 0;
+                c->f_l = c->f_l + c->phi_0 - mu * c->d_phi_0 * c->a_l; c->g_l = c->g_l + mu * c->d_phi_0;
+                c->f_u = c->f_u + c->phi_0 - mu * c->d_phi_0 * c->a_u; c->g_u = c->g_u + mu * c->d_phi_0;
+            }
+            if (c->open_interval) c->interval_converged = update_interval(c->a_l, c->f_l, c->g_l, c->a_u, c->f_u, c->g_u, c->a_t, psi_t, d_psi_t) ? 1 : 0;
+            else c->interval_converged = update_interval(c->a_l, c->f_l, c->g_l, c->a_u, c->f_u, c->g_u, c->a_t, phi_t, d_phi_t) ? 1 : 0;
+            c->it += 1;
+        }
+        if (!c->interval_converged && c->it < max_it && !(psi_t <= 0 && d_phi_t <= -nu * c->d_phi_0)) {
+            if (c->open_interval) c->a_t = trial_value(c->a_l, c->f_l, c->g_l, c->a_u, c->f_u, c->g_u, c->a_t, psi_t, d_psi_t);
+            else c->a_t = trial_value(c->a_l, c->f_l, c->g_l, c->a_u, c->f_u, c->g_u, c->a_t, phi_t, d_phi_t);
+            c->a_t = min_std(c->a_t, c->step_max);
+            c->a_t = max_std(c->a_t, c->step_min);
+            for (int i = 0; i < 6; ++i) c->x_t[i] = c->p[i] + c->dir[i] * c->a_t;
+            c->kind = kNdtPassDeriv; c->phase = kNdtPhaseLsLoop;
+            return true;
+        }
+        if (c->it) {      // computeHessian (:928-929): double precision, with the pose and the tables of the last pass
+            c->kind = kNdtPassHessian; c->phase = kNdtPhaseLsHess;
+            return false;
+        }
+        line_search_over = true;
+    } else if (c->phase == kNdtPhaseLsHess) {
+        line_search_over = true;
+    }
+    // ---- computeTransformation's loop (:120-160); passes that need no evaluation are walked through right here ----
+    for (;;) {
+        if (line_search_over) {
+            const double nrm = c->a_t;
+            c->final_T = c->T;
+            for (int i = 0; i < 6; ++i) c->p[i] += c->dir[i] * nrm;
+            if (c->nr_it > c->max_iters || (c->nr_it && fabs(nrm) < c->trans_eps)) c->conv = 1;
+            c->nr_it += 1;
+            if (c->conv) { c->done = 1; c->kind = kNdtPassNone; return false; }
+        }
+        // Newton direction (:124-135)
+        double rhs[6], dp[6];
+        for (int i = 0; i < 6; ++i) rhs[i] = -c->grad[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!lu6_solve_guarded(c->hess, rhs, dp)) { c->bail = 1; c->done = 1; c->kind = kNdtPassNone; return false; }
+#else
+        svd6_solve(c->hess, rhs, dp);
+#endif
+        double nrm = 0;
+        for (int i = 0; i < 6; ++i) nrm += dp[i] * dp[i];
+        nrm = sqrt(nrm);
+        if (nrm == 0 || nrm != nrm) { c->conv = nrm == nrm ? 1 : 0; c->done = 1; c->kind = kNdtPassNone; return false; }
+        for (int i = 0; i < 6; ++i) c->dir[i] = dp[i] / nrm;
+        // computeStepLengthMT up to its first evaluation (:735-830)
+        c->phi_0 = -c->score;
+        double d0 = 0;
+        for (int i = 0; i < 6; ++i) d0 += c->grad[i] * c->dir[i];
+        d0 = -d0;
+        if (d0 >= 0) {
+            if (d0 == 0) { c->a_t = 0; line_search_over = true; continue; }      // "not a descent direction": step 0, T untouched
+            d0 *= -1;
+            for (int i = 0; i < 6; ++i) c->dir[i] *= -1;
+        }
+        c->d_phi_0 = d0;
+        c->it = 0;
+        c->a_l = 0; c->a_u = 0;
+        c->f_l = c->phi_0 - c->phi_0 - mu * d0 * c->a_l; c->g_l = d0 - mu * d0;
+        c->f_u = c->phi_0 - c->phi_0 - mu * d0 * c->a_u; c->g_u = d0 - mu * d0;
+        c->step_max = c->step_size; c->step_min = c->trans_eps / 2;
+        c->interval_converged = (c->step_max - c->step_min) < 0 ? 1 : 0;
+        c->open_interval = 1;
+        c->a_t = min_std(nrm, c->step_max);
+        c->a_t = max_std(c->a_t, c->step_min);
+        for (int i = 0; i < 6; ++i) c->x_t[i] = c->p[i] + c->dir[i] * c->a_t;
+        c->kind = kNdtPassDerivH; c->phase = kNdtPhaseLsFirst;
+        return true;
+    }
+}
+
+// the whole step on one thread (host loop)
+NDT_HD inline void ctl_step(NdtCtl* c, const double sums[43]) {
+    if (ctl_decide(c, sums)) {
+        double sc[12];
+        for (int k = 0; k < 6; ++k) trig_pair(c->x_t, k, sc + 2 * k);
+        ctl_tables(c, sc);
+    }
+}
+
+}  // namespace ndt_opt
+}  // namespace pcr

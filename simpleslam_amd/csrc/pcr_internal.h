@@ -152,7 +152,8 @@ struct GridIndex {
     // the bounding-box pass and reuse that header -- a sub-map changes by a key frame at a time.  The bin kernel checks every
     // point against the box; one outside sets header.stale and the caller rebuilds with a fresh (and from then on padded) box.
     bool hint_ok = false;
-    double hint_cell = 0.0;
+    double hint_cell = 0.0, hint_shift = 0.0;
+    int hint_pcl = 0;                           // lattice kind of the build the hint comes from (a hint serves only a build of the same kind)
     int hint_margin = 0;                        // cells added around a fresh box in x and y (0 until a hint has failed once)
     bool used_hint = false;                     // the last build() reused the header
     void confirm() { hint_ok = valid && tiled_shift >= 0; }
@@ -246,6 +247,11 @@ hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* 
                              int min_points, double eig_mult, hipStream_t s);
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq = 0.0);
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
+// device-resident optimiser (ndt_opt.h): controller state in HBM, result in host-mapped memory
+struct NdtCtl;
+struct NdtOut;
+hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s);
+hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq);
 uint32_t ndt_blocks(uint32_t n_src);
 
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);

@@ -125,3 +125,31 @@ def test_edge_cases_match_oracle(gpu, nd_world):
         if np.isfinite(po).all():
             dt, dr = synth.pose_error(pose, po)
             assert dt <= 1e-4 and dr <= 1e-4, (name, dt, dr)
+
+
+def test_device_resident_optimiser_equals_the_host_driven_one(gpu, nd_world):
+    """The Newton / More-Thuente loop is one state machine (csrc/ndt_opt.h) that runs on the device by default (no host round
+    trip between evaluation passes) and on the host for sharded targets (pcr_params.reserved[6] = 1 selects it here).  Same
+    decisions -- convergence flag, iterations, derivative and Hessian passes -- and the same Matrix4f pose up to the last bits
+    of the 6x6 solve (elimination on the device, the restated JacobiSVD on the host) and of the two libms' sine."""
+    from simpleslam_amd.pcr import default_params
+    w = nd_world
+    p_host = default_params()
+    p_host.reserved[6] = 1
+    dev, host = NdtRegister(), NdtRegister(params=p_host)
+    for seed, tr, rd in ((31, 0.1, 0.5), (32, 0.15, 0.8), (33, 0.05, 0.3), (34, 0.4, 2.0), (35, 0.0, 0.0)):
+        T0 = synth.perturb(w["truth"], seed, trans=tr, rot_deg=rd) if tr else w["truth"].copy()
+        pd, ph = T0.copy(), T0.copy()
+        cd = dev.scan2Map(w["scan"], w["map"], pd)
+        ch = host.scan2Map(w["scan"], w["map"], ph)
+        assert cd == ch, seed
+        sd, sh = dev.stats(), host.stats()
+        assert (sd["iterations"], sd["kernel_launches"]) == (sh["iterations"], sh["kernel_launches"]), (seed, sd, sh)
+        dt, dr = synth.pose_error(pd, ph)
+        assert dt <= 2e-6 and dr <= 2e-6, (seed, dt, dr)      # (a float ulp of the pose at 10 m is 1e-6)
+    # many calls on one handle: passes enqueued beyond the end of one alignment must not leak into the next
+    T0 = synth.perturb(w["truth"], 31, trans=0.1, rot_deg=0.5)
+    first = T0.copy(); dev.scan2Map(w["scan"], w["map"], first)
+    for _ in range(20):
+        p = T0.copy(); dev.scan2Map(w["scan"], w["map"], p)
+        np.testing.assert_array_equal(p, first)
