@@ -916,8 +916,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
             if (*f_seq == seq) { finished = true; break; }
             const double pr = *f_prog;
             const int consumed = (pr >= seq * 4096.0 && pr < (seq + 1.0) * 4096.0) ? (int)(pr - seq * 4096.0) : 0;
-            if (enq - consumed < 3 && enq < limit) {
-                H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq)); ++enq;
+            if (enq - consumed < 2 && enq < limit) {       // two passes ahead of the device: a pass enqueued beyond the end costs ~10 us of device time
                 H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq)); ++enq;
                 continue;
             }

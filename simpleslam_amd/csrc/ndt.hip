@@ -69,9 +69,11 @@ __device__ inline void inv3_general(const double m[9], double out[9]) {
 static constexpr double kFix1 = 17592186044416.0;   // 2^44 for sums of (x - c)
 static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(x - c)^T
 
-// Pass 1: the cells with enough points, compacted into a list (one atomic per wave); every slot is cleared.  Only a
-// tenth of the cells of a lidar map qualify: with one thread per cell nearly every wave carried a few of them and ran
-// the whole eigen-decomposition path at ~10 % lane utilisation.
+// Pass 1: the cells with enough points, compacted into a list; every slot is cleared.  Only a tenth of the cells of a lidar map
+// qualify: with one thread per cell nearly every wave carried a few of them and ran the whole eigen-decomposition path at ~10 %
+// lane utilisation.  A block owns a contiguous range of cells, counts its candidates, claims room for all of them with ONE
+// atomic on the shared counter (an atomic per 1024 cells was 1 600 same-address atomics for a 5 M-point map: they serialise at
+// the memory side, 31 us) and then writes them; the order of the list is immaterial.
 __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_t* __restrict__ vox_slot, uint32_t* __restrict__ list,
                                                              uint32_t* __restrict__ count, int min_points, uint32_t capacity) {
     __shared__ uint32_t sh_w[4];
@@ -79,36 +81,46 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
     const GridHeader h = *g.hdr;
     if (h.overflow) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // 1024 cells per block and step: four consecutive cells per thread, ONE atomic on the shared counter per step
-    // (an atomic per wave made 47 k waves queue up on one address: 280 us for 3 M cells)
-    const uint64_t n_round = (h.n_cells + 1023) & ~1023ull;
-    for (uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; t0 < n_round; t0 += (uint64_t)gridDim.x * 1024) {
-        bool cand[4];
-        uint32_t mine = 0;
+    // this block's cells: [c_lo, c_hi), whole steps of 1024 (four consecutive cells per thread)
+    const uint64_t steps = (h.n_cells + 1023) / 1024, per = (steps + gridDim.x - 1) / gridDim.x;
+    const uint64_t s_lo = (uint64_t)blockIdx.x * per, s_hi = s_lo + per < steps ? s_lo + per : steps;
+    if (s_lo >= s_hi) return;
+    // round 1: count (and clear the slots)
+    uint32_t mine_total = 0;
+    for (uint64_t st = s_lo; st < s_hi; ++st) {
+        const uint64_t t0 = st * 1024 + (uint64_t)threadIdx.x * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
-            cand[u] = false;
             if (t < h.n_cells) {
-                cand[u] = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
+                mine_total += (!h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points) ? 1u : 0u;
                 vox_slot[t] = 0u;
             }
-            mine += cand[u] ? 1u : 0u;
         }
-        uint32_t inc = mine;                       // exclusive prefix over the block
+    }
+    uint32_t inc = mine_total;                     // inclusive prefix over the block
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
-        if (lane == 63) sh_w[wave] = inc;
-        __syncthreads();
-        uint32_t off = 0, tot = 0;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+    if (lane == 63) sh_w[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { if (w < wave) off += sh_w[w]; tot += sh_w[w]; }
-        if (threadIdx.x == 0) sh_base = tot ? atomicAdd(count, tot) : 0u;
-        __syncthreads();
-        uint32_t pos = sh_base + off + inc - mine;
+    for (int w = 0; w < 4; ++w) { if (w < wave) off += sh_w[w]; tot += sh_w[w]; }
+    if (threadIdx.x == 0) sh_base = tot ? atomicAdd(count, tot) : 0u;
+    __syncthreads();
+    if (!tot) return;
+    // round 2: the same cells again (cell_start is L2-resident), now with a place to put them
+    uint32_t pos = sh_base + off + inc - mine_total;
+    for (uint64_t st = s_lo; st < s_hi; ++st) {
+        const uint64_t t0 = st * 1024 + (uint64_t)threadIdx.x * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (cand[u]) { if (pos < capacity) list[pos] = (uint32_t)(t0 + u); ++pos; }      // (capacity = points / min_points: never short)
-        __syncthreads();                           // sh_w / sh_base are reused by the next step
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t t = t0 + u;
+            if (t < h.n_cells && !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points) {
+                if (pos < capacity) list[pos] = (uint32_t)t;      // (capacity = points / min_points: never short)
+                ++pos;
+            }
+        }
     }
 }
 
@@ -231,24 +243,39 @@ static constexpr int kNdtBlock = 128;
 static constexpr int kNdtStride = 130;
 static constexpr int kNdtComp = 43;    // score, gradient 6, Hessian 36
 
-// fold v[43] of every thread of the block into partials[block][48] in a fixed order
+// Fold v[kComp] of every thread of the block into partials[block][48] in a fixed order.  The components go through LDS sixteen
+// at a time ([16][kNdtStride] doubles = 16.6 KB: with all 43 at once a block held 45 KB and only three fitted on a CU, so a quarter
+// of the 1024 blocks of a pass ran as a second round): thread (e = tid & 15, part = tid >> 4) adds 16 of the 128 values of
+// component c0 + e, the parts of a wave are combined with two shuffles, and lanes 0..15 of each wave carry the running sums.
+static constexpr int kNdtChunk = 16;
+static constexpr int kNdtChunks = (kNdtComp + kNdtChunk - 1) / kNdtChunk;      // 3
 template <int kComp>     // 43 with the Hessian, 7 (score + gradient) in the passes of the line search that do not need it
-__device__ __forceinline__ void ndt_block_reduce(double* sh /* [43][kNdtStride] */, double* sh2 /* [2][64] */, const double v[kComp],
-                                                 double& acc, bool last, double* __restrict__ partials) {
-    const int tid = threadIdx.x, e = tid & 63, ch = tid >> 6;
+__device__ __forceinline__ void ndt_block_reduce(double* sh /* [16][kNdtStride] */, double* sh2 /* [2][48] */, const double v[kComp],
+                                                 double acc[kNdtChunks], bool last, double* __restrict__ partials) {
+    const int tid = threadIdx.x, e = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < kComp; ++k) sh[k * kNdtStride + tid] = v[k];
-    __syncthreads();
-    if (e < kComp) {
-        const double* row = sh + e * kNdtStride + ch * 64;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) acc += row[k];
-    }
-    __syncthreads();
-    if (last) {
-        sh2[ch * 64 + e] = e < kComp ? acc : 0.0;
+    for (int ch = 0; ch * kNdtChunk < kComp; ++ch) {
+        const int c0 = ch * kNdtChunk;
+#pragma unroll
+        for (int k = 0; k < kNdtChunk; ++k) if (c0 + k < kComp) sh[k * kNdtStride + tid] = v[c0 + k];
         __syncthreads();
-        if (tid < 48) partials[(size_t)blockIdx.x * 48 + tid] = tid < kComp ? sh2[tid] + sh2[64 + tid] : 0.0;
+        double s = 0.0;
+        if (c0 + e < kComp) {
+            const double* row = sh + e * kNdtStride + part * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += row[k];
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16) acc[ch] += s;
+        __syncthreads();
+    }
+    if (last) {
+#pragma unroll
+        for (int ch = 0; ch * kNdtChunk < kComp; ++ch)
+            if (lane < 16 && ch * kNdtChunk + lane < 48) sh2[wave * 48 + ch * kNdtChunk + lane] = acc[ch];
+        __syncthreads();
+        if (tid < 48) partials[(size_t)blockIdx.x * 48 + tid] = tid < kComp ? sh2[tid] + sh2[48 + tid] : 0.0;
     }
 }
 
@@ -260,7 +287,7 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
     constexpr int kComp = kHessian ? kNdtComp : 7;
     const GridHeader h = *a.hdr;
     const float gauss_d2 = (float)a.d2;
-    double acc = 0.0;
+    double acc[kNdtChunks] = {0.0, 0.0, 0.0};
     const uint32_t step = gridDim.x * kNdtBlock;
     for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
         const uint32_t idx = base + threadIdx.x;
@@ -350,7 +377,7 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* sh, double* sh2) {
     const GridHeader h = *a.hdr;
-    double acc = 0.0;
+    double acc[kNdtChunks] = {0.0, 0.0, 0.0};
     const uint32_t step = gridDim.x * kNdtBlock;
     for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
         const uint32_t idx = base + threadIdx.x;
@@ -423,14 +450,14 @@ __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose
 
 // the three evaluation kernels of the host-driven loop (pose and tables as kernel arguments)
 template <bool kHessian>
-__global__ __launch_bounds__(kNdtBlock) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
-    __shared__ double sh[kNdtComp * kNdtStride];
-    __shared__ double sh2[2 * 64];
+__global__ __launch_bounds__(kNdtBlock, 2) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+    __shared__ double sh[kNdtChunk * kNdtStride];
+    __shared__ double sh2[2 * 48];
     ndt_derivatives_body<kHessian>(a, T, ang, sh, sh2);
 }
-__global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
-    __shared__ double sh[kNdtComp * kNdtStride];
-    __shared__ double sh2[2 * 64];
+__global__ __launch_bounds__(kNdtBlock, 2) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
+    __shared__ double sh[kNdtChunk * kNdtStride];
+    __shared__ double sh2[2 * 48];
     ndt_hessian_body(a, T, ang, sh, sh2);
 }
 
@@ -440,9 +467,9 @@ __global__ __launch_bounds__(kNdtBlock) void ndt_hessian_kernel(const NdtArgs a,
 // of the state machine of ndt_opt.h).  The host enqueues passes ahead of the device and only watches a progress word; passes
 // enqueued beyond the end of the optimisation return at once.
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNdtBlock) void ndt_pass_kernel(const NdtArgs a, const NdtCtl* __restrict__ ctl) {
-    __shared__ double sh[kNdtComp * kNdtStride];
-    __shared__ double sh2[2 * 64];
+__global__ __launch_bounds__(kNdtBlock, 2) void ndt_pass_kernel(const NdtArgs a, const NdtCtl* __restrict__ ctl) {
+    __shared__ double sh[kNdtChunk * kNdtStride];
+    __shared__ double sh2[2 * 48];
     const int kind = ctl->kind;
     if (kind == kNdtPassNone) return;
     const NdtPose T = ctl->T;
@@ -578,7 +605,7 @@ hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* 
                              int min_points, double eig_mult, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const int blocks = (int)std::min<size_t>(4096, grid.cell_capacity / 1024 + 1);
+    const int blocks = (int)std::min<size_t>(512, grid.cell_capacity / 1024 + 1);
     hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     const int vblocks = (int)std::min<size_t>(65535, list_capacity / 256 + 1);
     hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
