@@ -90,7 +90,7 @@ typedef struct pcr_stats {
     int32_t iterations;     /* linearisations performed */
     int64_t n_src, n_dst;
     int32_t attempts;       /* LOAM: passes over the iteration loop (> 1: the cell table grew, or a cut index was widened) */
-    int32_t pad_;
+    int32_t target_builds;  /* pcr_scan2map_submap: times this handle has (re)built its target structures (one per sub-map generation) */
 } pcr_stats;
 
 void pcr_default_params(pcr_params* p);
@@ -184,6 +184,17 @@ int pcr_map_update(pcr_map* m, const double position[3], double radius, double g
 int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid_size, size_t* n_submap);
 const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes);
 int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size_t* n);
+/* Identity of the store and of the sub-map it currently holds: every pcr_map_update / pcr_map_update_window starts a new
+ * generation.  This is the explicit version of what the reference's registrars approximate by comparing cloud POINTERS
+ * (fast_gicp_impl.hpp:83-90): a structure built for generation g is valid exactly while the map reports g. */
+int pcr_map_generation(const pcr_map* m, uint64_t* id, uint64_t* generation);
+/* scan2Map against the sub-map `m` currently holds (stride = the map's).  The handle keeps the target structures it builds
+ * -- LOAM's grid index, NDT's voxel Gaussians, VGICP's covariances and voxel map -- together with (id, generation) of the
+ * sub-map they were built from and rebuilds them only when the map has moved on: LidarOdometry registers several scans
+ * against one sub-map between two MapManager updates (frontend/src/LidarOdometry.cpp:184, MapManager.cpp:151-201).  Same
+ * result as pcr_scan2map_device on pcr_map_submap(m), bit for bit. */
+int pcr_scan2map_submap(pcr_handle* h, const void* src, size_t n_src, int src_on_device, const pcr_map* m,
+                        double pose_inout[16], int* converged);
 
 /* ---- the loop-closure descriptor: backend/src/ScanContext.cpp (20 rings x 60 sectors over 80 m) ----
  * pcr_sc_add = addContext (:56-66): the polar binning of the (down-sampled, lidar-frame) scan runs on the device, the ring

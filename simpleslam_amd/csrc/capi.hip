@@ -105,6 +105,8 @@ struct pcr_handle {
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
     NdtOut* nd_out_host = nullptr;       // host-mapped: its result and progress word
     NdtOut* nd_out_dev = nullptr;
+    uint64_t map_id = 0, map_gen = 0;    // pcr_scan2map_submap: the sub-map the target structures were built from
+    long long target_builds = 0;         // ... and how often it had to build them
     bool nd_grid_checked = false, nd_grid_bad = false;      // the device loop reported the state of the index header with its result
     uint64_t nd_grid_cells = 0;
     int nd_last_passes = 8;              // passes the previous alignment took: how many are enqueued up front
@@ -980,6 +982,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
                 double pose[16], int* converged, bool on_device) {
     if (!h) return 1;
     h->err.clear();
+    h->map_id = 0; h->map_gen = 0;      // whatever target structures exist after this call were not built from a pcr_map generation
     if (!pose) return fail(h, "pose_inout is NULL");
     if ((n_src && !src) || (n_dst && !dst)) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
@@ -1157,6 +1160,20 @@ int pcr_scan2map_device(pcr_handle* h, const void* d_src, size_t n_src, const vo
     return do_scan2map(h, d_src, n_src, d_dst, n_dst, stride_bytes, pose_inout, converged, true);
 }
 
+// target structures of the handle's method from points in HBM that outlive them (the staging copy of pcr_set_target, or a
+// pcr_map's sub-map for as long as its generation lasts)
+static int prepare_target_from(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_bytes) {
+    h->map_id = 0; h->map_gen = 0;      // (pcr_scan2map_submap sets them after a successful preparation)
+    if (h->method == kVgicp) return agree_prepared(h, vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4));
+    if (h->method == kNdt) return agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4));
+    h->clamp.use = 0;
+    // settle the cell-table size now so that pcr_align never has to rebuild
+    int rc = build_target(h, d_dst, n_dst, stride_bytes / 4);
+    if (!rc) rc = settle_loam_index(h, nullptr, 0, 0, nullptr);
+    if (rc) { h->have_target = false; h->grid.valid = false; }
+    return agree_prepared(h, rc);
+}
+
 int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_bytes, int on_device) {
     if (!h) return 1;
     h->err.clear();
@@ -1167,14 +1184,33 @@ int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_b
     const size_t bytes = n_dst * stride_bytes;
     H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
     if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-    if (h->method == kVgicp) return agree_prepared(h, vgicp_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4));
-    if (h->method == kNdt) return agree_prepared(h, ndt_prepare_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4));
-    h->clamp.use = 0;
-    // settle the cell-table size now so that pcr_align never has to rebuild
-    int rc = build_target(h, h->tgt_stage.as<float>(), n_dst, stride_bytes / 4);
-    if (!rc) rc = settle_loam_index(h, nullptr, 0, 0, nullptr);
-    if (rc) { h->have_target = false; h->grid.valid = false; }
-    return agree_prepared(h, rc);
+    return prepare_target_from(h, h->tgt_stage.as<float>(), n_dst, stride_bytes);
+}
+
+int pcr_scan2map_submap(pcr_handle* h, const void* src, size_t n_src, int src_on_device, const pcr_map* m, double pose_inout[16],
+                        int* converged) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!m) return fail(h, "map is NULL");
+    uint64_t id = 0, gen = 0;
+    size_t n_dst = 0, stride_bytes = 0;
+    if (pcr_map_generation(m, &id, &gen)) return fail(h, "map is not usable");
+    const void* d_dst = pcr_map_submap(m, &n_dst, &stride_bytes);
+    if (!d_dst || n_dst == 0 || stride_bytes == 0) {
+        // an empty sub-map (no key frame selected yet): the ordinary entry point defines what registration against nothing returns
+        if (stride_bytes == 0) stride_bytes = 16;
+        pcr_invalidate_target(h);
+        return do_scan2map(h, src, n_src, nullptr, 0, stride_bytes, pose_inout, converged, src_on_device != 0);
+    }
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    const bool current = h->map_id == id && h->map_gen == gen && h->have_target &&
+                         (h->method == kLoam ? h->grid.valid && !h->clamp.use : (h->method == kNdt ? h->nd_target_ready : h->vg_target_ready));
+    if (!current) {
+        if (prepare_target_from(h, static_cast<const float*>(d_dst), n_dst, stride_bytes)) return 1;
+        h->map_id = id; h->map_gen = gen;
+        h->target_builds += 1;
+    }
+    return pcr_align(h, src, n_src, stride_bytes, src_on_device, pose_inout, converged);
 }
 
 int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, double pose_inout[16],
@@ -1195,6 +1231,7 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
 int pcr_invalidate_target(pcr_handle* h) {
     if (!h) return 1;
     h->have_target = false; h->grid.valid = false; h->vg_target_ready = false; h->nd_target_ready = false;
+    h->map_id = 0; h->map_gen = 0;
     return 0;
 }
 
@@ -1437,6 +1474,7 @@ int pcr_get_timeline(pcr_handle* h, uint64_t* out, size_t capacity, int* launche
 int pcr_get_stats(pcr_handle* h, pcr_stats* out) {
     if (!h || !out) return 1;
     *out = h->stats;
+    out->target_builds = (int32_t)h->target_builds;
     return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,7 @@ struct pcr_map {
     std::vector<Kf> kfs;
     std::vector<long long> selected;  // mSubmapIdx
     size_t n_submap = 0;
+    uint64_t id = 0, generation = 0;  // identity of this store and of the sub-map it currently holds (every update is a new generation)
     std::string err;
 };
 
@@ -88,7 +90,9 @@ pcr_map* pcr_map_create(int device) {
     p.device = device;
     pcr_handle* h = pcr_create("loam", &p);
     if (!h) { g_map_err = pcr_last_error(nullptr); return nullptr; }
+    static std::atomic<uint64_t> next_id{1};
     pcr_map* m = new pcr_map;
+    m->id = next_id.fetch_add(1);
     m->filter = h;
     if (device >= 0) m->device = device; else (void)hipGetDevice(&m->device);
     return m;
@@ -171,6 +175,7 @@ int pcr_map_update(pcr_map* m, const double position[3], double radius, double g
     M_TRY(hipSetDevice(m->device));
     m->selected.clear();
     m->n_submap = 0;
+    m->generation += 1;           // whatever happens below, the previous sub-map is gone
     if (n_submap) *n_submap = 0;
     if (m->kfs.empty()) return 0;                          // "no any keyframes to update!!" (MapManager.cpp:166-169)
     // radius search over the key-frame positions: squared distance in double, accumulated x, y, z; strict '<'
@@ -191,6 +196,7 @@ int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid
     M_TRY(hipSetDevice(m->device));
     m->selected.clear();
     m->n_submap = 0;
+    m->generation += 1;           // whatever happens below, the previous sub-map is gone
     if (n_submap) *n_submap = 0;
     const long long count = (long long)m->kfs.size();
     for (long long i = -(long long)search_num; i <= (long long)search_num; ++i) {      // LoopClosureManager.cpp:46-57
@@ -205,6 +211,13 @@ const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes) {
     if (n) *n = m->n_submap;
     if (stride_bytes) *stride_bytes = m->stride;
     return m->n_submap ? m->submap.p : nullptr;
+}
+
+int pcr_map_generation(const pcr_map* m, uint64_t* id, uint64_t* generation) {
+    if (!m) return 1;
+    if (id) *id = m->id;
+    if (generation) *generation = m->generation;
+    return 0;
 }
 
 int pcr_map_submap_indices(const pcr_map* m, int64_t* idx, size_t capacity, size_t* n) {

@@ -120,16 +120,15 @@ public:
         return idx;
     }
     const void* devicePointer(size_t* n, size_t* stride_bytes) const { return pcr_map_submap(m_, n, stride_bytes); }
+    const pcr_map* handle() const { return m_; }
+    uint64_t generation() const { uint64_t id = 0, g = 0; pcr_map_generation(m_, &id, &g); return g; }
 };
 
 inline bool HipRegister::scan2Map(const PC_cPtr& src, const SubMap& dst, pose_t& res) {
-    size_t n = 0, stride = 0;
-    const void* d_map = dst.devicePointer(&n, &stride);
-    if (stride && stride != sizeof(PointXYZI)) throw std::runtime_error("sub-map and scan must share one point layout");
-    // device-resident target + host scan: index the sub-map where it lies, then align the (uploaded) scan against it
+    // The handle keeps the target structures it builds from the sub-map for as long as the map stays at the same generation
+    // (pcr_scan2map_submap): LidarOdometry registers several scans between two MapManager::updateMap calls.
     int conv = 0;
-    if (pcr_set_target(h_, d_map, n, sizeof(PointXYZI), 1)) throw std::runtime_error(pcr_last_error(h_));
-    if (pcr_align(h_, src->points.data(), src->size(), sizeof(PointXYZI), 0, res.data(), &conv)) throw std::runtime_error(pcr_last_error(h_));
+    if (pcr_scan2map_submap(h_, src->points.data(), src->size(), 0, dst.handle(), res.data(), &conv)) throw std::runtime_error(pcr_last_error(h_));
     isConverge = conv != 0;
     return isConverge;
 }

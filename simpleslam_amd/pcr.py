@@ -41,7 +41,7 @@ class PcrStats(C.Structure):
     _fields_ = [
         ("total_ms", C.c_double), ("index_ms", C.c_double), ("solve_ms", C.c_double), ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_int32), ("iterations", C.c_int32), ("n_src", C.c_int64), ("n_dst", C.c_int64),
-        ("attempts", C.c_int32), ("pad_", C.c_int32),
+        ("attempts", C.c_int32), ("target_builds", C.c_int32),
     ]
 
 
@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init",
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
-    "pcr_map_submap_indices",
+    "pcr_map_submap_indices", "pcr_map_generation", "pcr_scan2map_submap",
     "pcr_sc_default_params", "pcr_sc_create", "pcr_sc_destroy", "pcr_sc_last_error", "pcr_sc_size", "pcr_sc_add", "pcr_sc_descriptor", "pcr_sc_distance",
     "pcr_sc_query",
 ]
@@ -112,6 +112,8 @@ def load_library():
     L.pcr_get_timeline.argtypes = [vp, vp, C.c_size_t, ip, ip]
     L.pcr_voxel_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, vp, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
     L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
+    L.pcr_scan2map_submap.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, dp, ip]
+    L.pcr_map_generation.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pcr_set_profile.argtypes = [vp, C.c_int]
     L.pcr_set_stream.argtypes = [vp, vp]
     L.pcr_set_query_tile.argtypes = [vp, dp, dp]
@@ -256,22 +258,26 @@ class PointCloudRegister:
         self._check(self._lib.pcr_set_target(self._h, p, n, s, dev))
 
     def align(self, src, res):
-        p, n, s, dev, _k = _cloud(src)
-        pose = _pose_in(res)
-        conv = C.c_int(0)
-        self._check(self._lib.pcr_align(self._h, p, n, s, dev, pose.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
-        np.asarray(res)[...] = _pose_out(pose)
-        self.isConverge = bool(conv.value)
+        p, n, s, dev, _k = self._cloud_cached(src)
+        res_np = np.asarray(res)
+        if res_np.shape != (4, 4):
+            raise ValueError("pose must be 4x4")
+        self._pose_cm[...] = res_np.T
+        self._check(self._lib.pcr_align(self._h, p, n, s, dev, self._pose_buf, self._conv_ref))
+        res_np[...] = self._pose_cm.T
+        self.isConverge = bool(self._conv.value)
         return self.isConverge
 
     def invalidateTarget(self):
         self._check(self._lib.pcr_invalidate_target(self._h))
 
-    def scan2MapSubmap(self, src, submap, pose):
-        """scan2Map with the device-resident sub-map of a SubMap as `dst` (no host copy of the map)."""
+    def scan2MapSubmap(self, src, submap, pose, rebuild=False):
+        """scan2Map with the device-resident sub-map of a SubMap as `dst` (no host copy of the map).  The handle keeps the target
+        structures it builds for as long as the SubMap stays at the same generation (pcr_scan2map_submap); rebuild=True is the
+        reference's behaviour of rebuilding on every call (pcr_scan2map_device on the same memory) -- same result either way."""
         p, n, s, dev, _k = _cloud(src)
         dp, dn, ds = submap.pointer()
-        if ds != s:
+        if dn and ds != s:
             raise ValueError("scan and sub-map must share one point layout")
         if not dev:
             import torch
@@ -279,7 +285,10 @@ class PointCloudRegister:
             p, _k = C.c_void_p(t.data_ptr()), t
         pc = _pose_in(pose)
         conv = C.c_int(0)
-        self._check(self._lib.pcr_scan2map_device(self._h, p, n, C.c_void_p(dp), dn, s, pc.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
+        if rebuild:
+            self._check(self._lib.pcr_scan2map_device(self._h, p, n, C.c_void_p(dp), dn, s, pc.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
+        else:
+            self._check(self._lib.pcr_scan2map_submap(self._h, p, n, 1, submap._m, pc.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv)))
         np.asarray(pose)[...] = _pose_out(pc)
         self.isConverge = bool(conv.value)
         return self.isConverge
@@ -514,6 +523,12 @@ class SubMap:
         p, n, s, dev, _keep = _cloud(cloud)
         pc = _pose_in(pose)
         self._check(self._lib.pcr_map_add_keyframe(self._m, p, n, s, dev, pc.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def generation(self):
+        """(store id, generation of the sub-map it holds): every updateMap / updateWindow starts a new generation."""
+        i, g = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.pcr_map_generation(self._m, C.byref(i), C.byref(g)))
+        return int(i.value), int(g.value)
 
     def keyframes(self):
         n = C.c_size_t(0)

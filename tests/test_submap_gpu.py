@@ -137,3 +137,53 @@ def test_loop_closure_flow(gpu, keyframes):
     po, co, _ = oracle.vgicp_scan2map(scan, sm.download(), guess, oracle.vgicp_params(max_iters=100, trans_eps=1e-6, threads=8))
     dt, dr = synth.pose_error(pose, po)
     assert co == conv and dt <= 1e-4 and dr <= 1e-4
+
+
+@pytest.mark.parametrize("method", ["loam", "ndt", "vgicp"])
+def test_target_structures_live_as_long_as_the_submap_generation(gpu, keyframes, method):
+    """LidarOdometry registers several scans against one sub-map between two MapManager updates.  pcr_scan2map_submap keys the
+    handle's target structures on (map id, generation): they are built once per generation, rebuilt when the map moves on or when
+    another entry point used the handle in between, and the pose is the one pcr_scan2map_device gives on the same memory."""
+    from simpleslam_amd import make_register
+    world, kfs = keyframes
+    sm = SubMap()
+    for c, T in kfs[:10]:
+        sm.addKeyFrame(c, T)
+    scans = [synth.make_scan(world, 10 + k, seed=91, beams=32, azimuths=512) for k in range(3)]
+    sm.updateMap(scans[0][1][:3, 3], radius=8.0, grid_size=0.4)
+    g0 = sm.generation()
+    reg, ref = make_register(method), make_register(method)
+    builds = lambda: reg.stats()["target_builds"]
+    for k, (scan, T_true) in enumerate(scans):
+        ds = reg.voxelDownSample(scan, 0.4)
+        init = synth.perturb(T_true, 91 + k, trans=0.1, rot_deg=0.5)
+        p_keep, p_ref = init.copy(), init.copy()
+        c_keep = reg.scan2MapSubmap(ds, sm, p_keep)
+        c_ref = ref.scan2MapSubmap(ds, sm, p_ref, rebuild=True)
+        assert c_keep == c_ref
+        np.testing.assert_array_equal(p_keep, p_ref)
+    assert builds() == 1                                   # three scans, one sub-map generation, one build
+    # the map moves on: new generation, new structures
+    sm.updateMap(scans[1][1][:3, 3] + np.array([0.5, 0.0, 0.0]), radius=8.0, grid_size=0.4)
+    assert sm.generation()[0] == g0[0] and sm.generation()[1] == g0[1] + 1
+    ds = reg.voxelDownSample(scans[1][0], 0.4)
+    init = synth.perturb(scans[1][1], 95, trans=0.1, rot_deg=0.5)
+    p_keep, p_ref = init.copy(), init.copy()
+    reg.scan2MapSubmap(ds, sm, p_keep)
+    ref.scan2MapSubmap(ds, sm, p_ref, rebuild=True)
+    np.testing.assert_array_equal(p_keep, p_ref)
+    assert builds() == 2
+    # another entry point on the same handle replaces the structures: they are not mistaken for the sub-map's afterwards
+    other = sm.download()[::2].copy()
+    tmp = init.copy(); reg.scan2Map(ds, other, tmp)
+    p_again = init.copy(); reg.scan2MapSubmap(ds, sm, p_again)
+    np.testing.assert_array_equal(p_again, p_ref)
+    assert builds() == 3
+    # a second store with an equal generation number is a different map
+    sm2 = SubMap()
+    for c, T in kfs[:6]:
+        sm2.addKeyFrame(c, T)
+    sm2.updateMap(scans[0][1][:3, 3], radius=8.0, grid_size=0.4); sm2.updateMap(scans[0][1][:3, 3], radius=8.0, grid_size=0.4)
+    assert sm2.generation()[1] == sm.generation()[1] and sm2.generation()[0] != sm.generation()[0]
+    p2 = init.copy(); reg.scan2MapSubmap(ds, sm2, p2)
+    assert builds() == 4
