@@ -348,15 +348,24 @@ __device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i
 }
 
 // dynamic LDS: max_bins counters (max_bins = tiles the cell table's capacity can make: host-known)
-template <bool kVec, int kBinPer>
+// kPlace: the build has a LAYOUT HINT -- lay_cur[t] = where tile t's points go in `tiled`, with room for an eighth more than the tile
+// held in the previous build (+32), written by the previous build's last block -- and moves every point to its tile right here:
+// the separate placing pass (a second read of the cloud, 15 us at 1 M points) disappears.  A sub-map changes by a key frame at a
+// time, so the room nearly always suffices; a tile that outgrows it raises header.stale, nothing is stored out of bounds, and the
+// caller rebuilds without hints (the same protocol as the bounding-box hint that this path requires anyway).
+template <bool kVec, int kBinPer, bool kPlace>
 __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
-                                                       uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start) {
+                                                       uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start, uint32_t* __restrict__ lay_next,
+                                                       const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;
+    uint32_t* const sh_lay = dyn_lds + max_bins;      // kPlace: max_bins + 1 entries
     const GridHeader h = *hdr;
     if (h.overflow || h.empty) return;
+    const uint32_t nbins_h = (uint32_t)(h.n_cells >> shift) + 1u;
     for (uint32_t b = threadIdx.x; b < max_bins; b += 256) hist[b] = 0u;
+    if (kPlace) { for (uint32_t b = threadIdx.x; b <= max_bins; b += 256) sh_lay[b] = b <= nbins_h ? lay_cur[b] : 0u; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     constexpr uint32_t kBinChunk = 256u * kBinPer;      // points a block histograms at a time
@@ -403,10 +412,24 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) if (first[u]) hist[bin[u]] = got[u];
         __syncthreads();
+        if (kPlace) {
+            bool over = false;
 #pragma unroll
-        for (int u = 0; u < kBinPer; ++u) {
-            const uint32_t i = c0 + u * 256 + threadIdx.x;
-            if (i < n) slot[i] = bin[u] != 0xffffffffu ? hist[bin[u]] + loc[u] : 0xffffffffu;
+            for (int u = 0; u < kBinPer; ++u) {
+                const uint32_t i = c0 + u * 256 + threadIdx.x;
+                if (i < n && bin[u] != 0xffffffffu) {
+                    const uint32_t r = hist[bin[u]] + loc[u], lo = sh_lay[bin[u]], room = sh_lay[bin[u] + 1u] - lo;
+                    if (r < room && lo + r < tiled_cap) tiled[lo + r] = make_float4(px[u], py[u], pz[u], __uint_as_float(i));
+                    else over = true;
+                }
+            }
+            if (over) hdr->stale = 1;      // the tile has outgrown the room the previous build left it
+        } else {
+#pragma unroll
+            for (int u = 0; u < kBinPer; ++u) {
+                const uint32_t i = c0 + u * 256 + threadIdx.x;
+                if (i < n) slot[i] = bin[u] != 0xffffffffu ? hist[bin[u]] + loc[u] : 0xffffffffu;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -438,6 +461,17 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     for (uint32_t j = 0; j < kMaxBins / 256; ++j)
         if (j < per && b0 + j < nbins) { bin_start[b0 + j] = off; off += c[j]; }
     if (threadIdx.x == 255) bin_start[nbins] = total;
+    // ... and into the layout the NEXT build may place its points by: every tile gets an eighth more room than it holds now
+    __syncthreads();      // sh4 is reused
+    uint32_t room = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j) if (j < per && b0 + j < nbins) room += c[j] + (c[j] >> 3) + 32u;
+    uint32_t room_total;
+    uint32_t lo = block_exclusive_scan_256(room, &room_total, sh4);
+#pragma unroll
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j)
+        if (j < per && b0 + j < nbins) { lay_next[b0 + j] = lo; lo += c[j] + (c[j] >> 3) + 32u; }
+    if (threadIdx.x == 255) lay_next[nbins] = room_total;
     if (threadIdx.x == 0) *ticket = 0u;                        // ready for the next build
 }
 
@@ -487,9 +521,11 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
 // (ranks parked in global scratch).
 static constexpr int kTilePer = 16;
 
+// src_start: where tile t's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
 __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
-                                                        float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift) {
+                                                        float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
+                                                        const uint32_t* __restrict__ src_start) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;                    // 1 << shift
     __shared__ uint32_t sh4[4];
@@ -498,8 +534,15 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
     if (h.overflow || h.empty) return;
     const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
     const uint32_t S = 1u << shift;
+    if (h.stale) {
+        // a hint did not hold (points outside the box, or a tile without room: not every point was stored): nothing here can be
+        // trusted and the caller rebuilds.  Only the counters are put back to zero, the state every build expects.
+        for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;
+        return;
+    }
     for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) {
         const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
+        const uint32_t q0 = src_start[tile];      // first point of the tile in `tiled`
         const uint64_t cell0 = (uint64_t)tile << shift;
         const bool small = np <= 256u * kTilePer;      // block-uniform
         float4 p[kTilePer];
@@ -508,7 +551,7 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {      // all loads in flight, issued before anything waits
                 const uint32_t j = u * 256u + threadIdx.x;
-                if (u * 256u < np) p[u] = tiled[p0 + (j < np ? j : 0u)];
+                if (u * 256u < np) p[u] = tiled[q0 + (j < np ? j : 0u)];
             }
         }
         for (uint32_t c = threadIdx.x * 4u; c < S; c += 1024u) *reinterpret_cast<uint4*>(hist + c) = make_uint4(0, 0, 0, 0);
@@ -529,7 +572,7 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
         } else {
             for (uint32_t j0 = 0; j0 < np; j0 += 256u * kTilePer) {      // chunks of 4096 points, their loads in flight together
 #pragma unroll
-                for (int u = 0; u < kTilePer; ++u) { const uint32_t j = j0 + u * 256u + threadIdx.x; p[u] = tiled[p0 + (j < np ? j : 0u)]; }
+                for (int u = 0; u < kTilePer; ++u) { const uint32_t j = j0 + u * 256u + threadIdx.x; p[u] = tiled[q0 + (j < np ? j : 0u)]; }
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) {
                     const uint32_t j = j0 + u * 256u + threadIdx.x;
@@ -582,7 +625,7 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) {
                     const uint32_t j = j0 + u * 256u + threadIdx.x;
-                    p[u] = tiled[p0 + (j < np ? j : 0u)];
+                    p[u] = tiled[q0 + (j < np ? j : 0u)];
                     cr[u] = scratch_rank[p0 + (j < np ? j : 0u)];
                 }
 #pragma unroll
@@ -638,7 +681,7 @@ void DeviceBuf::release() {
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
     bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
-    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release();
+    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); layout[0].release(); layout[1].release(); lay_ok = false;
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -729,20 +772,43 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const int bin_blocks = (int)std::min<size_t>(4096, (n + bin_chunk - 1) / bin_chunk ? (n + bin_chunk - 1) / bin_chunk : 1);
         const int place_blocks = (int)std::min<size_t>(2048, (n + 1023) / 1024 ? (n + 1023) / 1024 : 1);
         const int tile_blocks = (int)max_bins;
-        const size_t bin_lds = (size_t)max_bins * 4, place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
-#define PCR_LAUNCH_BIN(VEC, PER) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
-                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>())
-        if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8); else PCR_LAUNCH_BIN(true, 16); }
-        else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8); else PCR_LAUNCH_BIN(false, 16); }
+        // Layout hint (see grid_bin_kernel<.., kPlace>): the previous build of this index left, next to its header, where each tile's
+        // points may go; a build that reuses the header places by it and skips the placing pass.  PCR_INDEX_NO_LAYOUT=1 switches it off.
+        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && getenv("PCR_INDEX_NO_LAYOUT") == nullptr;
+        PCR_TRY(layout[0].reserve((kMaxBins + 8) * sizeof(uint32_t)));
+        PCR_TRY(layout[1].reserve((kMaxBins + 8) * sizeof(uint32_t)));
+        if (use_layout) {      // room for every tile's slack (the device also checks every store against the capacity it is told)
+            const size_t need = lay_n + lay_n / 8 + (size_t)32 * (max_bins + 1) + 16;
+            if (need > n + 16) PCR_TRY(tiled.reserve(need * sizeof(float4)));
+        }
+        const uint32_t tiled_cap = (uint32_t)std::min<size_t>(tiled.cap / sizeof(float4), 0xfffffff0u);
+        uint32_t* const lay_cur = layout[lay_idx].as<uint32_t>();
+        uint32_t* const lay_next = layout[lay_idx ^ 1].as<uint32_t>();
+        used_layout = use_layout;
+        const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
+#define PCR_LAUNCH_BIN(VEC, PER, PLACE) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
+                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
+                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap)
+        if (use_layout) {
+            if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, true); else PCR_LAUNCH_BIN(true, 16, true); }
+            else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, true); else PCR_LAUNCH_BIN(false, 16, true); }
+        } else {
+            if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, false); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, false); else PCR_LAUNCH_BIN(true, 16, false); }
+            else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, false); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, false); else PCR_LAUNCH_BIN(false, 16, false); }
+        }
 #undef PCR_LAUNCH_BIN
-        if (vec)
-            hipLaunchKernelGGL(grid_place_kernel<true>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
-                               ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
-        else
-            hipLaunchKernelGGL(grid_place_kernel<false>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
-                               ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
+        if (!use_layout) {
+            if (vec)
+                hipLaunchKernelGGL(grid_place_kernel<true>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
+                                   ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
+            else
+                hipLaunchKernelGGL(grid_place_kernel<false>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
+                                   ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
+        }
         hipLaunchKernelGGL(grid_tile_kernel, dim3(tile_blocks), dim3(256), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), bin_start.as<uint32_t>(),
-                           bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift);
+                           bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift,
+                           use_layout ? lay_cur : bin_start.as<uint32_t>());
+        lay_idx ^= 1; lay_ok = true; lay_n = n; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
         PCR_TRY(hipGetLastError());
         n_points = n;
         valid = true;

@@ -156,6 +156,12 @@ struct GridIndex {
     int hint_pcl = 0;                           // lattice kind of the build the hint comes from (a hint serves only a build of the same kind)
     int hint_margin = 0;                        // cells added around a fresh box in x and y (0 until a hint has failed once)
     bool used_hint = false;                     // the last build() reused the header
+    // Layout hint: where each tile's points may go in `tiled` (an eighth more room than the tile held + 32), written by the last block
+    // of every tiled build for the next one; two buffers, alternating.  Used only together with a reused header.
+    DeviceBuf layout[2];
+    int lay_idx = 0, lay_shift = -1;
+    size_t lay_n = 0;
+    bool lay_ok = false, used_layout = false;
     void confirm() { hint_ok = valid && tiled_shift >= 0; }
     size_t cell_capacity = 0;   // entries available in cell_count / cell_start
     size_t n_points = 0;
