@@ -559,3 +559,43 @@ def test_bounding_box_of_the_previous_target_is_a_hint_not_a_promise(gpu, world_
     # an empty target inside a hinted box is still an empty target
     p = w["init"].copy()
     assert reg.scan2Map(w["scan"], np.zeros((0, 4), np.float32), p) is False
+
+
+def test_tile_layout_of_the_previous_target_is_a_hint_too(gpu, world_small):
+    """A build that reuses the previous bounding box also reuses the previous PLACES of the tiles (each with an eighth of slack) and
+    moves the points there while it bins them, which saves the placing pass.  A target whose points have piled up in one region --
+    same box, so the box hint holds -- outgrows the room of those tiles: nothing is written out of bounds, the build is flagged
+    and redone without hints, and the answer is that of a fresh handle."""
+    w = world_small
+    m = w["map"]
+    reg = LoamRegister()
+    fresh = lambda mm, p0: (lambda r, p: (r.scan2Map(w["scan"], mm, p), p))(LoamRegister(), p0.copy())
+    for _ in range(3):                                             # box hint confirmed, layout written and used
+        p = w["init"].copy(); reg.scan2Map(w["scan"], m, p)
+    assert reg.stats()["attempts"] == 1
+    # same extent, but the points within 6 m of the scan's start position four times over (jittered by a millimetre: no duplicates)
+    c = w["init"][:3, 3]
+    near = m[np.linalg.norm(m[:, :3] - c, axis=1) < 6.0]
+    assert 500 < near.shape[0] < 0.5 * m.shape[0]
+    rng = np.random.default_rng(7)
+    piles = [near.copy() for _ in range(3)]
+    for q in piles:
+        q[:, :3] += rng.uniform(-1e-3, 1e-3, size=(q.shape[0], 3)).astype(np.float32)
+    piled = np.ascontiguousarray(np.vstack([m] + piles))
+    lo, hi = m[:, :3].min(0), m[:, :3].max(0)
+    piled = piled[((piled[:, :3] >= lo) & (piled[:, :3] <= hi)).all(1)]           # the old box still holds every point
+    c1, p1_ref = fresh(piled, w["init"])
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], piled, p) == c1
+    assert reg.stats()["attempts"] == 2                           # the tiles around the scan had no room: noticed, redone
+    np.testing.assert_array_equal(p, p1_ref)
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], piled, p) == c1                 # the new layout holds from now on
+    assert reg.stats()["attempts"] == 1
+    np.testing.assert_array_equal(p, p1_ref)
+    # and back: the thinner cloud fits the roomier layout
+    c0, p_ref = fresh(m, w["init"])
+    p = w["init"].copy()
+    assert reg.scan2Map(w["scan"], m, p) == c0
+    assert reg.stats()["attempts"] == 1
+    np.testing.assert_array_equal(p, p_ref)
