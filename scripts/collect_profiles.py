@@ -24,6 +24,16 @@ if f:
         for r in rows:
             o.write(",".join([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
 
+for m in ("vgicp", "ndt"):
+    f = newest(f"stats_{m}/**/*kernel_stats.csv")
+    if f:
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(dst, f"{tag}_{m}_kernel_stats.csv"), "w") as o:
+            o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --method {m} --steps 40 --warmup 5 --no-cpu-baseline\n")
+            o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+            for r in rows:
+                o.write(",".join([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+
 
 def means(pattern):
     f = newest(pattern)

@@ -14,4 +14,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARG
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $ARGS > $OUT/pmc_l2.log 2>&1
 grep -h '"metric"' $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json || true
+# the two secondary configurations (BASELINE configs[2] and configs[4]): kernel statistics only
+for m in vgicp ndt; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -- python3 $R/bench.py --method $m --steps 40 --warmup 5 --no-cpu-baseline --windows 1 > $OUT/stats_$m.log 2>&1
+done
 echo done

@@ -291,12 +291,12 @@ int settle_loam_index(pcr_handle* h, const float* d_src, size_t n_src, size_t st
         H_TRY(hipMemcpyAsync(&hdr, h->grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
         if (hdr.stale) {      // the box taken over from the previous target does not hold this one: fresh box, padded from now on
-            h->grid.hint_margin = 8;
+            h->grid.hint_margin = 8; h->grid.cells_hint = 0;      // (a cloud that left the old box: its cell count is anybody's guess too)
             if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
             continue;
         }
         const int ov = check_grid_overflow(h, hdr.overflow, hdr.n_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
-        if (ov == 0) { h->grid.confirm(); return 0; }
+        if (ov == 0) { h->grid.confirm(); h->grid.note_cells(hdr.n_cells); return 0; }
         if (ov == 1) return 1;
     }
     return fail(h, "target index could not be sized");
@@ -391,7 +391,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         }
         if (!shard) {
             if (r.grid_stale) {      // the box taken over from the previous target does not hold this one: fresh box, padded from now on
-                h->grid.hint_margin = 8;
+                h->grid.hint_margin = 8; h->grid.cells_hint = 0;      // (a cloud that left the old box: its cell count is anybody's guess too)
                 if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
                 index_timed = false;
                 continue;
@@ -399,7 +399,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
             int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
             if (ov == 1) return 1;
             if (ov == 2) { index_timed = false; continue; }
-            if (!h->clamp.use) h->grid.confirm();
+            if (!h->clamp.use) { h->grid.confirm(); h->grid.note_cells(r.grid_cells); }
         }
         memcpy(pose, r.pose, 16 * sizeof(double));
         if (converged) *converged = r.converged;
@@ -482,7 +482,7 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
         GridHeader hdr;
         H_TRY(hipMemcpyAsync(&hdr, g.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
-        if (!hdr.overflow) return 0;
+        if (!hdr.overflow) { g.note_cells(hdr.n_cells); return 0; }
         if (g.grow_cells(hdr.n_cells, &h->err) != hipSuccess) return 1;
     }
     return fail(h, "index could not be sized");
@@ -493,6 +493,17 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
 // uniform density: measured 0.74 ms on one level vs 0.94 ms on three for the 1 M-point map, 7.7 ms vs 0.36 ms for the
 // 65 k-point scan.  Scan-sized clouds get three levels, map-sized ones one.
 int cov_levels(size_t n) { return n <= 300000 ? 3 : 1; }
+
+int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats);
+int vgicp_side_init(pcr_handle* h) {
+    if (!h->side_stream) {
+        H_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        H_TRY(hipEventCreateWithFlags(&h->ev_side_in, hipEventDisableTiming));
+        H_TRY(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+        H_TRY(hipHostMalloc((void**)&h->side_hdr, 3 * sizeof(GridHeader), hipHostMallocDefault));
+    }
+    return 0;
+}
 
 // the fine index plus the coarse ones of the covariance search, settled with one round trip
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
@@ -514,7 +525,7 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
             if (hdr[l].overflow) { if (lv[l]->grow_cells(hdr[l].n_cells, &h->err) != hipSuccess) return 1; again = true; }
-            else { todo[l] = false; if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
+            else { todo[l] = false; lv[l]->note_cells(hdr[l].n_cells); if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
         }
         if (!again) return 0;
     }
@@ -527,12 +538,7 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
 // vgicp_source_settle() detects from the headers and redoes in order.
 int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats) {
     h->side_pending = false;
-    if (!h->side_stream) {
-        H_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-        H_TRY(hipEventCreateWithFlags(&h->ev_side_in, hipEventDisableTiming));
-        H_TRY(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
-        H_TRY(hipHostMalloc((void**)&h->side_hdr, 3 * sizeof(GridHeader), hipHostMallocDefault));
-    }
+    if (vgicp_side_init(h)) return 1;
     if (n_src > 0xfffffff0ull) return 0;                         // run_vgicp reports it
     H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
@@ -565,7 +571,12 @@ int vgicp_source_settle(pcr_handle* h, const float* d_src, size_t n_src, size_t 
         H_TRY(hipEventSynchronize(h->ev_side_done));
         bool overflow = false;
         for (int l = 0; l < levels; ++l) overflow = overflow || h->side_hdr[l].overflow != 0;
-        if (!overflow) { H_TRY(hipStreamWaitEvent(h->stream, h->ev_side_done, 0)); return 0; }
+        if (!overflow) {
+            GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
+            for (int l = 0; l < levels; ++l) lv[l]->note_cells(h->side_hdr[l].n_cells);
+            H_TRY(hipStreamWaitEvent(h->stream, h->ev_side_done, 0));
+            return 0;
+        }
     } else if (h->side_pending) {
         h->side_pending = false;
         H_TRY(hipEventSynchronize(h->ev_side_done));             // never leave side work in flight behind the caller's back
@@ -1006,9 +1017,9 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
             if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
             if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
             if (!deferred) break;
-            if (h->nd_grid_checked && !h->nd_grid_bad) { h->grid.confirm(); break; }
+            if (h->nd_grid_checked && !h->nd_grid_bad) { h->grid.confirm(); h->grid.note_cells(h->nd_grid_cells); break; }
             // the hint or the table size did not hold (or the device loop handed over to the host before it could tell): checked build
-            h->grid.hint_margin = 8;
+            h->grid.hint_margin = 8; h->grid.cells_hint = 0;      // (a cloud that left the old box: its cell count is anybody's guess too)
             memcpy(pose, pose_in, sizeof pose_in);
         }
         if (h->profile >= 1) {
@@ -1024,6 +1035,9 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     if (h->method == kVgicp) {
         // the reference keeps its target structures while the cloud POINTER is unchanged and goes stale
         // when the cloud is edited in place; this entry point always rebuilds them
+        // (source side first: its ~15 launches run on the side stream while the host is still queueing the target's.  Measured the other
+        //  way round -- target builds queued first, source side enqueued while the host waits for them -- 1.17 instead of 0.93 ms: the
+        //  two covariance kernels then run side by side for their whole length and slow each other down)
         int prc = vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4);
         if (!prc) prc = vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4);
         if (prc && h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
@@ -1252,11 +1266,11 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
     if (!on_device && stage_host(h, &h->vf_in, pts, n, stride_bytes, &d_pts)) return 1;
     GridHeader hdr;
     bool settled = false;
-    for (int attempt = 0; attempt < 3 && !settled; ++attempt) {
+    for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
         if (h->vf_grid.build(d_pts, n, sf, leaf, h->stream, &h->err, 0.0, 1) != hipSuccess) return 1;
         H_TRY(hipMemcpyAsync(&hdr, h->vf_grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
-        if (!hdr.overflow) settled = true;
+        if (!hdr.overflow) { settled = true; h->vf_grid.note_cells(hdr.n_cells); }
         else if (h->vf_grid.grow_cells(hdr.n_cells, &h->err) != hipSuccess) return 1;
     }
     if (!settled) return fail(h, "voxel table could not be sized");

@@ -690,6 +690,8 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
         if (err) *err = "target bounding box needs " + std::to_string(need_cells) + " grid cells (> 4e9): cloud too sparse for the dense index";
         return hipErrorInvalidValue;
     }
+    if (cells_hint && need_cells + 1 <= cell_capacity) { cells_hint = need_cells; return hipSuccess; }      // only the bound taken from the previous build was too small
+    cells_hint = 0;
     const size_t want = (size_t)need_cells + need_cells / 2 + 4096;
     cell_count.release(); cell_start.release(); block_sums.release();
     hipError_t e;
@@ -738,25 +740,36 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     if (clamp) cb = *clamp;
     const uint32_t n32 = (uint32_t)n, st = (uint32_t)stride_floats;
     const int pt_blocks = (int)std::min<size_t>(2048, (n + 255) / 256 ? (n + 255) / 256 : 1);
-    // tile size: see below
-    int tshift = 8;
-    while (((uint64_t)cell_capacity >> tshift) + 2 > 2048 && tshift < 11) ++tshift;
-    if (const char* e = getenv("PCR_TILE_SHIFT")) tshift = atoi(e);      // (development: tile size sweep)
-    while (((uint64_t)cell_capacity >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
+    // The cell count this build may use: the table's capacity, or -- once a header of this index has been seen (note_cells) -- twice that
+    // header's count.  The tile size follows from it, and a grid of a few hundred cells (the coarse levels of the covariance search)
+    // must not be cut into 256-cell tiles: two blocks then sorted a whole scan between them (158 us).  A cloud that needs more cells
+    // than the bound raises header.overflow like a table that is too small, and grow_cells() lifts the bound.
+    size_t cap_eff = cell_capacity;
+    if (cells_hint) cap_eff = std::min<size_t>(cell_capacity, std::max<size_t>(2 * (size_t)cells_hint + 64, 1024));
+    // tile size: ~512 points per tile on average, at most 2048 tiles, at least 4 cells per tile (16-byte accesses of the tile kernel)
+    const size_t tiles_target = std::min<size_t>(2048, std::max<size_t>(64, n / 512));
+    // (never more than 2^11 cells per tile unless the counter array forces it: a tile's block zeroes, scans and writes every cell of it,
+    //  and a sparse fine grid -- 3.6 M cells for a 65 k-point scan -- is better served by many small tiles than by 440 blocks of 8 192 cells)
+    int tshift;
+    if (cells_hint) { tshift = 2; while ((cells_hint >> tshift) > tiles_target && tshift < 11) ++tshift; }
+    else { tshift = 8; while (((uint64_t)cap_eff >> tshift) + 2 > 2048 && tshift < 11) ++tshift; }
+    if (const char* e = getenv("PCR_TILE_SHIFT")) tshift = std::max(2, atoi(e));      // (development: tile size sweep)
+    while (((uint64_t)cap_eff >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
     const bool tiled_path = tshift <= kMaxTileShift && !force_atomic_path;
+    if (getenv("PCR_INDEX_DEBUG")) fprintf(stderr, "index build: n %zu cell %.3g capacity %zu cells_hint %llu cap_eff %zu tshift %d hint_ok %d lay_ok %d\n", n, cell, cell_capacity, (unsigned long long)cells_hint, cap_eff, tshift, (int)hint_ok, (int)lay_ok);
     const bool reuse_header = allow_hint && hint_ok && tiled_path && hint_pcl == pcl_mode && hint_shift == shift && !cb.use && hint_cell == cell && tiled_shift == tshift;
     hint_ok = false;      // until the host has seen this build's header (confirm())
     used_hint = reuse_header;
     hint_cell = cell; hint_shift = shift; hint_pcl = pcl_mode;
     if (!reuse_header)
         hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
-                           ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cell_capacity, cell, shift, pcl_mode, cb,
+                           ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cap_eff, cell, shift, pcl_mode, cb,
                            (allow_hint && !cb.use) ? hint_margin : 0);
     // Tile size from the CAPACITY of the cell table (the device-side cell count never exceeds it: a larger box is an overflow):
     // ~2048 tiles when the table allows it -- 8 KB of LDS counters per block in the bin kernel, tiles of a few hundred to a few
     // thousand points -- never more than kMaxBins.
     if (tiled_path) {
-        const uint32_t max_bins = (uint32_t)(((uint64_t)cell_capacity >> tshift) + 2);
+        const uint32_t max_bins = (uint32_t)(((uint64_t)cap_eff >> tshift) + 2);
         PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
         PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));

@@ -164,6 +164,8 @@ struct GridIndex {
     bool lay_ok = false, used_layout = false;
     void confirm() { hint_ok = valid && tiled_shift >= 0; }
     size_t cell_capacity = 0;   // entries available in cell_count / cell_start
+    uint64_t cells_hint = 0;    // cells of the last header of this index the host has seen (0: none): bounds the next build's cell count and sets its tile size
+    void note_cells(uint64_t n_cells) { if (n_cells) cells_hint = n_cells; }
     size_t n_points = 0;
     bool valid = false;
     GridView view() const {
