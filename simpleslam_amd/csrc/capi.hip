@@ -109,6 +109,7 @@ struct pcr_handle {
     long long target_builds = 0;         // ... and how often it had to build them
     bool nd_grid_checked = false, nd_grid_bad = false;      // the device loop reported the state of the index header with its result
     uint64_t nd_grid_cells = 0;
+    int nd_count_idx = 0;
     int nd_last_passes = 8;              // passes the previous alignment took: how many are enqueued up front
     bool nd_target_ready = false;
     int nd_iters = 0, nd_deriv = 0, nd_hess = 0;
@@ -809,8 +810,13 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
     const size_t max_vox = n_dst / (size_t)min_points + 2;      // a voxel needs min_points points
     H_TRY(h->nd_vox.reserve(max_vox * sizeof(NdtVoxel)));
     H_TRY(h->nd_list.reserve((max_vox + 64) * sizeof(uint32_t)));
-    H_TRY(h->nd_count.reserve(16));
-    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>(), h->nd_list.as<uint32_t>(),
+    if (!h->nd_count.p) {      // two counters used alternately; each call leaves the other one cleared for the next (ndt_candidates_kernel)
+        H_TRY(h->nd_count.reserve(256));
+        H_TRY(hipMemsetAsync(h->nd_count.p, 0, 256, h->stream));
+    }
+    h->nd_count_idx ^= 1;
+    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>() + 32 * h->nd_count_idx,
+                            h->nd_count.as<uint32_t>() + 32 * (h->nd_count_idx ^ 1), h->nd_list.as<uint32_t>(),
                             max_vox, min_points, 0.01, h->stream));
     h->nd_target_ready = true;
     return 0;
@@ -919,7 +925,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4;        // an iteration takes at most 1 + 10 + 1 passes
         int enq = 0;
-        const int first = std::min(std::max(h->nd_last_passes, 3), 24);
+        const int first = 3;      // (the host enqueues a pass in a quarter of the time the device needs for one: it only has to stay two ahead)
         for (; enq < first; ++enq) H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq));
         const volatile double* f_seq = &out->seq;
         const volatile double* f_prog = &out->progress;

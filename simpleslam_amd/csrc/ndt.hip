@@ -11,6 +11,8 @@
 //   N5 computeHessian / updateHessian           ndt_omp_impl.hpp:541-645 (serial, double)
 //      -> ndt_hessian_kernel
 //   N2/N4 Newton step + More-Thuente line search: host code in capi.hip.
+#include <string.h>
+
 #include "pcr_internal.h"
 #include "ndt_opt.h"
 #include "small_math.h"
@@ -75,9 +77,12 @@ static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(
 // atomic on the shared counter (an atomic per 1024 cells was 1 600 same-address atomics for a 5 M-point map: they serialise at
 // the memory side, 31 us) and then writes them; the order of the list is immaterial.
 __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_t* __restrict__ vox_slot, uint32_t* __restrict__ list,
-                                                             uint32_t* __restrict__ count, int min_points, uint32_t capacity) {
+                                                             uint32_t* __restrict__ count, uint32_t* __restrict__ count_next, int min_points, uint32_t capacity) {
     __shared__ uint32_t sh_w[4];
     __shared__ uint32_t sh_base;
+    // two counters, used alternately: this call counts in `count` (left at zero by the previous call) and clears the other for the next
+    // one -- a memset launch less per call.  Before anything can return.
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0u;
     const GridHeader h = *g.hdr;
     if (h.overflow) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -478,13 +483,11 @@ __global__ __launch_bounds__(kNdtBlock, 2) void ndt_pass_kernel(const NdtArgs a,
     else ndt_hessian_body(a, T, ctl->ang, sh, sh2);
 }
 
-__global__ __launch_bounds__(64) void ndt_ctl_init_kernel(NdtCtl* __restrict__ ctl, const NdtPose T0, const double p0, const double p1, const double p2,
-                                                          const double p3, const double p4, const double p5, const double step_size,
-                                                          const double trans_eps, const int max_iters) {
-    if (threadIdx.x == 0) {
-        const double p[6] = {p0, p1, p2, p3, p4, p5};
-        ndt_opt::ctl_init(ctl, T0, p, step_size, trans_eps, max_iters);
-    }
+// the controller's initial state, prepared on the host (ndt_opt::ctl_init) and handed over as a kernel argument
+struct NdtCtlArg { uint32_t w[(sizeof(NdtCtl) + 3) / 4]; };
+__global__ __launch_bounds__(512) void ndt_ctl_store_kernel(NdtCtl* __restrict__ ctl, const NdtCtlArg init) {
+    const int n = (int)(sizeof(NdtCtl) / 4);
+    for (int t = threadIdx.x; t < n; t += 512) reinterpret_cast<uint32_t*>(ctl)[t] = init.w[t];
 }
 
 static constexpr int kCtlWords = (int)((sizeof(NdtCtl) + 3) / 4);
@@ -499,21 +502,35 @@ __global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restr
     __shared__ double sh_sc[12];
     __shared__ int sh_need;
     __shared__ __attribute__((aligned(16))) uint32_t sh_ctl[kCtlWords];
-    if (ctl->done) return;                       // a pass enqueued beyond the end
     const unsigned long long t_in = wall_clock64();
     const int t = threadIdx.x;
-    const bool light = ctl->kind == kNdtPassDeriv;
-    const int cw = light ? 8 : 48, ns = 768 / cw;             // components per slice, slices
-    const int comp = t % cw, slice = t / cw;
+    // Everything this kernel needs from memory is requested in ONE round trip: the controller's state, and -- on the guess that this was
+    // a line-search pass, which ten of thirteen are -- the 7 sums of every block in the [96 slices][8 components] layout.
+    const int compL = t & 7, sliceL = t >> 3;
+    double vL[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) { const uint32_t b = (uint32_t)(sliceL + 96 * u); vL[u] = b < nblocks ? partials[(size_t)b * 48 + compL] : 0.0; }
     // the controller's state to LDS (thread 0 then works at LDS latency instead of one memory round trip per field)
     for (int w = t; w < kCtlWords; w += 768) sh_ctl[w] = reinterpret_cast<const uint32_t*>(ctl)[w];
+    const int done = ctl->done, kind = ctl->kind;
+#pragma unroll
+    for (int u = 0; u < 12; ++u) asm volatile("" ::"v"(vL[u]));      // (keeps the speculative loads above the branches below)
+    if (done) return;                            // a pass enqueued beyond the end
+    const bool light = kind == kNdtPassDeriv;
+    const int cw = light ? 8 : 48, ns = 768 / cw;             // components per slice, slices
+    const int comp = t % cw, slice = t / cw;
     double acc = 0.0;
-    for (uint32_t b0 = slice; b0 < nblocks; b0 += (uint32_t)ns * 12u) {
-        double v[12];
+    if (light) {
 #pragma unroll
-        for (int u = 0; u < 12; ++u) { const uint32_t b = b0 + (uint32_t)(ns * u); v[u] = b < nblocks ? partials[(size_t)b * 48 + comp] : 0.0; }
+        for (int u = 0; u < 12; ++u) acc += vL[u];
+    } else {
+        for (uint32_t b0 = slice; b0 < nblocks; b0 += (uint32_t)ns * 12u) {
+            double v[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) acc += v[u];
+            for (int u = 0; u < 12; ++u) { const uint32_t b = b0 + (uint32_t)(ns * u); v[u] = b < nblocks ? partials[(size_t)b * 48 + comp] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) acc += v[u];
+        }
     }
     sh[slice * cw + comp] = acc;
     __syncthreads();
@@ -601,12 +618,10 @@ uint32_t ndt_blocks(uint32_t n_src) {
     return b < 1 ? 1 : (b > 1024 ? 1024 : b);
 }
 
-hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_list, size_t list_capacity,
+hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
                              int min_points, double eig_mult, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
     const int blocks = (int)std::min<size_t>(512, grid.cell_capacity / 1024 + 1);
-    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
+    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, d_count_next, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     const int vblocks = (int)std::min<size_t>(65535, list_capacity / 256 + 1);
     hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     return hipGetLastError();
@@ -621,7 +636,13 @@ hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtA
 }
 
 hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s) {
-    hipLaunchKernelGGL(ndt_ctl_init_kernel, dim3(1), dim3(64), 0, s, d_ctl, T0, p[0], p[1], p[2], p[3], p[4], p[5], step_size, trans_eps, max_iters);
+    static_assert(sizeof(NdtCtl) % 4 == 0, "NdtCtl is copied word by word");
+    NdtCtl c;
+    memset(&c, 0, sizeof c);
+    ndt_opt::ctl_init(&c, T0, p, step_size, trans_eps, max_iters);
+    NdtCtlArg a;
+    memcpy(a.w, &c, sizeof c);
+    hipLaunchKernelGGL(ndt_ctl_store_kernel, dim3(1), dim3(512), 0, s, d_ctl, a);
     return hipGetLastError();
 }
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq) {

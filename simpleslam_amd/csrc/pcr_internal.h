@@ -251,7 +251,7 @@ struct NdtArgs {
     int32_t use_tile, pad_;  // sharded target: only source points whose transformed position lies in [tile_lo, tile_hi)
     double tile_lo[3], tile_hi[3];
 };
-hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_list, size_t list_capacity,
+hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
                              int min_points, double eig_mult, hipStream_t s);
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq = 0.0);
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
