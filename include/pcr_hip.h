@@ -221,6 +221,21 @@ int pcr_sc_descriptor(const pcr_sc* sc, size_t id, double* desc_row_major_20x60,
 int pcr_sc_distance(const pcr_sc* sc, size_t id1, size_t id2, double* dist, int* shift);
 int pcr_sc_query(pcr_sc* sc, long long id, long long* match, float* yaw_rad, double* min_dist);
 
+/* The NDT optimiser on its own (host only, no GPU): pclomp's computeTransformation + computeStepLengthMT (ndt_omp_impl.hpp:81-171,
+ * 735-932) as the state machine that pcr_scan2map runs on the device (csrc/ndt_opt.h), driven from outside -- the caller evaluates what
+ * it asks for and feeds the 43 sums back.  An introspection entry point like pcr_ndt_derivatives: the CPU test suite drives it with the
+ * oracle's derivatives and must arrive where the oracle's own loop arrives.
+ *   request: kind 0 = score + gradient + Hessian at p6 (computeDerivatives), 1 = score + gradient only, 2 = computeHessian (double) at
+ *            the same p6 as the previous request, 3 = finished.  pose16 (optional) = the float transform of p6, column-major.
+ *   feed:    sums = score, gradient[6], Hessian[36] (row-major; ignored entries may be anything finite).
+ *   result:  the pose computeTransformation would return (Matrix4f values), converged flag, iterations. */
+typedef struct pcr_ndt_opt pcr_ndt_opt;
+pcr_ndt_opt* pcr_ndt_opt_create(const double pose_guess[16], double step_size, double trans_eps, int max_iters);
+void pcr_ndt_opt_destroy(pcr_ndt_opt* o);
+int pcr_ndt_opt_request(const pcr_ndt_opt* o, int* kind, double p6[6], double pose16[16]);
+int pcr_ndt_opt_feed(pcr_ndt_opt* o, const double sums[43]);
+int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, int* iterations, int* done);
+
 /* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
  * accumulation done, partial sums stored (+ the fold inside the prologue and three stamps of the dense search).  out receives

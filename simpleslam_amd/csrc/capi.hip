@@ -1451,6 +1451,50 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     return 0;
 }
 
+struct pcr_ndt_opt { NdtCtl c; };
+
+pcr_ndt_opt* pcr_ndt_opt_create(const double pose_guess[16], double step_size, double trans_eps, int max_iters) {
+    if (!pose_guess) return nullptr;
+    pcr_ndt_opt* o = new pcr_ndt_opt;
+    memset(&o->c, 0, sizeof o->c);
+    // guess handed over as Matrix4f, Euler angles of its linear part (NdtRegister.cpp:27, ndt_omp_impl.hpp:103-111): as run_ndt does
+    float G[16];
+    for (int i = 0; i < 16; ++i) G[i] = (float)pose_guess[i];
+    NdtPose T0;
+    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) T0.R[rr * 3 + c] = G[c * 4 + rr]; T0.t[rr] = G[12 + rr]; }
+    float eul[3];
+    ndt_host::euler_xyz(T0.R, eul);
+    const double p0[6] = {T0.t[0], T0.t[1], T0.t[2], eul[0], eul[1], eul[2]};
+    ndt_opt::ctl_init(&o->c, T0, p0, step_size, trans_eps, max_iters);
+    return o;
+}
+void pcr_ndt_opt_destroy(pcr_ndt_opt* o) { delete o; }
+static void ndt_pose_out(const NdtPose& T, double pose16[16]) {
+    for (int i = 0; i < 16; ++i) pose16[i] = 0;
+    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) pose16[c * 4 + rr] = (double)T.R[rr * 3 + c]; pose16[12 + rr] = (double)T.t[rr]; }
+    pose16[15] = 1.0;
+}
+int pcr_ndt_opt_request(const pcr_ndt_opt* o, int* kind, double p6[6], double pose16[16]) {
+    if (!o || !kind) return 1;
+    *kind = o->c.done ? kNdtPassNone : o->c.kind;
+    if (p6) for (int i = 0; i < 6; ++i) p6[i] = o->c.x_t[i];
+    if (pose16) ndt_pose_out(o->c.T, pose16);
+    return 0;
+}
+int pcr_ndt_opt_feed(pcr_ndt_opt* o, const double sums[43]) {
+    if (!o || !sums || o->c.done) return 1;
+    ndt_opt::ctl_step(&o->c, sums);
+    return 0;
+}
+int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, int* iterations, int* done) {
+    if (!o) return 1;
+    if (pose16) ndt_pose_out(o->c.final_T, pose16);
+    if (converged) *converged = o->c.conv;
+    if (iterations) *iterations = o->c.nr_it;
+    if (done) *done = o->c.done;
+    return 0;
+}
+
 int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int64_t* n, double* x) {
     if (!h) return 1;
     if (!h->prm.record_trace) return fail(h, "trace not recorded: set pcr_params.record_trace");

@@ -280,3 +280,50 @@ def test_thread_collective_sums_in_rank_order():
     for r in range(n):
         np.testing.assert_array_equal(outs[r], expect)
         np.testing.assert_array_equal(mx[r], np.max(vals, axis=0))
+
+
+def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracle_does():
+    """csrc/ndt_opt.h is pclomp's computeTransformation + computeStepLengthMT turned inside out: a state machine that asks for one
+    evaluation at a time.  On the GPU it runs in the kernel that folds a pass's sums; here it runs on the host (pcr_ndt_opt_*, no GPU
+    involved) and every evaluation it asks for is answered by the ORACLE's computeDerivatives / computeHessian.  If the state machine
+    takes the decisions of the reference's loop it must finish after the same number of Newton iterations and evaluations, with the
+    same flag and the same Matrix4f pose as the oracle's own loop (oracle/ndt_oracle.c)."""
+    import ctypes as C
+    from simpleslam_amd import synth
+    from simpleslam_amd.pcr import load_library
+    L = load_library()
+    world, m = synth.make_map(60_000, seed=77, spacing=0.2)
+    scan, T = synth.make_scan(world, 0, seed=77, beams=16, azimuths=256)
+    dp = C.POINTER(C.c_double)
+    prm = oracle.ndt_params()
+    for seed, tr, rd in ((1, 0.1, 0.5), (2, 0.3, 1.5), (3, 0.0, 0.0)):
+        T0 = synth.perturb(T, seed, trans=tr, rot_deg=rd) if tr else T.copy()
+        po, co, info = oracle.ndt_scan2map(scan, m, T0, prm)
+        guess = np.ascontiguousarray(T0.T).reshape(16).copy()
+        o = L.pcr_ndt_opt_create(guess.ctypes.data_as(dp), float(prm.step_size), float(prm.trans_eps), int(prm.max_iters))
+        assert o
+        try:
+            n_deriv = n_hess = 0
+            for _ in range(600):
+                kind, p6 = C.c_int(-1), np.zeros(6)
+                assert L.pcr_ndt_opt_request(o, C.byref(kind), p6.ctypes.data_as(dp), None) == 0
+                if kind.value == 3:
+                    break
+                d = oracle.ndt_derivatives(scan, m, p6, prm, double_hessian=(kind.value == 2))
+                sums = np.zeros(43)
+                sums[0] = d["score"]; sums[1:7] = d["grad"]
+                sums[7:] = (d["hess_d"] if kind.value == 2 else d["hess"]).reshape(36)
+                n_hess += kind.value == 2
+                n_deriv += kind.value != 2
+                assert L.pcr_ndt_opt_feed(o, sums.ctypes.data_as(dp)) == 0
+            else:
+                raise AssertionError("the optimiser did not finish")
+            pose, conv, its, done = np.zeros(16), C.c_int(0), C.c_int(0), C.c_int(0)
+            assert L.pcr_ndt_opt_result(o, pose.ctypes.data_as(dp), C.byref(conv), C.byref(its), C.byref(done)) == 0 and done.value == 1
+        finally:
+            L.pcr_ndt_opt_destroy(o)
+        assert bool(conv.value) == co, seed
+        assert (its.value, n_deriv, n_hess) == (info["iterations"], info["derivative_passes"], info["hessian_passes"]), (seed, its.value, n_deriv, n_hess, info)
+        # same decisions; the pose agrees to a few float ulps (the stand-alone derivative entry point of the oracle rebuilds the float
+        # transform from p6 on its own, so the sums fed here are not bit for bit those of the oracle's inner loop)
+        np.testing.assert_allclose(pose.reshape(4, 4).T, po, rtol=0, atol=5e-6)
