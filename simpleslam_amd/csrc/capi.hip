@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <vector>
 
 #include "pcr_internal.h"
 #include "ndt_opt.h"
@@ -105,6 +106,7 @@ struct pcr_handle {
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
     NdtOut* nd_out_host = nullptr;       // host-mapped: its result and progress word
     NdtOut* nd_out_dev = nullptr;
+    bool clamp_from_bulk = false;        // pcr_set_target in progress: an untabulatable box may be cut to the bulk of the target
     uint64_t map_id = 0, map_gen = 0;    // pcr_scan2map_submap: the sub-map the target structures were built from
     long long target_builds = 0;         // ... and how often it had to build them
     bool nd_grid_checked = false, nd_grid_bad = false;      // the device loop reported the state of the index header with its result
@@ -269,11 +271,43 @@ int set_clamp_from_scan(pcr_handle* h, const float* d_src, size_t n_src, size_t 
     return 0;
 }
 
+// pcr_set_target on a cloud whose bounding box cannot be tabulated (a stray point kilometres away) and no scan to cut the box around:
+// the box of the BULK of the cloud instead.  A strided sample of <= 4096 points comes to the host; per axis the 2nd and 98th
+// percentile of the finite samples, widened by half their span + 20 m, is a region that holds every point of an ordinary map and
+// leaves a stray one out.  What lies outside is not indexed -- and, as with the scan-centred cut, not silently: a face with target
+// points beyond it is marked (header.cut_mask), a query whose 3x3x3 block touches such a face is counted, and the registration is
+// then redone on a region cut around the scan (run_loam), so a scan that really visits the far part of the cloud is still served.
+int set_clamp_from_target_sample(pcr_handle* h) {
+    const size_t n = h->tgt_n, stride_b = h->tgt_stride * 4;
+    if (!n || !h->tgt_ptr) return fail(h, "target bounding box too large for the dense index");
+    const size_t step = std::max<size_t>(1, n / 4096), m = (n + step - 1) / step;
+    std::vector<float> xyz(m * 3);
+    H_TRY(hipMemcpy2DAsync(xyz.data(), 12, h->tgt_ptr, stride_b * step, 12, m, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    for (int d = 0; d < 3; ++d) {
+        std::vector<double> v;
+        v.reserve(m);
+        for (size_t i = 0; i < m; ++i) { const float a = xyz[i * 3], b = xyz[i * 3 + 1], c = xyz[i * 3 + 2]; if (std::isfinite(a) && std::isfinite(b) && std::isfinite(c)) v.push_back((double)xyz[i * 3 + d]); }
+        if (v.empty()) return fail(h, "target bounding box too large for the dense index and no finite point in its sample");
+        std::sort(v.begin(), v.end());
+        const double q_lo = v[(size_t)(0.02 * (double)(v.size() - 1))], q_hi = v[(size_t)(0.98 * (double)(v.size() - 1) + 0.5)];
+        const double pad = 0.5 * (q_hi - q_lo) + 20.0;
+        h->clamp.lo[d] = q_lo - pad; h->clamp.hi[d] = q_hi + pad;
+    }
+    h->clamp.use = 1;
+    return 0;
+}
+
 int check_grid_overflow(pcr_handle* h, int overflow, uint64_t need_cells, const float* d_src = nullptr, size_t n_src = 0, size_t stride_floats = 0,
                         const double* pose = nullptr) {
     if (!overflow) return 0;
     if (need_cells > 4000000000ull && h->method == kLoam && d_src && pose && !h->clamp.use) {
         if (set_clamp_from_scan(h, d_src, n_src, stride_floats, pose)) return 1;
+        if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
+        return 2;
+    }
+    if (need_cells > 4000000000ull && h->method == kLoam && h->clamp_from_bulk && !h->clamp.use) {      // pcr_set_target: no scan to go by
+        if (set_clamp_from_target_sample(h)) return 1;
         if (build_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride)) return 1;
         return 2;
     }
@@ -1189,7 +1223,9 @@ static int prepare_target_from(pcr_handle* h, const float* d_dst, size_t n_dst, 
     h->clamp.use = 0;
     // settle the cell-table size now so that pcr_align never has to rebuild
     int rc = build_target(h, d_dst, n_dst, stride_bytes / 4);
+    h->clamp_from_bulk = true;          // a box that cannot be tabulated is cut to the bulk of the cloud (set_clamp_from_target_sample)
     if (!rc) rc = settle_loam_index(h, nullptr, 0, 0, nullptr);
+    h->clamp_from_bulk = false;
     if (rc) { h->have_target = false; h->grid.valid = false; }
     return agree_prepared(h, rc);
 }

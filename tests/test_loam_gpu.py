@@ -474,8 +474,9 @@ def test_handles_release_their_device_memory(gpu, world_small):
 def test_far_outlier_in_the_target(gpu, world_small):
     """One stray point kilometres (or 3e38 m) away makes the bounding box too large for dense cell tables.  scan2Map then
     indexes the part of the target around the scan (it only ever looks one gate radius around a query) and returns what
-    the oracle returns on the same cloud; an index without a scan to cut the box around (setTarget) is still refused, and
-    the cut index is not offered to a later align()."""
+    the oracle returns on the same cloud; the cut index is not offered to a later align().  setTarget has no scan to cut the
+    box around: it indexes the bulk of the cloud (percentiles of a sample, generously padded) and align() on it returns the
+    oracle's pose as well -- a query that reached a cut face would be noticed, not silently short of neighbours."""
     from simpleslam_amd import PcrError
     w = world_small
     clean = LoamRegister()
@@ -492,8 +493,12 @@ def test_far_outlier_in_the_target(gpu, world_small):
         assert dt < 1e-9 and dr < 1e-9, (dist, dt, dr)
         with pytest.raises(PcrError):
             reg.align(w["scan"], w["init"].copy())                 # the cut index is private to that call
-        with pytest.raises(PcrError, match="too sparse"):
-            reg.setTarget(m)
+        reg.setTarget(m)                                           # the bulk of the cloud is indexed, the stray point left out
+        for _ in range(2):
+            p3 = w["init"].copy()
+            assert reg.align(w["scan"], p3) == co
+            dt, dr = synth.pose_error(p3, po)
+            assert dt < 1e-9 and dr < 1e-9, (dist, dt, dr)
         p2 = w["init"].copy()                                      # and the handle is as good as new on an ordinary target
         assert reg.scan2Map(w["scan"], w["map"], p2) == c0
         np.testing.assert_array_equal(p2, p0)
@@ -598,3 +603,32 @@ def test_tile_layout_of_the_previous_target_is_a_hint_too(gpu, world_small):
     assert reg.scan2Map(w["scan"], m, p) == c0
     assert reg.stats()["attempts"] == 1
     np.testing.assert_array_equal(p, p_ref)
+
+
+def test_static_target_cut_to_its_bulk_still_serves_a_scan_in_the_part_left_out(gpu, world_small):
+    """setTarget on a cloud too spread out for dense cell tables indexes the bulk of it.  Here the cloud is the map plus a copy of a
+    two-hundredth of it a few kilometres away in every direction (5e9 cells of 1 m) -- outside the bulk box -- and the scan to align lies in that far copy: every query falls beyond a cut
+    face, which is noticed, and the call is redone on a region cut around the scan.  Same pose as the oracle on the same cloud."""
+    w = world_small
+    off = np.array([3000.0, 2000.0, 800.0], np.float32)
+    c = w["init"][:3, 3]
+    near = w["map"][np.argsort(np.linalg.norm(w["map"][:, :3] - c, axis=1))[: w["map"].shape[0] // 200]].copy()
+    far = near.copy(); far[:, :3] += off
+    both = np.ascontiguousarray(np.vstack([w["map"], far]))
+    scan_far_init = w["init"].copy(); scan_far_init[:3, 3] += off          # the same scan, placed in the far copy
+    reg = LoamRegister()
+    reg.setTarget(both)
+    p = w["init"].copy()                                                    # a scan in the bulk: served by the bulk index
+    conv = reg.align(w["scan"], p)
+    po, co, _ = oracle.loam_scan2map(w["scan"], both, w["init"])
+    assert conv == co
+    dt, dr = synth.pose_error(p, po)
+    assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+    assert reg.stats()["attempts"] == 1
+    p = scan_far_init.copy()                                                # a scan in the part that was left out
+    conv = reg.align(w["scan"], p)
+    po, co, _ = oracle.loam_scan2map(w["scan"], both, scan_far_init)
+    assert conv == co
+    dt, dr = synth.pose_error(p, po)
+    assert dt < 1e-7 and dr < 1e-9, (dt, dr)                                # (lever arms of 3.7 km: the normal equations amplify the order of summation)
+    assert reg.stats()["attempts"] >= 2
