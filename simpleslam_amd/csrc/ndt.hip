@@ -145,12 +145,21 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
                       cz = (int)(t / ((uint64_t)h.dims[0] * (uint64_t)h.dims[1]));
             const double ox = (h.org[0] + cx + 0.5) * h.cell, oy = (h.org[1] + cy + 0.5) * h.cell, oz = (h.org[2] + cz + 0.5) * h.cell;
             long long s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
-            for (uint32_t j = s; j < e; ++j) {
-                const float4 p = g.pts[j];
-                const double dx = (double)p.x - ox, dy = (double)p.y - oy, dz = (double)p.z - oz;
-                s1[0] += llrint(dx * kFix1); s1[1] += llrint(dy * kFix1); s1[2] += llrint(dz * kFix1);
-                s2[0] += llrint(dx * dx * kFix2); s2[1] += llrint(dx * dy * kFix2); s2[2] += llrint(dx * dz * kFix2);
-                s2[3] += llrint(dy * dy * kFix2); s2[4] += llrint(dy * dz * kFix2); s2[5] += llrint(dz * dz * kFix2);
+            // four points per step, their loads issued together (one dependent load per iteration left the lanes of crowded cells
+            // waiting a memory round trip per point; the sums are integers, so the grouping does not change a bit)
+            for (uint32_t j = s; j < e; j += 4) {
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = g.pts[j + u < e ? j + u : j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j + u < e) {
+                        const double dx = (double)q[u].x - ox, dy = (double)q[u].y - oy, dz = (double)q[u].z - oz;
+                        s1[0] += llrint(dx * kFix1); s1[1] += llrint(dy * kFix1); s1[2] += llrint(dz * kFix1);
+                        s2[0] += llrint(dx * dx * kFix2); s2[1] += llrint(dx * dy * kFix2); s2[2] += llrint(dx * dz * kFix2);
+                        s2[3] += llrint(dy * dy * kFix2); s2[4] += llrint(dy * dz * kFix2); s2[5] += llrint(dz * dz * kFix2);
+                    }
+                }
             }
             // The reference accumulates sum(x) and sum(x x^T) about the ORIGIN and then evaluates
             //   cov = (sum_xx - 2 (sum_x mean^T)) / n + mean mean^T,  cov *= (n-1)/n      (:329-330, all nine entries)
