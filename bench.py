@@ -341,16 +341,18 @@ def main():
         ct = time.perf_counter() - c0
         out["concurrent"] = {"streams": args.streams, "value": per * args.streams / ct, "unit": "scans/s",
                              "scans": per * args.streams, "note": "independent handles (pcr_params.reserved[4] = 1), one stream and one host thread each, same GPU"}
-    if rank == 0:
-        # ---- roofline of the dominant kernel (loam_iterate_kernel), live, HIP events on its stream ----
+    # ---- roofline of the dominant kernel (loam_iterate_kernel), live, HIP events on its stream.  Rank 0 reports it; with a sharded
+    #      map every rank has to take part in the calls (each one is a chain of collectives) ----
+    k_ms, k_n, idx_ms, tot_ms = 0.0, 0, 0.0, 0.0
+    reps = 16
+    if rank == 0 or (args.shard_map and world_size > 1):
         reg.set_profile(2)
-        k_ms, k_n, idx_ms, tot_ms = 0.0, 0, 0.0, 0.0
-        reps = 16
         for i in range(reps):
             step(i)
             st = reg.stats()
             k_ms += st["kernel_ms"]; k_n += st["kernel_launches"]; idx_ms += st["index_ms"]; tot_ms += st["total_ms"]
         reg.set_profile(0)
+    if rank == 0:
         avg_s = (k_ms / max(1, k_n)) * 1e-3
         alg_bytes = 96 * N_SCAN + 216          # per linearisation launch
         achieved = alg_bytes / avg_s / 1e9
