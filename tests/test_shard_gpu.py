@@ -322,3 +322,25 @@ def test_two_processes_over_gloo(gpu):
         assert got[0][method][1] == c
         dt, dr = synth.pose_error(got[0][method][0], ref)
         assert dt <= tol and dr <= tol, (method, dt, dr)
+
+
+@pytest.mark.parametrize("method", ["ndt", "vgicp"])
+def test_rccl_transport_with_a_one_rank_communicator(gpu, nd_w, vg_w, method):
+    """Between GPUs the sums travel through RCCL (pcr_comm_init) instead of the host callback.  No box with two GPUs was available, but a
+    communicator of one rank runs the same code -- staging buffer, ncclAllReduce on the handle's stream (SUM for the sums, MAX for the
+    'every rank prepared its tile' flag), copy back -- and must leave every number as it was: the host-driven loop of a sharded handle
+    then gives the pose of the host-driven loop of an unsharded one, bit for bit."""
+    from simpleslam_amd.pcr import default_params
+    w = nd_w if method == "ndt" else vg_w
+    Reg = NdtRegister if method == "ndt" else VgicpRegister
+    kw = {} if method == "ndt" else dict(vgicp_resolution=0.5)
+    p_host = default_params(**kw)
+    p_host.reserved[6] = 1                                         # NDT: the host-driven loop, which is what a sharded handle runs
+    plain, one = Reg(params=p_host), Reg(params=default_params(**kw))
+    one.comm_init(shard.unique_id(), 0, 1)
+    pa, pb = w["init"].copy(), w["init"].copy()
+    ca = plain.scan2Map(w["scan"], w["map"], pa)
+    cb = one.scan2Map(w["scan"], w["map"], pb)
+    assert ca == cb
+    np.testing.assert_array_equal(pa, pb)
+    assert plain.stats()["iterations"] == one.stats()["iterations"]
