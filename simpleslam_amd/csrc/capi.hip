@@ -511,9 +511,9 @@ int wait_result(pcr_handle* h, const double* flag_word, double seq) {
 // ---------------------------------------------------------------------------------
 // VGICP host driver: PCL align() + LsqRegistration (lsq_registration_impl.hpp:53-171)
 // ---------------------------------------------------------------------------------
-int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell, int pcl_mode = 0) {
+int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_t stride_floats, double cell, int pcl_mode = 0, const ClampBox* clamp = nullptr) {
     for (int attempt = 0; attempt < 3; ++attempt) {
-        if (g.build(d_pts, n, stride_floats, cell, h->stream, &h->err, 0.0, pcl_mode) != hipSuccess) return 1;
+        if (g.build(d_pts, n, stride_floats, cell, h->stream, &h->err, 0.0, pcl_mode, clamp) != hipSuccess) return 1;
         GridHeader hdr;
         H_TRY(hipMemcpyAsync(&hdr, g.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
@@ -542,16 +542,16 @@ int vgicp_side_init(pcr_handle* h) {
 
 // the fine index plus the coarse ones of the covariance search, settled with one round trip
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
-                      double shift0, GridHeader* hdr0_out) {
+                      double shift0, GridHeader* hdr0_out, bool may_cut = false) {
     GridIndex* lv[3] = {&g, &l1, &l2};
     const double cells[3] = {cell, 4.0 * cell, 16.0 * cell};
     const int levels = cov_levels(n);
     bool todo[3] = {true, levels > 1, levels > 2};
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         GridHeader hdr[3];
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
-            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0) != hipSuccess) return 1;
+            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr) != hipSuccess) return 1;
             if (l == 0 && hdr0_out) H_TRY(lv[l]->enqueue_density(h->stream));
             H_TRY(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
@@ -559,7 +559,17 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
         bool again = false;
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
-            if (hdr[l].overflow) { if (lv[l]->grow_cells(hdr[l].n_cells, &h->err) != hipSuccess) return 1; again = true; }
+            if (hdr[l].overflow) {
+                if (hdr[l].n_cells > 4000000000ull && may_cut && !h->clamp.use) {
+                    // a box no dense table can hold (a stray point far from the map): index the bulk of the cloud instead, all levels alike
+                    if (set_clamp_from_target_sample(h)) return 1;
+                    for (int k = 0; k < 3; ++k) todo[k] = k < levels;
+                    again = true;
+                    break;
+                }
+                if (lv[l]->grow_cells(hdr[l].n_cells, &h->err) != hipSuccess) return 1;
+                again = true;
+            }
             else { todo[l] = false; lv[l]->note_cells(hdr[l].n_cells); if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
         }
         if (!again) return 0;
@@ -628,8 +638,11 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     const double res = h->prm.vgicp_resolution;
     if (!(res > 0)) return fail(h, "vgicp_resolution must be positive");
     if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
-    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0)) return 1;
-    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
+    h->clamp.use = 0;
+    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats;
+    // (unsharded: a cloud too spread out for dense tables is cut to its bulk, settle_cov_levels; a rank of a sharded call refuses it)
+    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h))) return 1;
+    h->have_target = true;
     H_TRY(h->tgt_cov6.reserve((n_dst + 1) * 6 * sizeof(double)));
     H_TRY(h->vox.reserve((n_dst + 1) * sizeof(VgicpVoxel)));
     // A map-sized cloud is searched on ONE level whose cell is sized for the 20-neighbour radius, not for the voxel
@@ -641,7 +654,7 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
         const double occ = grid_sum_sq(h->cov_hdr0) / (double)n_dst;
         const double scale = std::min(8.0, sqrt(10.0 / std::max(occ, 1e-3)));
         if (scale >= 1.3) {
-            if (settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * scale)) return 1;
+            if (settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * scale, 0, h->clamp.use ? &h->clamp : nullptr)) return 1;
             cov_grid = &h->cov_l1;
         }
     }
@@ -730,6 +743,13 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     a.partials = h->vg_partials.as<double>();
     a.use_tile = h->use_tile; a.pad_ = 0;
     for (int d = 0; d < 3; ++d) { a.tile_lo[d] = h->tile_lo[d]; a.tile_hi[d] = h->tile_hi[d]; }
+    a.escapes = nullptr; a.guard_cells = 0; a.pad2_ = 0;
+    if (h->clamp.use) {      // the target index was cut to the bulk of the cloud (vgicp_prepare_target): watch where the scan goes
+        H_TRY(h->cov_viol.reserve(16));
+        H_TRY(hipMemsetAsync(h->cov_viol.p, 0, 16, h->stream));
+        a.escapes = h->cov_viol.as<uint32_t>() + 1;
+        a.guard_cells = (int)ceil(std::max(4.0, 8.0 * h->prm.vgicp_resolution) / h->prm.vgicp_resolution);      // the reach of a 20-neighbour covariance (as pcr_set_shard's halo)
+    }
     const bool shard = sharded(h);      // every rank linearises its tile's share of the scan; H, b and the error are summed over the ranks
 
     Pose16 x0;
@@ -796,6 +816,13 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         }
         if (!ok) break;                                  // "lm not converged!!"
         conv = host_is_converged(D, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps);
+    }
+    if (a.escapes) {
+        uint32_t esc = 0;
+        H_TRY(hipMemcpyAsync(&esc, a.escapes, sizeof esc, hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        if (esc) return fail(h, "the target is too spread out for the dense voxel tables (a stray point far from the map?) and was cut to its bulk, but the scan reaches "
+                                "the part that was left out: range-filter the target");
     }
     for (int i = 0; i < 16; ++i) pose[i] = (double)(float)x0.m[i];     // final_transformation_ is a Matrix4f
     if (converged) *converged = conv ? 1 : 0;
@@ -1432,6 +1459,7 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     a.corr_slot_next = h->corr_slot2.as<uint32_t>(); a.corr_M_next = h->corr_M2.as<double>();
     a.partials = h->vg_partials.as<double>();
     a.use_tile = h->use_tile; a.pad_ = 0;
+    a.escapes = nullptr; a.guard_cells = 0; a.pad2_ = 0;
     for (int d = 0; d < 3; ++d) { a.tile_lo[d] = h->tile_lo[d]; a.tile_hi[d] = h->tile_hi[d]; }
     Pose16 T;
     memcpy(T.m, pose, sizeof T.m);

@@ -205,6 +205,8 @@ struct VgicpArgs {
     double* partials;            // [blocks][32]
     int32_t use_tile, pad_;      // sharded target: only source points whose transformed position lies in [tile_lo, tile_hi)
     double tile_lo[3], tile_hi[3];
+    uint32_t* escapes;           // target index cut to the bulk of the cloud (header.clamped): count of source points that land within
+    int32_t guard_cells, pad2_;  //   guard_cells voxels of a face with target points beyond it (their voxels' covariances may lack neighbours); else NULL
 };
 
 // Halo check of a sharded target (pcr_set_shard): for every point inside [chk_lo, chk_hi) the 20th neighbour must be nearer

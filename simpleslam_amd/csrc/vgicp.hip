@@ -384,6 +384,18 @@ __device__ __forceinline__ void vgicp_lin_point(const VgicpArgs& a, const GridHe
 #pragma unroll
     for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
     uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
+    if (a.escapes && h.clamped) {
+        // The index covers only the bulk of the target (a stray point made its box too large for dense tables).  A source point that
+        // lands near -- or beyond -- a face behind which target points were left out would meet voxels whose covariances lack
+        // neighbours, or miss a voxel altogether: counted, and the host fails the call instead of returning a pose of the cut map.
+        const double c[3] = {floor(tp[0] / h.cell - h.shift) - h.org[0], floor(tp[1] / h.cell - h.shift) - h.org[1], floor(tp[2] / h.cell - h.shift) - h.org[2]};
+        const double g = (double)(kPad + a.guard_cells);
+        bool esc = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            esc = esc || ((h.cut_mask & (1 << d)) && c[d] < g) || ((h.cut_mask & (8 << d)) && c[d] >= (double)h.dims[d] - g);
+        if (esc) atomicAdd(a.escapes, 1u);
+    }
     if (a.use_tile && !(tp[0] >= a.tile_lo[0] && tp[0] < a.tile_hi[0] && tp[1] >= a.tile_lo[1] && tp[1] < a.tile_hi[1] &&
                         tp[2] >= a.tile_lo[2] && tp[2] < a.tile_hi[2])) slot = 0;      // sharded target: another rank's query
     slot_out[i] = slot;

@@ -159,3 +159,41 @@ def test_gated_fitness_of_align_cpp(gpu, vg_world):
         np.testing.assert_allclose(got, want, rtol=1e-6)
         far = np.eye(4); far[:3, 3] = [0.0, 0.0, 500.0]
         assert reg.fitnessGated(w["scan"], far, 1.0) == (-1.0, 0)
+
+
+def test_far_outlier_in_the_target(gpu, vg_world):
+    """One stray point kilometres (or 3e38 m) away makes the voxel lattice too large for dense tables; the reference's hash map and
+    kd-tree do not care.  The target is then indexed over the bulk of the cloud (percentiles of a sample, generously padded): the
+    stray point is in nobody's 20-neighbourhood and in no voxel the scan visits, so the pose is the oracle's on the same cloud.  A scan
+    that does go to the part left out is refused with an error that says so -- never a pose of the truncated map."""
+    from simpleslam_amd import PcrError
+    w = vg_world
+    for dist in (2.0e4, 3.0e38):
+        m = w["map"].copy()
+        m[0, :3] = [dist, -dist / 2, dist / 7]
+        po, co, info = oracle.vgicp_scan2map(w["scan"], m, w["init"], oracle.vgicp_params(threads=8))
+        reg = VgicpRegister()
+        for via in ("scan2Map", "align"):
+            pose = w["init"].copy()
+            if via == "scan2Map":
+                conv = reg.scan2Map(w["scan"], m, pose)
+            else:
+                reg.setTarget(m)
+                conv = reg.align(w["scan"], pose)
+            assert conv == co, (dist, via)
+            assert reg.stats()["iterations"] == info["outer"], (dist, via)
+            dt, dr = synth.pose_error(pose, po)
+            assert dt <= 1e-4 and dr <= 1e-4, (dist, via, dt, dr)
+    # a second cluster a few kilometres off in every direction, and a scan placed in it
+    off = np.array([30000.0, 20000.0, 8000.0], np.float32)
+    far = w["map"][:: 200].copy(); far[:, :3] += off
+    both = np.ascontiguousarray(np.vstack([w["map"], far]))
+    there = w["init"].copy(); there[:3, 3] += off
+    reg = VgicpRegister()
+    with pytest.raises(PcrError, match="left out"):
+        reg.scan2Map(w["scan"], both, there)
+    pose = w["init"].copy()                                        # the same handle and cloud, a scan in the bulk: served
+    po, co, _ = oracle.vgicp_scan2map(w["scan"], both, w["init"], oracle.vgicp_params(threads=8))
+    assert reg.scan2Map(w["scan"], both, pose) == co
+    dt, dr = synth.pose_error(pose, po)
+    assert dt <= 1e-4 and dr <= 1e-4
