@@ -104,6 +104,7 @@ struct pcr_handle {
     double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
     double* out48_dev = nullptr;
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
+    DeviceBuf nd_sums;                   // sharded device loop: the 48 sums of a pass, all-reduced in place
     NdtOut* nd_out_host = nullptr;       // host-mapped: its result and progress word
     NdtOut* nd_out_dev = nullptr;
     bool clamp_from_bulk = false;        // pcr_set_target in progress: an untabulatable box may be cut to the bulk of the target
@@ -976,8 +977,45 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     double score = 0;
     // ---- device-resident loop: passes are enqueued ahead of the device, the host watches a progress word.  Not for sharded
     // targets (every pass's sums cross the ranks through the host) and not when pcr_params.reserved[6] asks for the host loop ----
+    // Sharded over RCCL the loop stays on the device as well: fold -> ncclAllReduce on the handle's stream -> controller step, in
+    // batches of a fixed number of passes -- whether another batch is due is decided from the controller state the ranks share, so
+    // every rank enqueues the same collectives.  (A host-supplied collective needs the host in every pass: the host loop below.)
+    const bool dev_sharded = sharded(h) && h->comm && !h->host_ar && n_src > 0 && h->prm.reserved[6] == 0;
     bool on_device = n_src > 0 && !sharded(h) && h->prm.reserved[6] == 0;
     h->nd_grid_checked = false; h->nd_grid_bad = false;
+    bool sharded_done = false;
+    if (dev_sharded) {
+        NdtCtl* d_ctl = h->nd_ctl.as<NdtCtl>();
+        NdtOut* out = h->nd_out_host;
+        H_TRY(h->nd_sums.reserve(64 * sizeof(double)));
+        h->seq += 1.0;
+        const double seq = h->seq;
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream));
+        const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4, kBatch = 6;
+        const volatile double* f_batch = &out->batch;
+        for (int batch = 1, enq = 0;; ++batch) {
+            for (int b = 0; b < kBatch; ++b, ++enq) {
+                H_TRY(ndt_launch_pass_fold(r.a, d_ctl, h->nd_sums.as<double>(), h->stream));      // (a rank with an empty scan still folds zeros and takes part)
+                const int rc = g_rccl.allreduce(h->nd_sums.p, h->nd_sums.p, 48, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+                if (rc != 0) return fail(h, "ncclAllReduce failed with code " + std::to_string(rc));
+                H_TRY(ndt_launch_ctl(r.a, d_ctl, h->nd_sums.as<double>(), h->nd_out_dev, h->stream, seq, b == kBatch - 1 ? batch : 0));
+            }
+            const double want0 = seq * 65536.0 + 2.0 * batch;
+            long spins = 0;
+            while (!(*f_batch == want0 || *f_batch == want0 + 1.0)) {
+                __builtin_ia32_pause();
+                if (++spins > 400000 || h->profile != 0) { H_TRY(hipStreamSynchronize(h->stream)); if (!(*f_batch == want0 || *f_batch == want0 + 1.0)) return fail(h, "ndt: the sharded device loop lost its batch marker"); }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (*f_batch == want0 + 1.0) break;
+            if (enq >= limit) return fail(h, "ndt: the optimiser did not finish within its pass budget");
+        }
+        if (!out->bail) {      // (a nearly singular Newton system: every rank saw the same pivots and goes to the host loop below, with the SVD)
+            final_T = out->final_T; conv = out->conv; nr_it = out->nr_it; score = out->score;
+            h->nd_deriv = out->n_deriv; h->nd_hess = out->n_hess;
+            sharded_done = true;
+        }
+    }
     if (on_device) {
         NdtCtl* d_ctl = h->nd_ctl.as<NdtCtl>();
         NdtOut* out = h->nd_out_host;
@@ -1022,7 +1060,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
             h->nd_deriv = out->n_deriv; h->nd_hess = out->n_hess;
         }
     }
-    if (!on_device) {
+    if (!on_device && !sharded_done) {
         NdtCtl c;
         ctl_init(&c, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters);
         double sums[43];
@@ -1211,7 +1249,7 @@ void pcr_destroy(pcr_handle* h) {
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);
     if (h->nd_out_host) (void)hipHostFree(h->nd_out_host);
-    h->nd_ctl.release();
+    h->nd_ctl.release(); h->nd_sums.release();
     h->loam_state.release(); h->loam_partials.release(); h->loam_trace.release(); h->loam_reduced.release();
     h->dbg_status.release(); h->dbg_rows.release(); h->dbg_nn.release(); h->nn_cache.release(); h->timeline.release();
     if (h->result_host) (void)hipHostFree(h->result_host);

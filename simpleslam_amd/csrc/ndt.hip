@@ -594,6 +594,83 @@ __global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------
+// Sharded targets over RCCL: the sums of a pass have to cross the ranks between the fold and the controller step, so the
+// fold/controller kernel is cut in two around an ncclAllReduce on the same stream -- ndt_fold_kernel (this rank's 48 sums into
+// a device buffer), all-reduce, ndt_ctl_kernel (one step of the state machine on the summed values).  Every rank holds the same
+// controller state and feeds it the same sums: the ranks decide alike and stay in step without ever talking about it.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void ndt_fold_kernel(const double* __restrict__ partials, uint32_t nblocks, const NdtCtl* __restrict__ ctl,
+                                                       double* __restrict__ sums48) {
+    __shared__ double sh[16 * 48];
+    const int t = threadIdx.x, comp = t % 48, slice = t / 48;
+    const int kind = ctl->done ? kNdtPassNone : ctl->kind;
+    // (a pass enqueued beyond the end still takes part in the collective that follows: with zeros)
+    double acc = 0.0;
+    if (kind != kNdtPassNone) {
+        for (uint32_t b0 = slice; b0 < nblocks; b0 += 16 * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t b = b0 + 16 * u; v[u] = b < nblocks ? partials[(size_t)b * 48 + comp] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+    }
+    sh[slice * 48 + comp] = acc;
+    __syncthreads();
+    if (t < 48) {
+        double v = sh[t];
+#pragma unroll
+        for (int s2 = 1; s2 < 16; ++s2) v += sh[s2 * 48 + t];
+        // a line-search pass fills 7 of the 48 slots of every block; the others hold what an earlier pass left there
+        sums48[t] = (kind == kNdtPassDeriv && t >= 7) || t >= kNdtComp ? 0.0 : v;
+    }
+}
+
+__global__ __launch_bounds__(64) void ndt_ctl_kernel(NdtCtl* __restrict__ ctl, const double* __restrict__ sums48, const GridHeader* __restrict__ hdr,
+                                                     NdtOut* __restrict__ out, double seq, int batch_mark) {
+    __shared__ double sh_sums[48];
+    __shared__ double sh_sc[12];
+    __shared__ int sh_need;
+    __shared__ __attribute__((aligned(16))) uint32_t sh_ctl[kCtlWords];
+    const int t = threadIdx.x;
+    const int done_in = ctl->done;
+    if (!done_in) {
+        for (int w = t; w < kCtlWords; w += 64) sh_ctl[w] = reinterpret_cast<const uint32_t*>(ctl)[w];
+        if (t < 48) sh_sums[t] = sums48[t];
+        __syncthreads();
+        if (t == 0) sh_need = ndt_opt::ctl_decide(reinterpret_cast<NdtCtl*>(sh_ctl), sh_sums) ? 1 : 0;
+        __syncthreads();
+        if (sh_need) {
+            if (t < 6) {
+                double sc[2];
+                ndt_opt::trig_pair(reinterpret_cast<const NdtCtl*>(sh_ctl)->x_t, t, sc);
+                sh_sc[2 * t] = sc[0]; sh_sc[2 * t + 1] = sc[1];
+            }
+            __syncthreads();
+            if (t == 0) ndt_opt::ctl_tables(reinterpret_cast<NdtCtl*>(sh_ctl), sh_sc);
+        }
+        __syncthreads();
+        for (int w = t; w < kCtlWords; w += 64) reinterpret_cast<uint32_t*>(ctl)[w] = sh_ctl[w];
+    }
+    if (t == 0) {
+        const NdtCtl* c = done_in ? ctl : reinterpret_cast<const NdtCtl*>(sh_ctl);
+        if (c->done && !done_in) {
+            out->final_T = c->final_T; out->score = c->score;
+            out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
+            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->pad0 = 0; out->grid_cells = hdr->n_cells;
+            __threadfence_system();
+            __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // the end of a batch is marked whether or not the loop has finished: the host decides only then whether another batch is
+        // due -- a decision every rank takes from the same state, so that all of them enqueue the same collectives
+        if (batch_mark) {
+            __threadfence_system();
+            __hip_atomic_store(&out->batch, seq * 65536.0 + 2.0 * (double)batch_mark + (c->done ? 1.0 : 0.0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // fold per-block partials (48 doubles each) into 48 doubles, fixed order; 16 slices of 48 components, each
 // slice keeps 8 independent loads in flight
 // out lives in host-mapped memory: out[47] receives `seq` LAST (system-scope release), the word the host spins on
@@ -658,6 +735,18 @@ hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipSt
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
     hipLaunchKernelGGL(ndt_fold_ctl_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, a.hdr, d_out, seq);
+    return hipGetLastError();
+}
+
+// one pass of the sharded device-resident loop, in three pieces around the caller's all-reduce of d_sums48
+hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums48, hipStream_t s) {
+    const uint32_t nb = ndt_blocks(a.n_src);
+    hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
+    hipLaunchKernelGGL(ndt_fold_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, d_sums48);
+    return hipGetLastError();
+}
+hipError_t ndt_launch_ctl(const NdtArgs& a, NdtCtl* d_ctl, const double* d_sums48, NdtOut* d_out, hipStream_t s, double seq, int batch_mark) {
+    hipLaunchKernelGGL(ndt_ctl_kernel, dim3(1), dim3(64), 0, s, d_ctl, d_sums48, a.hdr, d_out, seq, batch_mark);
     return hipGetLastError();
 }
 

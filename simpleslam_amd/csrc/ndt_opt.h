@@ -53,6 +53,7 @@ struct NdtOut {
     int32_t conv, nr_it, n_deriv, n_hess, bail, passes, grid_overflow, grid_empty, grid_stale, pad0;
     uint64_t grid_cells;
     uint32_t ticks[4];
+    double batch;           // sharded device loop: seq * 65536 + 2 * (batches finished) + done, written by the last controller step of a batch
     double progress;        // number of passes consumed so far (written after every pass: the host keeps the queue ahead of it)
     double seq;             // == the call's sequence number once the loop has finished
 };

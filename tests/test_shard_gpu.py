@@ -333,8 +333,8 @@ def test_rccl_transport_with_a_one_rank_communicator(gpu, nd_w, vg_w, method):
     Reg = NdtRegister if method == "ndt" else VgicpRegister
     kw = {} if method == "ndt" else dict(vgicp_resolution=0.5)
     p_host = default_params(**kw)
-    p_host.reserved[6] = 1                                         # NDT: the host-driven loop, which is what a sharded handle runs
-    plain, one = Reg(params=p_host), Reg(params=default_params(**kw))
+    p_host.reserved[6] = 1                                         # NDT: the host-driven loop
+    plain, one = Reg(params=p_host), Reg(params=p_host)
     one.comm_init(shard.unique_id(), 0, 1)
     pa, pb = w["init"].copy(), w["init"].copy()
     ca = plain.scan2Map(w["scan"], w["map"], pa)
@@ -342,3 +342,18 @@ def test_rccl_transport_with_a_one_rank_communicator(gpu, nd_w, vg_w, method):
     assert ca == cb
     np.testing.assert_array_equal(pa, pb)
     assert plain.stats()["iterations"] == one.stats()["iterations"]
+    if method == "ndt":
+        # with RCCL the sharded NDT loop stays on the device (fold -> ncclAllReduce on the stream -> controller step, in batches):
+        # same decisions, the pose within a float ulp of the host-driven loop (elimination instead of the SVD, the device's libm)
+        dev = Reg(params=default_params(**kw))
+        dev.comm_init(shard.unique_id(), 0, 1)
+        pc = w["init"].copy()
+        assert dev.scan2Map(w["scan"], w["map"], pc) == ca
+        sd, sp = dev.stats(), plain.stats()
+        assert (sd["iterations"], sd["kernel_launches"]) == (sp["iterations"], sp["kernel_launches"])
+        dt, dr = synth.pose_error(pc, pa)
+        assert dt <= 2e-6 and dr <= 2e-6, (dt, dr)
+        first = pc.copy()
+        for _ in range(5):                                         # batches enqueued beyond the end must not leak into the next call
+            pc = w["init"].copy(); dev.scan2Map(w["scan"], w["map"], pc)
+            np.testing.assert_array_equal(pc, first)
