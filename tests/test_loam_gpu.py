@@ -632,3 +632,33 @@ def test_static_target_cut_to_its_bulk_still_serves_a_scan_in_the_part_left_out(
     dt, dr = synth.pose_error(p, po)
     assert dt < 1e-7 and dr < 1e-9, (dt, dr)                                # (lever arms of 3.7 km: the normal equations amplify the order of summation)
     assert reg.stats()["attempts"] >= 2
+
+
+def test_one_handle_through_a_sequence_of_unrelated_targets(gpu):
+    """Every call rebuilds the index, but with what the previous call left behind: its bounding box, the places of its tiles, its cell
+    count.  None of that may ever show in a result.  One handle is driven through targets that grow, shrink, move, thin out and pile up;
+    after every call its pose must equal, bit for bit, that of a handle that has never seen another target."""
+    rng = np.random.default_rng(2026)
+    reg = LoamRegister()
+    world, base = synth.make_map(120_000, seed=11)
+    scan, T = synth.make_scan(world, 0, seed=11, beams=16, azimuths=512)
+    retries = 0
+    for case in range(24):
+        kind = case % 8
+        m = base
+        if kind == 1: m = base[:: int(rng.integers(2, 40))]                                   # thinned out
+        elif kind == 2: m = np.vstack([base, base[: 20_000] + np.array([0.003, 0.002, 0.001, 0], np.float32)])   # piled up
+        elif kind == 3: m = base + np.array([float(rng.uniform(-30, 30)), float(rng.uniform(-30, 30)), 0, 0], np.float32)   # moved
+        elif kind == 4: m = base[np.abs(base[:, 0] - T[0, 3]) < float(rng.uniform(8, 25))]    # a slab around the scan
+        elif kind == 5: m = np.vstack([base, base[: 500] + np.array([150.0, -90.0, 12.0, 0], np.float32)])          # box grows
+        elif kind == 6: m = base[: int(rng.integers(50, 2000))]                               # a handful of points
+        elif kind == 7: m = np.vstack([base, base[::3] + np.array([0.0, 0.0, 0.004, 0], np.float32)])               # denser everywhere
+        m = np.ascontiguousarray(m, np.float32)
+        init = synth.perturb(T, 100 + case)
+        p_fresh, p_used = init.copy(), init.copy()
+        c_fresh = LoamRegister().scan2Map(scan, m, p_fresh)
+        c_used = reg.scan2Map(scan, m, p_used)
+        assert c_used == c_fresh, (case, kind)
+        np.testing.assert_array_equal(p_used, p_fresh, err_msg=f"case {case} kind {kind}")
+        retries += reg.stats()["attempts"] - 1
+    assert retries >= 3            # (the sequence did make hints fail: grown boxes, tiles without room)

@@ -153,3 +153,31 @@ def test_device_resident_optimiser_equals_the_host_driven_one(gpu, nd_world):
     for _ in range(20):
         p = T0.copy(); dev.scan2Map(w["scan"], w["map"], p)
         np.testing.assert_array_equal(p, first)
+
+
+def test_one_handle_through_a_sequence_of_unrelated_targets(gpu, nd_world):
+    """scan2Map enqueues the target's index unchecked, with the previous target's box, tile layout and cell count as hints, and learns
+    with the result whether that held.  A handle driven through targets that move, grow, shrink and thin out must return, every time,
+    the pose of a handle that has never seen another target -- bit for bit (the voxel a point belongs to does not depend on where
+    the lattice starts)."""
+    w = nd_world
+    rng = np.random.default_rng(7)
+    base = w["map"]
+    reg = NdtRegister()
+    for case in range(12):
+        kind = case % 6
+        m = base
+        if kind == 1: m = base + np.array([float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40)), 0, 0], np.float32)
+        elif kind == 2: m = base[:: int(rng.integers(2, 6))]
+        elif kind == 3: m = np.vstack([base, base[: 2000] + np.array([300.0, -200.0, 20.0, 0], np.float32)])
+        elif kind == 4: m = base[: int(rng.integers(200, 5000))]
+        elif kind == 5: m = np.vstack([base, base[::2] + np.array([0.01, 0.0, 0.0, 0], np.float32)])
+        m = np.ascontiguousarray(m, np.float32)
+        shift = (m[:, :3].mean(0) - base[:, :3].mean(0)) if kind == 1 else np.zeros(3)
+        T0 = synth.perturb(w["truth"], 40 + case, trans=0.1, rot_deg=0.5)
+        T0[:3, 3] += shift
+        p_fresh, p_used = T0.copy(), T0.copy()
+        c_fresh = NdtRegister().scan2Map(w["scan"], m, p_fresh)
+        c_used = reg.scan2Map(w["scan"], m, p_used)
+        assert c_used == c_fresh, (case, kind)
+        np.testing.assert_array_equal(p_used, p_fresh, err_msg=f"case {case} kind {kind}")
