@@ -197,3 +197,26 @@ def test_far_outlier_in_the_target(gpu, vg_world):
     assert reg.scan2Map(w["scan"], both, pose) == co
     dt, dr = synth.pose_error(pose, po)
     assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_one_handle_through_a_sequence_of_unrelated_targets(gpu, vg_world):
+    """The index of every build takes its tile size and its cell bound from the previous build of the same handle.  Driven through
+    targets and scans of very different extent and density, a handle must return what a fresh one returns, bit for bit."""
+    w = vg_world
+    rng = np.random.default_rng(3)
+    base = w["map"]
+    reg = VgicpRegister()
+    for case in range(10):
+        kind = case % 5
+        m, scan = base, w["scan"]
+        if kind == 1: m = base[:: int(rng.integers(3, 12))]
+        elif kind == 2: m = np.vstack([base, base[: 3000] + np.array([120.0, 80.0, 15.0, 0], np.float32)])
+        elif kind == 3: scan = w["scan"][:: int(rng.integers(2, 9))]
+        elif kind == 4: m = base[: int(rng.integers(2000, 20000))]
+        m, scan = np.ascontiguousarray(m, np.float32), np.ascontiguousarray(scan, np.float32)
+        T0 = synth.perturb(w["truth"], 70 + case, trans=0.2, rot_deg=1.0)
+        p_fresh, p_used = T0.copy(), T0.copy()
+        c_fresh = VgicpRegister().scan2Map(scan, m, p_fresh)
+        c_used = reg.scan2Map(scan, m, p_used)
+        assert c_used == c_fresh, (case, kind)
+        np.testing.assert_array_equal(p_used, p_fresh, err_msg=f"case {case} kind {kind}")
