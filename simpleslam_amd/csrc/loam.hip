@@ -133,8 +133,9 @@ __device__ __noinline__ void knn8_exact(double org_x, double org_y, double org_z
 // Two instructions per list slot (v_min_u32 / v_max_u32) instead of the five a (double distance, position) pair costs,
 // float arithmetic for the distance, and nothing else per candidate but the cursor of the stream.  The float distance is a
 // SCREEN: d~ differs from the exact double distance by < 1e-6 relative, the cleared bits by 2^-(23 - id bits).  What is
-// exact: a candidate that did not make the list has key >= the list's last key, hence an exact distance
-//     >= LB = float(last key, low bits cleared) * (1 - 1e-6).
+// exact: the smallest key that falls off the list is kept too; a candidate that did not make the list has a key >= that one,
+// hence an exact distance
+//     >= LB = float(that key, low bits cleared) * (1 - 1e-6).
 // The owner recomputes the kNb listed candidates in double, sorts them by (distance, index) and accepts the five nearest
 // iff the fifth is strictly nearer than LB (nothing outside the list can tie with it or beat it); otherwise, a handful of
 // queries per million, the out-of-line exact scan decides.  LB also bounds every target point that is not in the list,
@@ -182,10 +183,10 @@ __device__ __forceinline__ void knn_ranges_issue(const GridHeader& h, const uint
 template <int kGroup>
 __device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
                                         float qxf, float qyf, float qzf, float gate_f, bool active, KnnRuns& sh, uint32_t part, uint32_t parts_log2,
-                                        uint32_t key[kNb], uint32_t* idmask_out, unsigned long long* tl, const KnnRanges* pre = nullptr) {
+                                        uint32_t key[kNb + 1], uint32_t* idmask_out, unsigned long long* tl, const KnnRanges* pre = nullptr) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < kNb; ++j) key[j] = kKeyEmpty;
+    for (int j = 0; j <= kNb; ++j) key[j] = kKeyEmpty;      // (key[kNb]: the smallest key that is NOT in the list -- the bound of everything else)
     *idmask_out = 0u;
     KnnRanges g;
     if (pre) g = *pre;
@@ -261,6 +262,7 @@ __device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __res
             t = (seq < n_mine && d <= gate_f) ? t : kKeyEmpty;      // beyond the end of this lane's stream, beyond the gate, or NaN
 #pragma unroll
             for (int k = 0; k < kNb; ++k) { const uint32_t lo = min(key[k], t), hi = max(key[k], t); key[k] = lo; t = hi; }
+            key[kNb] = min(key[kNb], t);          // what falls off the list: its minimum is the (kNb + 1)-th smallest key
         }
 #pragma unroll
         for (int u = 0; u < kGroup; ++u) c[u] = n[u];
@@ -270,7 +272,7 @@ __device__ __forceinline__ int knn_scan(const GridHeader& h, const float4* __res
 }
 
 // sequence number of a candidate in the lane's stream -> position in the cell-sorted array (the lane's run table is still in LDS)
-__device__ __forceinline__ void knn_decode(const KnnRuns& sh, int tid, const uint32_t key[kNb], uint32_t idmask, uint32_t pos[kNb]) {
+__device__ __forceinline__ void knn_decode(const KnnRuns& sh, int tid, const uint32_t key[kNb + 1], uint32_t idmask, uint32_t pos[kNb]) {
     // run t holds the sequence numbers [P_t, P_t + len_t): position = sequence number + (start_t - P_t) of the last run with P_t <= it
     uint32_t P[9], off[9];
     uint32_t acc = 0;
@@ -287,9 +289,9 @@ __device__ __forceinline__ void knn_decode(const KnnRuns& sh, int tid, const uin
 }
 
 // squared-distance bound of everything that is not in a screened list (see knn_scan)
-__device__ __forceinline__ double knn_list_bound(const uint32_t key[kNb], uint32_t idmask) {
-    if (key[kNb - 1] == kKeyEmpty) return __longlong_as_double(0x7ff0000000000000ll);   // every candidate inside the gate is in the list
-    return (double)__uint_as_float(key[kNb - 1] & ~idmask) * (1.0 - 1e-6);
+__device__ __forceinline__ double knn_list_bound(const uint32_t key[kNb + 1], uint32_t idmask) {
+    if (key[kNb] == kKeyEmpty) return __longlong_as_double(0x7ff0000000000000ll);   // every candidate inside the gate is in the list
+    return (double)__uint_as_float(key[kNb] & ~idmask) * (1.0 - 1e-6);
 }
 
 // ------------------------------------------------------------------------------
@@ -573,7 +575,7 @@ struct MissExchange {
             uint32_t pos[kNb][256];      // by owner: positions of the listed candidates in the cell-sorted array
             double bound[256];           // by owner: squared-distance bound of every target point not listed
             uint32_t state[256];         // by owner: 0 no candidates / outside, 1 screened list (to be proven), 2 exact list, 3 redo exactly
-            uint32_t keys[kNb][256];     // by worker thread: partial lists of the lanes that share a query
+            uint32_t keys[kNb + 1][256]; // by worker thread: partial lists of the lanes that share a query (+ the first key off each list)
             uint32_t idmask[256];
         } res;
         double rows[8 * kRowStride];     // later: [component][point] rows of the normal equations
@@ -681,7 +683,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             // more than half the block: every lane searches its OWN query (a compaction would not free a single wave), with the
             // ranges it asked for before the barrier and without the trip through the exchange
             self = true;
-            uint32_t key[kNb], idmask = 0u;
+            uint32_t key[kNb + 1], idmask = 0u;
             const float gate_f = __double2float_ru(a.c.knn_max_sq * (1.0 + 1e-5));      // every candidate inside the gate has a float distance <= this
             const int rc = knn_scan<kGroup>(h, a.grid.pts, a.grid.cell_start, px, py, pz, gate_f, miss, sh, 0u, 0u, key, &idmask, tl, &own_ranges);
             knn_decode(sh, tid, key, idmask, self_pos);
@@ -696,24 +698,25 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
             const uint32_t m = (uint32_t)tid & (per - 1u), part = (uint32_t)tid >> (8u - pl2);
             const bool worker = m < n_miss;
             const uint32_t owner = worker ? ex.list[m] : 0u;
-            uint32_t key[kNb], idmask = 0u;
+            uint32_t key[kNb + 1], idmask = 0u;
             const float gate_f = __double2float_ru(a.c.knn_max_sq * (1.0 + 1e-5));      // every candidate inside the gate has a float distance <= this
             const int rc = knn_scan<kGroup>(h, a.grid.pts, a.grid.cell_start, ex.qx[owner], ex.qy[owner], ex.qz[owner], gate_f, worker, sh, part, pl2, key,
                                             &idmask, tl);
             if (pl2) {
                 if (worker && part) {
 #pragma unroll
-                    for (int j = 0; j < kNb; ++j) ex.u.res.keys[j][tid] = key[j];
+                    for (int j = 0; j <= kNb; ++j) ex.u.res.keys[j][tid] = key[j];
                 }
                 __syncthreads();
                 if (worker && !part) {
                     for (uint32_t q = 1; q < (1u << pl2); ++q) {
                         const uint32_t t2 = m + q * per;
 #pragma unroll
-                        for (int j = 0; j < kNb; ++j) {
+                        for (int j = 0; j <= kNb; ++j) {
                             uint32_t t = ex.u.res.keys[j][t2];
 #pragma unroll
                             for (int k = 0; k < kNb; ++k) { const uint32_t lo = min(key[k], t), hi = max(key[k], t); key[k] = lo; t = hi; }
+                            key[kNb] = min(key[kNb], t);
                         }
                     }
                 }
