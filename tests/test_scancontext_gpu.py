@@ -134,3 +134,29 @@ def test_default_parameters_follow_the_reference_config():
     assert d is not None
     with pytest.raises(Exception):
         sc.query(52)
+
+
+def test_sector_of_a_point_follows_the_c_librarys_atan2f():
+    """xy2theta (ScanContext.cpp:28-33) is std::atan2 on floats: the C library's atan2f, which in glibc is an fdlibm-style float routine
+    that is NOT correctly rounded -- its last bit differs from the device libm's (and from the rounded double atan2) for one argument
+    in six, and with it the sector of a point next to a sector edge.  The device therefore evaluates that published algorithm itself
+    (csrc/scancontext.hip: sc_atan2f).  Every point of a 1/8 m lattice out to 40 m, where azimuths pile up on rational directions
+    and sector edges, plus a million random directions: each descriptor bit for bit the oracle's (whose atan2f is the C library's)."""
+    g = np.arange(-320, 321, dtype=np.float32) * 0.125
+    xx, yy = np.meshgrid(g, g)
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        pts = np.zeros((xx.size, 8), np.float32)
+        pts[:, 0], pts[:, 1] = xx.ravel(), yy.ravel()
+        pts[:, 2] = rng.uniform(-1.0, 5.0, xx.size).astype(np.float32)      # distinct heights: the maximum of a bin identifies its point
+        sc, orc = ScanContext(), oracle.ScanContextOracle()
+        sc.addContext(pts); orc.add(pts)
+        np.testing.assert_array_equal(sc.descriptor(0)[0], orc.descriptor(0))
+        g = g * np.float32(0.73)                                            # another lattice, not aligned with the first
+        xx, yy = np.meshgrid(g, g)
+    pts = np.zeros((1_000_000, 8), np.float32)
+    a = rng.uniform(-np.pi, np.pi, pts.shape[0]); r = rng.uniform(0.1, 85.0, pts.shape[0])
+    pts[:, 0], pts[:, 1], pts[:, 2] = r * np.cos(a), r * np.sin(a), rng.uniform(-1.0, 5.0, pts.shape[0])
+    sc, orc = ScanContext(), oracle.ScanContextOracle()
+    sc.addContext(pts); orc.add(pts)
+    np.testing.assert_array_equal(sc.descriptor(0)[0], orc.descriptor(0))
