@@ -1,6 +1,7 @@
 """GPU parity of the NDT scan-to-map path (HIP through the C ABI) vs the CPU oracle.
 The reference's inner derivative math is float32 (ndt_omp_impl.hpp:485-537) and its final pose is a
-Matrix4f, so agreement is to float rounding, inside the 1e-4 m / 1e-4 rad bar of BASELINE.json."""
+Matrix4f; the device evaluates every float term as the oracle does (its expf is the C library's algorithm), so the poses
+normally agree bit for bit -- the bar of BASELINE.json is 1e-4 m / 1e-4 rad."""
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation as Rot
@@ -30,10 +31,12 @@ def test_derivatives_match_oracle(gpu, nd_world):
         p = _p_of(T)
         g = reg.derivatives(w["scan"], p, double_hessian=True)
         o = oracle.ndt_derivatives(w["scan"], w["map"], p, double_hessian=True)
-        assert abs(g["score"] - o["score"]) <= 2e-5 * abs(o["score"])
+        # (the float terms are the oracle's bit for bit -- the exponential is evaluated the way the C library does it, ndt.hip: ndt_expf --
+        #  what is left is the order of the double sums and the 1e-10 of the voxel Gaussians; 2e-5 before that)
+        assert abs(g["score"] - o["score"]) <= 1e-9 * abs(o["score"])
         gs, hs = np.abs(o["grad"]).max(), np.abs(o["hess"]).max()
-        assert np.abs(g["grad"] - o["grad"]).max() <= 2e-5 * gs
-        assert np.abs(g["hess"] - o["hess"]).max() <= 2e-5 * hs
+        assert np.abs(g["grad"] - o["grad"]).max() <= 1e-7 * gs
+        assert np.abs(g["hess"] - o["hess"]).max() <= 1e-8 * hs
         assert np.abs(g["hess_d"] - o["hess_d"]).max() <= 1e-8 * hs     # double path: voxel Gaussians agree to ~1e-10
 
 
@@ -51,8 +54,7 @@ def test_scan2map_matches_oracle(gpu, nd_world):
         conv = reg.scan2Map(w["scan"], w["map"], pose)
         assert conv == co
         assert reg.stats()["iterations"] == info["iterations"]
-        dt, dr = synth.pose_error(pose, po)
-        assert dt <= 1e-4 and dr <= 1e-4, (seed, dt, dr)
+        np.testing.assert_array_equal(pose, po)                                           # the same Matrix4f, bit for bit
         np.testing.assert_array_equal(pose, pose.astype(np.float32).astype(np.float64))   # Matrix4f result
         ok += 1
     assert ok == 3
