@@ -266,7 +266,7 @@ __device__ __constant__ unsigned long long kExp2fTab[32] = {
     0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, 0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
     0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL,
     0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
-__device__ __forceinline__ float ndt_expf(float x) {
+__device__ __forceinline__ float ndt_expf(float x, const unsigned long long* __restrict__ tab /* kExp2fTab, staged in LDS */) {
     const double N = 32.0, inv_ln2_n = 0x1.71547652b82fep+0 * N, shift = 0x1.8p+52;
     const double c0 = 0x1.c6af84b912394p-5 / N / N / N, c1 = 0x1.ebfce50fac4f3p-3 / N / N, c2 = 0x1.62e42ff0c52d6p-1 / N;
     const uint32_t abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
@@ -281,7 +281,7 @@ __device__ __forceinline__ float ndt_expf(float x) {
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
     kd -= shift;
     const double r = z - kd;
-    const double sc = __longlong_as_double((long long)(kExp2fTab[ki & 31u] + (ki << 47)));
+    const double sc = __longlong_as_double((long long)(tab[ki & 31u] + (ki << 47)));
     z = c0 * r + c1;
     const double r2 = r * r;
     double y = c2 * r + 1.0;
@@ -335,6 +335,11 @@ __device__ __forceinline__ void ndt_block_reduce(double* sh /* [16][kNdtStride] 
 template <bool kHessian>
 __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* sh, double* sh2) {
     constexpr int kComp = kHessian ? kNdtComp : 7;
+    // the exponential's table in LDS (a per-lane index into constant memory serialises; the slot is the tail of sh2, which the
+    // block reduction uses only up to entry 96)
+    unsigned long long* const exp_tab = reinterpret_cast<unsigned long long*>(sh2 + 96);
+    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
     const GridHeader h = *a.hdr;
     const float gauss_d2 = (float)a.d2;
     double acc[kNdtChunks] = {0.0, 0.0, 0.0};
@@ -384,7 +389,7 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { float s = x4t[0] * ci[0][c]; s += x4t[1] * ci[1][c]; s += x4t[2] * ci[2][c]; xc[c] = s; }
                     float dot = x4t[0] * xc[0]; dot += x4t[1] * xc[1]; dot += x4t[2] * xc[2];
-                    float e = ndt_expf(-gauss_d2 * dot * 0.5f);                  // :497 (the C library's expf: see ndt_expf)
+                    float e = ndt_expf(-gauss_d2 * dot * 0.5f, exp_tab);         // :497 (the C library's expf: see ndt_expf)
                     const float score_inc = (float)(-a.d1 * (double)e);          // :499
                     e = gauss_d2 * e;
                     if (e > 1 || e < 0 || e != e) continue;                      // :504-505
@@ -502,12 +507,12 @@ __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose
 template <bool kHessian>
 __global__ __launch_bounds__(kNdtBlock, 2) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
     __shared__ double sh[kNdtChunk * kNdtStride];
-    __shared__ double sh2[2 * 48];
+    __shared__ double sh2[2 * 48 + 32];
     ndt_derivatives_body<kHessian>(a, T, ang, sh, sh2);
 }
 __global__ __launch_bounds__(kNdtBlock, 2) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
     __shared__ double sh[kNdtChunk * kNdtStride];
-    __shared__ double sh2[2 * 48];
+    __shared__ double sh2[2 * 48 + 32];
     ndt_hessian_body(a, T, ang, sh, sh2);
 }
 
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(kNdtBlock, 2) void ndt_hessian_kernel(const NdtArgs
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(kNdtBlock, 2) void ndt_pass_kernel(const NdtArgs a, const NdtCtl* __restrict__ ctl) {
     __shared__ double sh[kNdtChunk * kNdtStride];
-    __shared__ double sh2[2 * 48];
+    __shared__ double sh2[2 * 48 + 32];
     const int kind = ctl->kind;
     if (kind == kNdtPassNone) return;
     const NdtPose T = ctl->T;
