@@ -110,7 +110,7 @@ struct pcr_handle {
     bool clamp_from_bulk = false;        // pcr_set_target in progress: an untabulatable box may be cut to the bulk of the target
     uint64_t map_id = 0, map_gen = 0;    // pcr_scan2map_submap: the sub-map the target structures were built from
     long long target_builds = 0;         // ... and how often it had to build them
-    bool nd_grid_checked = false, nd_grid_bad = false;      // the device loop reported the state of the index header with its result
+    bool nd_grid_checked = false, nd_grid_bad = false, nd_grid_empty = false;      // the device loop reported the state of the index header with its result
     uint64_t nd_grid_cells = 0;
     int nd_count_idx = 0;
     int nd_last_passes = 8;              // passes the previous alignment took: how many are enqueued up front
@@ -332,7 +332,7 @@ int settle_loam_index(pcr_handle* h, const float* d_src, size_t n_src, size_t st
             continue;
         }
         const int ov = check_grid_overflow(h, hdr.overflow, hdr.n_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
-        if (ov == 0) { h->grid.confirm(); h->grid.note_cells(hdr.n_cells); return 0; }
+        if (ov == 0) { if (!hdr.empty) { h->grid.confirm(); h->grid.note_cells(hdr.n_cells); } return 0; }      // (the header of an EMPTY target is no hint: the kernels of a build that reused it would leave at once)
         if (ov == 1) return 1;
     }
     return fail(h, "target index could not be sized");
@@ -435,7 +435,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
             int ov = check_grid_overflow(h, r.grid_overflow, r.grid_cells, h->clamp_allowed ? d_src : nullptr, n_src, stride_floats, pose);
             if (ov == 1) return 1;
             if (ov == 2) { index_timed = false; continue; }
-            if (!h->clamp.use) { h->grid.confirm(); h->grid.note_cells(r.grid_cells); }
+            if (!h->clamp.use && !r.grid_empty) { h->grid.confirm(); h->grid.note_cells(r.grid_cells); }      // (an empty target's header is no hint)
         }
         memcpy(pose, r.pose, 16 * sizeof(double));
         if (converged) *converged = r.converged;
@@ -1051,6 +1051,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         h->nd_last_passes = out->passes;
         if (getenv("PCR_NDT_TICKS")) fprintf(stderr, "ndt passes %d: fold %.2f us/pass, controller %.2f us/pass (decide %.2f, tables %.2f)\n", out->passes, out->ticks[0] * 0.01 / std::max(1, out->passes), out->ticks[1] * 0.01 / std::max(1, out->passes), out->ticks[2] * 0.01 / std::max(1, out->passes), out->ticks[3] * 0.01 / std::max(1, out->passes));
         h->nd_grid_bad = out->grid_overflow || out->grid_stale;
+        h->nd_grid_empty = out->grid_empty != 0;
         h->nd_grid_cells = out->grid_cells;
         h->nd_grid_checked = true;
         if (h->nd_grid_bad) return 0;           // the caller prepares the target again and repeats the call
@@ -1122,7 +1123,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
             if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
             if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
             if (!deferred) break;
-            if (h->nd_grid_checked && !h->nd_grid_bad) { h->grid.confirm(); h->grid.note_cells(h->nd_grid_cells); break; }
+            if (h->nd_grid_checked && !h->nd_grid_bad) { if (!h->nd_grid_empty) { h->grid.confirm(); h->grid.note_cells(h->nd_grid_cells); } break; }
             // the hint or the table size did not hold (or the device loop handed over to the host before it could tell): checked build
             h->grid.hint_margin = 8; h->grid.cells_hint = 0;      // (a cloud that left the old box: its cell count is anybody's guess too)
             memcpy(pose, pose_in, sizeof pose_in);

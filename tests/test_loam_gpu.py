@@ -662,3 +662,13 @@ def test_one_handle_through_a_sequence_of_unrelated_targets(gpu):
         np.testing.assert_array_equal(p_used, p_fresh, err_msg=f"case {case} kind {kind}")
         retries += reg.stats()["attempts"] - 1
     assert retries >= 3            # (the sequence did make hints fail: grown boxes, tiles without room)
+    # an empty target (twice: a hint is only trusted once the host has seen it hold) must not leave its header behind as a hint either
+    nothing = np.zeros((0, 4), np.float32)
+    nowhere = np.full((50, 4), np.nan, np.float32)
+    for m in (nothing, nothing, base, nowhere, nowhere, base):
+        init = synth.perturb(T, 999)
+        p_fresh, p_used = init.copy(), init.copy()
+        c_fresh = LoamRegister().scan2Map(scan, m, p_fresh)
+        c_used = reg.scan2Map(scan, m, p_used)
+        assert c_used == c_fresh
+        np.testing.assert_array_equal(p_used, p_fresh)

@@ -183,3 +183,10 @@ def test_one_handle_through_a_sequence_of_unrelated_targets(gpu, nd_world):
         c_used = reg.scan2Map(w["scan"], m, p_used)
         assert c_used == c_fresh, (case, kind)
         np.testing.assert_array_equal(p_used, p_fresh, err_msg=f"case {case} kind {kind}")
+    # an empty target must not leave its header behind as a hint
+    nothing = np.zeros((0, base.shape[1]), np.float32)
+    for m in (nothing, nothing, base):
+        T0 = synth.perturb(w["truth"], 77, trans=0.1, rot_deg=0.5)
+        p_fresh, p_used = T0.copy(), T0.copy()
+        assert NdtRegister().scan2Map(w["scan"], m, p_fresh) == reg.scan2Map(w["scan"], m, p_used)
+        np.testing.assert_array_equal(p_used, p_fresh)
