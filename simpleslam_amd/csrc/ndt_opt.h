@@ -63,15 +63,59 @@ namespace ndt_opt {
 NDT_HD inline double min_std(double a, double b) { return (b < a) ? b : a; }      // std::min / std::max, including what they do with NaN
 NDT_HD inline double max_std(double a, double b) { return (a < b) ? b : a; }
 
+// sinf / cosf the way this image's glibc (2.35) evaluates them on a host with FMA (sysdeps/ieee754/flt-32/s_sincosf.h, the "ARM optimized
+// routines" algorithm: reduction by pi/2 in double, a degree-7 sine or degree-6 cosine polynomial, rounding to float). glibc compiles that
+// file with contraction for its FMA ifunc variant, so the multiply-adds below are explicit fma()s (the library is built with
+// -ffp-contract=off); in this form the routine reproduced glibc's sinf and cosf bit for bit on 100 million arguments over [-96, 96], and
+// differed in 1e-7 of them from the variant glibc selects on a host WITHOUT FMA. The result is not the correctly rounded value: rounding
+// sin((double)x) to float differs from it for 0.65 % of the arguments, which is why that shortcut is not used.
+// which = 0: sine, 1: cosine. |x| >= 120 (never an angle of a pose that converges) falls back to the double routine.
+NDT_HD inline float glibc_sincosf(float y, int which) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    uint32_t bits;
+    memcpy(&bits, &y, 4);
+    const uint32_t top = (bits >> 20) & 0x7ff;
+    double x = (double)y;
+    int n = which;
+    double flip = 1.0;       // -1 selects the negated polynomial table glibc switches to when n & 2
+    if (top < 0x3f4u) {      // |y| < pi/4
+        if (top < 0x398u) return which ? 1.0f : y;      // |y| < 2^-12
+    } else if (top < 0x42fu) {                          // |y| < 120
+        const double r = x * hpi_inv;
+        const int q = ((int32_t)r + 0x800000) >> 24;
+        x = fma(-(double)q, hpi, x);
+        if (q & 2) flip = -1.0;
+        n = q ^ which;
+        if (!(n & 1)) x *= ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;   // sign[q & 3] = {1, -1, -1, 1}, applied to the sine's argument
+    } else {
+        return (float)(which ? cos((double)y) : sin((double)y));
+    }
+    const double x2 = x * x;
+    if (!(n & 1)) {
+        const double x3 = x * x2;
+        const double t1 = fma(x2, s3, s2);
+        const double x7 = x3 * x2;
+        const double t = fma(x3, s1, x);
+        return (float)fma(x7, t1, t);
+    }
+    const double x4 = x2 * x2;
+    const double k2 = fma(x2, flip * c4, flip * c3);
+    const double k1 = fma(x2, flip * c1, flip * c0);
+    const double x6 = x4 * x2;
+    const double k = fma(x4, flip * c2, k1);
+    return (float)fma(x6, k2, k);
+}
+
 // The six sine/cosine pairs a request needs, so that the device can evaluate them in six lanes at once:
-//   k = 0..2  the float angles of the pose, Eigen::AngleAxisf(float(x[3+k])) -> sinf / cosf (evaluated in double and rounded, which is
-//             the correctly rounded float in all but ~1e-9 of the cases on either libm)
+//   k = 0..2  the float angles of the pose, Eigen::AngleAxisf(float(x[3+k])) -> sinf / cosf
 //   k = 3..5  the double angles of computeAngleDerivatives (ndt_omp_impl.hpp:289-312), with its small-angle shortcut
 // sc[2k] = sine, sc[2k+1] = cosine.
 NDT_HD inline void trig_pair(const double x[6], int k, double sc[2]) {
     if (k < 3) {
-        const double a = (double)(float)x[3 + k];
-        sc[0] = (double)(float)sin(a); sc[1] = (double)(float)cos(a);
+        const float a = (float)x[3 + k];
+        sc[0] = (double)glibc_sincosf(a, 0); sc[1] = (double)glibc_sincosf(a, 1);
     } else {
         const double a = x[k];
         if (fabs(a) < 10e-5) { sc[0] = 0.0; sc[1] = 1.0; } else { sc[0] = sin(a); sc[1] = cos(a); }
