@@ -946,8 +946,8 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         memset(h->nd_out_host, 0, sizeof(NdtOut));
         H_TRY(hipHostGetDevicePointer((void**)&h->nd_out_dev, h->nd_out_host, 0));
     }
-    H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));
-    H_TRY(h->nd_ctl.reserve(sizeof(NdtCtl)));
+    H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));      // (one buffer of 1024 rows, or the two of 256 of the one-launch-per-pass loop)
+    H_TRY(h->nd_ctl.reserve(2 * sizeof(NdtCtl)));
     NdtRun r;
     r.h = h;
     r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)stride_floats;
@@ -1022,10 +1022,15 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         h->seq += 1.0;
         const double seq = h->seq;
         H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream));
-        const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4;        // an iteration takes at most 1 + 10 + 1 passes
+        const int limit = (h->prm.ndt_max_iters + 3) * 13 + 5;        // an iteration takes at most 1 + 10 + 1 passes; one launch more finishes
         int enq = 0;
         const int first = 3;      // (the host enqueues a pass in a quarter of the time the device needs for one: it only has to stay two ahead)
-        for (; enq < first; ++enq) H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq));
+        static const bool two_launches = getenv("PCR_NDT_TWO_LAUNCHES") != nullptr;      // the round's earlier form (pass kernel + fold/controller kernel), for A/B runs
+        auto launch = [&](int index) -> hipError_t {
+            if (two_launches) return ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq);
+            return ndt_launch_pass_pro(r.a, d_ctl, h->nd_partials.as<double>(), h->nd_out_dev, h->stream, seq, index);
+        };
+        for (; enq < first; ++enq) H_TRY(launch(enq));
         const volatile double* f_seq = &out->seq;
         const volatile double* f_prog = &out->progress;
         long spins = 0;
@@ -1035,7 +1040,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
             const double pr = *f_prog;
             const int consumed = (pr >= seq * 4096.0 && pr < (seq + 1.0) * 4096.0) ? (int)(pr - seq * 4096.0) : 0;
             if (enq - consumed < 2 && enq < limit) {       // two passes ahead of the device: a pass enqueued beyond the end costs ~10 us of device time
-                H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq)); ++enq;
+                H_TRY(launch(enq)); ++enq;
                 continue;
             }
             __builtin_ia32_pause();
@@ -1044,7 +1049,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
                 if (*f_seq == seq) { finished = true; break; }
                 if (enq >= limit) return fail(h, "ndt: the optimiser did not finish within its pass budget");
                 spins = 0;
-                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY(ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq));
+                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY(launch(enq));
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);

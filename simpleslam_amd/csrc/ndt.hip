@@ -299,19 +299,20 @@ static constexpr int kNdtComp = 43;    // score, gradient 6, Hessian 36
 // component c0 + e, the parts of a wave are combined with two shuffles, and lanes 0..15 of each wave carry the running sums.
 static constexpr int kNdtChunk = 16;
 static constexpr int kNdtChunks = (kNdtComp + kNdtChunk - 1) / kNdtChunk;      // 3
-template <int kComp>     // 43 with the Hessian, 7 (score + gradient) in the passes of the line search that do not need it
-__device__ __forceinline__ void ndt_block_reduce(double* sh /* [16][kNdtStride] */, double* sh2 /* [2][48] */, const double v[kComp],
+template <int kComp, int kB>     // 43 with the Hessian, 7 (score + gradient) in the passes of the line search that do not need it; kB threads
+__device__ __forceinline__ void ndt_block_reduce(double* sh /* [16][kB + 2] */, double* sh2 /* [kB / 64][48] */, const double v[kComp],
                                                  double acc[kNdtChunks], bool last, double* __restrict__ partials) {
+    constexpr int kStride = kB + 2, kWaves = kB / 64;
     const int tid = threadIdx.x, e = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int ch = 0; ch * kNdtChunk < kComp; ++ch) {
         const int c0 = ch * kNdtChunk;
 #pragma unroll
-        for (int k = 0; k < kNdtChunk; ++k) if (c0 + k < kComp) sh[k * kNdtStride + tid] = v[c0 + k];
+        for (int k = 0; k < kNdtChunk; ++k) if (c0 + k < kComp) sh[k * kStride + tid] = v[c0 + k];
         __syncthreads();
         double s = 0.0;
         if (c0 + e < kComp) {
-            const double* row = sh + e * kNdtStride + part * 16;
+            const double* row = sh + e * kStride + part * 16;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += row[k];
         }
@@ -325,26 +326,31 @@ __device__ __forceinline__ void ndt_block_reduce(double* sh /* [16][kNdtStride] 
         for (int ch = 0; ch * kNdtChunk < kComp; ++ch)
             if (lane < 16 && ch * kNdtChunk + lane < 48) sh2[wave * 48 + ch * kNdtChunk + lane] = acc[ch];
         __syncthreads();
-        if (tid < 48) partials[(size_t)blockIdx.x * 48 + tid] = tid < kComp ? sh2[tid] + sh2[48 + tid] : 0.0;
+        if (tid < 48) {
+            double r = sh2[tid];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) r += sh2[w * 48 + tid];
+            partials[(size_t)blockIdx.x * 48 + tid] = tid < kComp ? r : 0.0;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------
 // N3: computeDerivatives
 // ------------------------------------------------------------------------------
-template <bool kHessian>
+template <bool kHessian, int kB>
 __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* sh, double* sh2) {
     constexpr int kComp = kHessian ? kNdtComp : 7;
     // the exponential's table in LDS (a per-lane index into constant memory serialises; the slot is the tail of sh2, which the
     // block reduction uses only up to entry 96)
-    unsigned long long* const exp_tab = reinterpret_cast<unsigned long long*>(sh2 + 96);
+    unsigned long long* const exp_tab = reinterpret_cast<unsigned long long*>(sh2 + (kB / 64) * 48);
     if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
     __syncthreads();
     const GridHeader h = *a.hdr;
     const float gauss_d2 = (float)a.d2;
     double acc[kNdtChunks] = {0.0, 0.0, 0.0};
-    const uint32_t step = gridDim.x * kNdtBlock;
-    for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
+    const uint32_t step = gridDim.x * kB;
+    for (uint32_t base = blockIdx.x * kB; base < a.n_src; base += step) {
         const uint32_t idx = base + threadIdx.x;
         double v[kComp];
 #pragma unroll
@@ -423,18 +429,19 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
                 }
             }
         }
-        ndt_block_reduce<kComp>(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
+        ndt_block_reduce<kComp, kB>(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
     }
 }
 
 // ------------------------------------------------------------------------------
 // N5: computeHessian (double)
 // ------------------------------------------------------------------------------
+template <int kB>
 __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* sh, double* sh2) {
     const GridHeader h = *a.hdr;
     double acc[kNdtChunks] = {0.0, 0.0, 0.0};
-    const uint32_t step = gridDim.x * kNdtBlock;
-    for (uint32_t base = blockIdx.x * kNdtBlock; base < a.n_src; base += step) {
+    const uint32_t step = gridDim.x * kB;
+    for (uint32_t base = blockIdx.x * kB; base < a.n_src; base += step) {
         const uint32_t idx = base + threadIdx.x;
         double v[kNdtComp];
 #pragma unroll
@@ -499,7 +506,7 @@ __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose
                 }
             }
         }
-        ndt_block_reduce<kNdtComp>(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
+        ndt_block_reduce<kNdtComp, kB>(sh, sh2, v, acc, base + step >= a.n_src, a.partials);
     }
 }
 
@@ -508,12 +515,12 @@ template <bool kHessian>
 __global__ __launch_bounds__(kNdtBlock, 2) void ndt_derivatives_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
     __shared__ double sh[kNdtChunk * kNdtStride];
     __shared__ double sh2[2 * 48 + 32];
-    ndt_derivatives_body<kHessian>(a, T, ang, sh, sh2);
+    ndt_derivatives_body<kHessian, kNdtBlock>(a, T, ang, sh, sh2);
 }
 __global__ __launch_bounds__(kNdtBlock, 2) void ndt_hessian_kernel(const NdtArgs a, const NdtPose T, const NdtAngles ang) {
     __shared__ double sh[kNdtChunk * kNdtStride];
     __shared__ double sh2[2 * 48 + 32];
-    ndt_hessian_body(a, T, ang, sh, sh2);
+    ndt_hessian_body<kNdtBlock>(a, T, ang, sh, sh2);
 }
 
 // ------------------------------------------------------------------------------
@@ -528,9 +535,9 @@ __global__ __launch_bounds__(kNdtBlock, 2) void ndt_pass_kernel(const NdtArgs a,
     const int kind = ctl->kind;
     if (kind == kNdtPassNone) return;
     const NdtPose T = ctl->T;
-    if (kind == kNdtPassDerivH) ndt_derivatives_body<true>(a, T, ctl->ang, sh, sh2);
-    else if (kind == kNdtPassDeriv) ndt_derivatives_body<false>(a, T, ctl->ang, sh, sh2);
-    else ndt_hessian_body(a, T, ctl->ang, sh, sh2);
+    if (kind == kNdtPassDerivH) ndt_derivatives_body<true, kNdtBlock>(a, T, ctl->ang, sh, sh2);
+    else if (kind == kNdtPassDeriv) ndt_derivatives_body<false, kNdtBlock>(a, T, ctl->ang, sh, sh2);
+    else ndt_hessian_body<kNdtBlock>(a, T, ctl->ang, sh, sh2);
 }
 
 // the controller's initial state, prepared on the host (ndt_opt::ctl_init) and handed over as a kernel argument
@@ -632,6 +639,175 @@ __global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restr
         } else {
             __hip_atomic_store(&out->progress, seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// One launch per pass (the unsharded device loop).  A launch on this stream costs ~5 us of device time whatever it does, and the
+// fold/controller kernel above is a second one per pass: here its work is the PROLOGUE of the next pass instead -- every block
+// folds the rows of the previous launch and takes the controller step itself (same instructions on the same numbers: the blocks
+// agree to the bit, as loam_iterate_kernel's do), block 0 writes the new state and the progress word.  So that a block needs
+// 256 rows and not 1024, the blocks are 512 threads, one per CU.  State and rows are double-buffered by launch parity: launch k
+// reads what launch k - 1 wrote (buffer (k - 1) & 1) and writes buffer k & 1.  The optimisation ends in the prologue of the launch
+// AFTER its last pass; that launch and any queued behind it leave at once, each handing the finished state on to the other buffer.
+// ------------------------------------------------------------------------------
+static constexpr int kProBlock = 512;
+static constexpr int kProRows = 256;
+struct NdtProArgs {
+    const double* rows_prev;     // [rows_prev_n][48], written by the previous launch
+    const NdtCtl* ctl_prev;      // the state the previous launch evaluated
+    NdtCtl* ctl_next;            // the state this launch evaluates (written by block 0)
+    NdtOut* out;
+    double seq;
+    uint32_t rows_prev_n;
+    int32_t first;               // launch 0 of a call: ctl_prev is the initial state, nothing to fold
+};
+
+__device__ __forceinline__ float lds_uniform(const float* p) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *p)));
+}
+__device__ __forceinline__ double lds_uniform(const double* p) {
+    const double v = *p;
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// pose and tables out of LDS into scalar registers (what a body does not use is never read)
+__device__ __forceinline__ void lds_uniform_copy(const NdtCtl* c, NdtPose& T, NdtAngles& ang) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T.R[i] = lds_uniform(&c->T.R[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T.t[i] = lds_uniform(&c->T.t[i]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ang.j[r][k] = lds_uniform(&c->ang.j[r][k]); ang.jd[r][k] = lds_uniform(&c->ang.jd[r][k]); }
+#pragma unroll
+    for (int r = 0; r < 15; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ang.h[r][k] = lds_uniform(&c->ang.h[r][k]); ang.hd[r][k] = lds_uniform(&c->ang.hd[r][k]); }
+}
+
+__global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArgs a, const NdtProArgs pa) {
+    __shared__ double sh[kNdtChunk * (kProBlock + 2)];
+    __shared__ double sh2[(kProBlock / 64) * 48 + 32];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_ctl[kCtlWords];
+    __shared__ double sh_sums[48];
+    __shared__ double sh_sc[12];
+    __shared__ int sh_need;
+    const unsigned long long t_in = wall_clock64();
+    const int t = threadIdx.x;
+    NdtCtl* const c = reinterpret_cast<NdtCtl*>(sh_ctl);
+    // ONE round trip: the state, and -- on the guess that the previous launch was a line-search pass, which ten of thirteen are --
+    // its 7 sums a row in the [64 slices][8 components] layout
+    const int compL = t & 7, sliceL = t >> 3;
+    double vL[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t row = (uint32_t)(sliceL + 64 * u);
+        vL[u] = (!pa.first && row < pa.rows_prev_n) ? pa.rows_prev[(size_t)row * 48 + compL] : 0.0;
+    }
+    for (int w = t; w < kCtlWords; w += kProBlock) sh_ctl[w] = reinterpret_cast<const uint32_t*>(pa.ctl_prev)[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(vL[u]));
+    __syncthreads();
+    if (c->done) {      // finished in an earlier launch: hand the state on, so that whatever is queued behind reads it too
+        if (blockIdx.x == 0) for (int w = t; w < kCtlWords; w += kProBlock) reinterpret_cast<uint32_t*>(pa.ctl_next)[w] = sh_ctl[w];
+        return;
+    }
+    if (!pa.first) {
+        const bool light = c->kind == kNdtPassDeriv;
+        if (light) {
+            sh[sliceL * 8 + compL] = ((vL[0] + vL[1]) + vL[2]) + vL[3];
+        } else if (t < 480) {
+            const int comp = t % 48, slice = t / 48;      // 10 slices
+            double v[26];
+#pragma unroll
+            for (int u = 0; u < 26; ++u) {
+                const uint32_t row = (uint32_t)(slice + 10 * u);
+                v[u] = row < pa.rows_prev_n ? pa.rows_prev[(size_t)row * 48 + comp] : 0.0;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 26; ++u) acc += v[u];
+            sh[slice * 48 + comp] = acc;
+        }
+        __syncthreads();
+        if (t < 48) {
+            double v = 0.0;
+            if (light) {
+                if (t < 7) { v = sh[t]; for (int s2 = 1; s2 < 64; ++s2) v += sh[s2 * 8 + t]; }
+            } else if (t < kNdtComp) {
+                v = sh[t];
+#pragma unroll
+                for (int s2 = 1; s2 < 10; ++s2) v += sh[s2 * 48 + t];
+            }
+            sh_sums[t] = v;      // (a light pass leaves the Hessian slots at zero: ctl_decide does not read them)
+        }
+        __syncthreads();
+        unsigned long long t_a = 0;
+        if (t == 0) {
+            t_a = wall_clock64();
+            sh_need = ndt_opt::ctl_decide(c, sh_sums) ? 1 : 0;
+            c->ticks[2] += (uint32_t)(wall_clock64() - t_a);
+        }
+        __syncthreads();
+        if (sh_need) {
+            if (t < 6) {
+                double sc[2];
+                ndt_opt::trig_pair(c->x_t, t, sc);
+                sh_sc[2 * t] = sc[0]; sh_sc[2 * t + 1] = sc[1];
+            }
+            __syncthreads();
+            // pose and the four parts of the angle tables: five waves, one lane each
+            const unsigned long long t_c = wall_clock64();
+            if ((t & 63) == 0) {
+                const int wave = t >> 6;
+                if (wave == 0) ndt_opt::pose_from_trig(c->x_t, sh_sc, &c->T);
+                else if (wave == 1) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 0);
+                else if (wave == 2) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 1);
+                else if (wave == 3) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 2);
+                else if (wave == 4) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 3);
+            }
+            __syncthreads();
+            if (t == 0) c->ticks[3] += (uint32_t)(wall_clock64() - t_c);
+        }
+        if (t == 0) {
+            const unsigned long long t_b = wall_clock64();
+            c->ticks[0] += (uint32_t)(t_a - t_in); c->ticks[1] += (uint32_t)(t_b - t_a);
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            for (int w = t; w < kCtlWords; w += kProBlock) reinterpret_cast<uint32_t*>(pa.ctl_next)[w] = sh_ctl[w];
+            if (t == 0) {
+                NdtOut* const out = pa.out;
+                if (c->done) {
+                    const GridHeader* hdr = a.hdr;
+                    out->final_T = c->final_T; out->score = c->score;
+                    out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
+                    for (int i = 0; i < 4; ++i) out->ticks[i] = c->ticks[i];
+                    out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->pad0 = 0; out->grid_cells = hdr->n_cells;
+                    __threadfence_system();
+                    __hip_atomic_store(&out->seq, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    __hip_atomic_store(&out->progress, pa.seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        if (c->done) return;
+    }
+    const int kind = __builtin_amdgcn_readfirstlane(c->kind);
+    // (the copy inside each branch: a readfirstlane cannot be sunk into one, and 220 scalars live across the branch all spill)
+    if (kind == kNdtPassDerivH) {
+        NdtPose T; NdtAngles ang;
+        lds_uniform_copy(c, T, ang);
+        ndt_derivatives_body<true, kProBlock>(a, T, ang, sh, sh2);
+    } else if (kind == kNdtPassDeriv) {
+        NdtPose T; NdtAngles ang;
+        lds_uniform_copy(c, T, ang);
+        ndt_derivatives_body<false, kProBlock>(a, T, ang, sh, sh2);
+    } else {
+        NdtPose T; NdtAngles ang;
+        lds_uniform_copy(c, T, ang);
+        ndt_hessian_body<kProBlock>(a, T, ang, sh, sh2);
     }
 }
 
@@ -776,6 +952,20 @@ hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipSt
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
     hipLaunchKernelGGL(ndt_fold_ctl_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, a.hdr, d_out, seq);
+    return hipGetLastError();
+}
+// launch `index` of the one-launch-per-pass loop: d_ctl2 = two NdtCtl, d_rows2 = two buffers of kProRows * 48 doubles
+hipError_t ndt_launch_pass_pro(const NdtArgs& a_in, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index) {
+    uint32_t nb = (a_in.n_src + kProBlock - 1) / kProBlock;
+    nb = nb < 1 ? 1 : (nb > (uint32_t)kProRows ? (uint32_t)kProRows : nb);
+    NdtArgs a = a_in;
+    a.partials = d_rows2 + (size_t)(index & 1) * kProRows * 48;
+    NdtProArgs pa;
+    pa.rows_prev = d_rows2 + (size_t)((index + 1) & 1) * kProRows * 48;
+    pa.ctl_prev = index == 0 ? d_ctl2 : d_ctl2 + ((index + 1) & 1);
+    pa.ctl_next = d_ctl2 + (index & 1);
+    pa.out = d_out; pa.seq = seq; pa.rows_prev_n = nb; pa.first = index == 0 ? 1 : 0;
+    hipLaunchKernelGGL(ndt_pass_pro_kernel, dim3(nb), dim3(kProBlock), 0, s, a, pa);
     return hipGetLastError();
 }
 

@@ -22,8 +22,10 @@ namespace pcr {
 
 #if defined(__HIPCC__)
 #define NDT_HD __host__ __device__
+#define NDT_HD_FLAT __host__ __device__ __forceinline__      // the controller's own code: a call on the device saves and restores ~60 registers through scratch memory
 #else
 #define NDT_HD
+#define NDT_HD_FLAT inline
 #endif
 
 enum : int { kNdtPassDerivH = 0, kNdtPassDeriv = 1, kNdtPassHessian = 2, kNdtPassNone = 3 };
@@ -145,14 +147,14 @@ NDT_HD inline void mul33(const float A[9], const float B[9], float C[9]) {
     for (int i = 0; i < 9; ++i) C[i] = o[i];
 }
 // Translation(x[0:3]) * Rx * Ry * Rz evaluated in float (ndt_omp_impl.hpp:146-149,827-830)
-NDT_HD inline void pose_from_trig(const double x[6], const double sc[12], NdtPose* T) {
+NDT_HD_FLAT void pose_from_trig(const double x[6], const double sc[12], NdtPose* T) {
     float Rx[9], Ry[9], Rz[9], M[9];
     angle_axis((float)sc[0], (float)sc[1], 0, Rx); angle_axis((float)sc[2], (float)sc[3], 1, Ry); angle_axis((float)sc[4], (float)sc[5], 2, Rz);
     mul33(Rx, Ry, M); mul33(M, Rz, T->R);
     T->t[0] = (float)x[0]; T->t[1] = (float)x[1]; T->t[2] = (float)x[2];
 }
 // computeAngleDerivatives (ndt_omp_impl.hpp:289-395)
-NDT_HD inline void angle_tables_from_trig(const double sc[12], NdtAngles* a) {
+NDT_HD_FLAT void angle_tables_from_trig(const double sc[12], NdtAngles* a, int part = -1) {
     const double sx = sc[6], cx = sc[7], sy = sc[8], cy = sc[9], sz = sc[10], cz = sc[11];
     const double J[8][3] = {
         {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)}, {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},
@@ -166,17 +168,20 @@ NDT_HD inline void angle_tables_from_trig(const double sc[12], NdtAngles* a) {
         {(sy * sz), (sy * cz), 0}, {(-sx * cy * sz), (-sx * cy * cz), 0}, {(cx * cy * sz), (cx * cy * cz), 0},
         {(-cy * cz), (cy * sz), 0}, {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};
     // (fully unrolled: indexed with a loop variable the two tables would live in scratch memory on the device)
+    // `part` lets the device spread the rows over four waves (0: j, 1..3: five rows of h each); -1 = everything
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
+        if (part >= 1) continue;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { a->jd[r][c] = J[r][c]; a->j[r][c] = (float)J[r][c]; }
     }
 #pragma unroll
     for (int r = 0; r < 15; ++r) {
+        if (part >= 0 && part != 1 + r / 5) continue;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { a->hd[r][c] = Hh[r][c]; a->h[r][c] = (float)Hh[r][c]; }
     }
-    a->h[6][2] = (float)(sy);   // the float table (:384) writes (sy) where h_ang_d1_ (:362) has (-sy)
+    if (part < 0 || part == 2) a->h[6][2] = (float)(sy);   // the float table (:384) writes (sy) where h_ang_d1_ (:362) has (-sy)
 }
 NDT_HD inline void pose_from_p(const double x[6], NdtPose* T) {
     double sc[12];
@@ -223,48 +228,66 @@ NDT_HD inline void svd6_solve(const double A_in[36], const double b[6], double x
     }
 }
 
-// Device flavour of the Newton solve: Gaussian elimination with partial pivoting (a single lane: ~1 us, where the 100-odd
-// dependent rotations of the Jacobi SVD take ~40).  For a matrix of full numerical rank both give A^-1 b to cond(A) * eps.  When a
-// pivot falls below 1e-9 of the largest entry -- or anything is not finite -- the SVD's pseudo-inverse may drop a direction
-// that elimination keeps: returns false and the caller hands the whole alignment to the host path.
-NDT_HD inline bool lu6_solve_guarded(const double A_in[36], const double b[6], double x[6]) {
+// Device flavour of the Newton solve: Gaussian elimination with partial pivoting.  For a matrix of full numerical rank it and the
+// Jacobi SVD both give A^-1 b to cond(A) * eps.  When a pivot falls below 1e-9 of the largest entry -- or anything is not finite --
+// the SVD's pseudo-inverse may drop a direction that elimination keeps: returns false and the caller hands the whole alignment to
+// the host path.  Every index below is a compile-time constant once the loops are unrolled (the row exchange is a chain of
+// conditional swaps, of which at most one fires): the 6x7 system then lives in registers.  Indexed by the pivot row it lived in
+// scratch memory and one solve took ~20 us on the device's single lane, a quarter of a whole NDT iteration's controller time.
+NDT_HD_FLAT bool lu6_solve_guarded(const double A_in[36], const double b[6], double x[6]) {
     double M[6][7];
     double amax = 0;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
+#pragma unroll
         for (int j = 0; j < 6; ++j) { M[i][j] = A_in[i * 6 + j]; const double a = fabs(M[i][j]); amax = a > amax ? a : amax; }
         M[i][6] = b[i];
     }
     if (!(amax > 0) || !(amax < 1e300)) return false;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int piv = k;
         double best = fabs(M[k][k]);
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) { const double a = fabs(M[i][k]); if (a > best) { best = a; piv = i; } }
         if (!(best > 1e-9 * amax)) return false;
-        if (piv != k) for (int j = k; j < 7; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const bool sw = piv == i;
+#pragma unroll
+            for (int j = k; j < 7; ++j) { const double u = M[k][j], v = M[i][j]; M[k][j] = sw ? v : u; M[i][j] = sw ? u : v; }
+        }
         const double inv = 1.0 / M[k][k];
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) {
             const double f = M[i][k] * inv;
+#pragma unroll
             for (int j = k + 1; j < 7; ++j) M[i][j] -= f * M[k][j];
         }
     }
+    double y[6];
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = M[i][6];
-        for (int j = i + 1; j < 6; ++j) s -= M[i][j] * x[j];
-        x[i] = s / M[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= M[i][j] * y[j];
+        y[i] = s / M[i][i];
     }
-    for (int i = 0; i < 6; ++i) if (!(fabs(x[i]) < 1e300)) return false;
-    return true;
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { x[i] = y[i]; if (!(fabs(y[i]) < 1e300)) finite = false; }
+    return finite;
 }
 
 // updateIntervalMT (:713-733)
-NDT_HD inline bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
+NDT_HD_FLAT bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
     if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
     else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
     else if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
     return true;
 }
 // trialValueSelectionMT (:649-711)
-NDT_HD inline double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+NDT_HD_FLAT double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
     if (f_t > f_l) {
         const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
         const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
@@ -304,7 +327,7 @@ NDT_HD inline void ctl_init(NdtCtl* c, const NdtPose& T0, const double p0[6], do
 }
 
 // the pose and the angle tables of the next pass from the six sine/cosine pairs of x_t (trig_pair)
-NDT_HD inline void ctl_tables(NdtCtl* c, const double sc[12]) {
+NDT_HD_FLAT void ctl_tables(NdtCtl* c, const double sc[12]) {
     pose_from_trig(c->x_t, sc, &c->T);
     angle_tables_from_trig(sc, &c->ang);
 }
@@ -312,7 +335,7 @@ NDT_HD inline void ctl_tables(NdtCtl* c, const double sc[12]) {
 // `sums` = score, gradient[6], Hessian[36] of the pass that ctl->kind asked for.  Leaves the next request in *c (or done).
 // Returns true when the next pass evaluates at a NEW point x_t: the caller then owes ctl_tables() (the trigonometry is kept out
 // of this function so that the device can spread it over lanes).
-NDT_HD inline bool ctl_decide(NdtCtl* c, const double sums[43]) {
+NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
     const double mu = 1.e-4, nu = 0.9;
     const int max_it = 10;
     if (c->done) return false;
