@@ -12,6 +12,7 @@
 
 #include "pcr_internal.h"
 #include "ndt_opt.h"
+#include "vgicp_opt.h"
 #include "small_math.h"
 
 using namespace pcr;
@@ -98,6 +99,9 @@ struct pcr_handle {
     double* out32_dev = nullptr;
     bool vg_target_ready = false;
     int vg_outer = 0, vg_lin = 0, vg_err = 0;
+    DeviceBuf vg_ctl;                    // two VgCtl: the device-resident LM loop's state, by launch parity
+    VgOut* vg_out_host = nullptr;        // host-mapped: its result and progress word
+    VgOut* vg_out_dev = nullptr;
 
     // NDT work memory
     DeviceBuf nd_slot, nd_vox, nd_count, nd_list, nd_partials;
@@ -758,12 +762,59 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     double lambda = -1.0;
     bool conv = false;
     h->vg_outer = h->vg_lin = h->vg_err = 0;
+    // ---- device-resident loop (vgicp_opt.h): launches are enqueued ahead of the device, the host watches a progress word.  Not for
+    // sharded targets (every pass's sums cross the ranks) and not when pcr_params.reserved[6] asks for the host loop below ----
+    const bool on_device = n_src > 0 && !shard && h->prm.reserved[6] == 0 && h->prm.vgicp_max_iters > 0;
+    if (on_device) {
+        if (!h->vg_out_host) {
+            H_TRY(hipHostMalloc((void**)&h->vg_out_host, sizeof(VgOut), hipHostMallocMapped));
+            memset(h->vg_out_host, 0, sizeof(VgOut));
+            H_TRY(hipHostGetDevicePointer((void**)&h->vg_out_dev, h->vg_out_host, 0));
+        }
+        H_TRY(h->vg_ctl.reserve(2 * sizeof(VgCtl)));
+        H_TRY(h->vg_partials.reserve((size_t)2 * 512 * 32 * sizeof(double)));
+        a.partials = h->vg_partials.as<double>();
+        VgCtl* d_ctl = h->vg_ctl.as<VgCtl>();
+        VgOut* out = h->vg_out_host;
+        h->seq += 1.0;
+        const double seq = h->seq;
+        H_TRY(vgicp_launch_ctl_init(d_ctl, x0, h->prm.vgicp_max_iters, h->prm.vgicp_lm_inner, h->prm.vgicp_lm_init_scale, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps, h->stream));
+        // every outer iteration takes at most lm_inner passes, plus the first linearisation and the launch that finishes
+        const long limit = (long)h->prm.vgicp_max_iters * std::max(1, h->prm.vgicp_lm_inner) + 3;
+        long enq = 0;
+        // (a pass is ~14 us, and the word that says one has begun is written ~6 us into it: with fewer than three launches ahead of
+        // that word the queue runs dry while the host enqueues; a launch beyond the end costs ~5 us)
+        for (; enq < 4 && enq < limit; ++enq) H_TRY(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
+        const volatile double* f_seq = &out->seq;
+        const volatile double* f_prog = &out->progress;
+        long spins = 0;
+        for (;;) {
+            if (*f_seq == seq) break;
+            const double pr = *f_prog;
+            const long consumed = (pr >= seq * 4096.0 && pr < (seq + 1.0) * 4096.0) ? (long)(pr - seq * 4096.0) : 0;
+            if (enq - consumed < 3 && enq < limit) {
+                H_TRY(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq)); ++enq;
+                continue;
+            }
+            __builtin_ia32_pause();
+            if (++spins > 400000 || h->profile != 0) {          // a slow device (or a profiler): wait for what is queued, then look again
+                H_TRY(hipStreamSynchronize(h->stream));
+                if (*f_seq == seq) break;
+                if (enq >= limit) return fail(h, "vgicp: the optimiser did not finish within its pass budget");
+                spins = 0;
+                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        x0 = out->x0; conv = out->conv != 0;
+        h->vg_outer = out->outer; h->vg_lin = out->n_lin; h->vg_err = out->n_err;
+    }
     // The LM trial pass (vgicp_launch_error) also linearises at the trial pose: once a trial is accepted that pose IS the next
     // linearisation point, so its H, b, error and correspondences are already there (one launch + round trip less per
     // outer iteration; same values as a separate linearize() would return).
     double lin[28];
     bool have_lin = false;
-    for (int it = 0; it < h->prm.vgicp_max_iters && !conv; ++it) {
+    for (int it = 0; !on_device && it < h->prm.vgicp_max_iters && !conv; ++it) {
         h->vg_outer = it + 1;
         if (!have_lin) {
             h->seq += 1.0;
@@ -1250,7 +1301,8 @@ void pcr_destroy(pcr_handle* h) {
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
-    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release();
+    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release(); h->vg_ctl.release();
+    if (h->vg_out_host) (void)hipHostFree(h->vg_out_host);
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
     if (h->out48_host) (void)hipHostFree(h->out48_host);

@@ -217,6 +217,11 @@ hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, con
 hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s);
 // (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
+// device-resident Levenberg-Marquardt loop (vgicp_opt.h): state in HBM, result in host-mapped memory
+struct VgCtl;
+struct VgOut;
+hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s);
+hipError_t vgicp_launch_pass_pro(const VgicpArgs& a, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index);
 // out32[28] = compute_error(T); out32[0..27] = the linearisation at T (correspondences into a.corr_*_next)
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
 // out32[0] = sum of the squared 1-NN distances <= max_range, [1] = their number, [2] = (tile given) source points whose nearest

@@ -16,6 +16,7 @@
 
 #include "pcr_internal.h"
 #include "small_math.h"
+#include "vgicp_opt.h"
 
 namespace pcr {
 
@@ -464,10 +465,8 @@ __device__ __forceinline__ double vgicp_err_point(const VgicpArgs& a, const Pose
 // host swaps the buffers instead of paying another launch and round trip; when it is rejected the sums are dropped.
 // Both sums go through the same fixed-order block reduction as a stand-alone linearisation: bit-identical values.
 template <bool kWithError>
-__global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a, const Pose16 T) {
+__device__ __forceinline__ void vgicp_lin_body(const VgicpArgs& a, const Pose16& T, double* sh /* [29][kLinStride] */, double* sh_sum /* [8][32] */) {
     constexpr int kRows = kWithError ? 29 : 28;
-    __shared__ double sh[kRows * kLinStride];
-    __shared__ double sh_sum[8 * 32];
     const GridHeader h = *a.hdr;
     const int tid = threadIdx.x, e = tid & 31, ch = tid >> 5;
     double acc = 0.0;
@@ -504,6 +503,124 @@ __global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a,
         for (int c = 1; c < 8; ++c) s += sh_sum[c * 32 + tid];
         a.partials[(size_t)blockIdx.x * 32 + tid] = s;
     }
+}
+
+template <bool kWithError>
+__global__ __launch_bounds__(256) void vgicp_linearize_kernel(const VgicpArgs a, const Pose16 T) {
+    __shared__ double sh[(kWithError ? 29 : 28) * kLinStride];
+    __shared__ double sh_sum[8 * 32];
+    vgicp_lin_body<kWithError>(a, T, sh, sh_sum);
+}
+
+// ------------------------------------------------------------------------------
+// Device-resident Levenberg-Marquardt loop (unsharded targets): one launch per pass.  The prologue of a launch folds the 29 sums
+// of the previous one and takes the optimiser's step (vgicp_opt.h: vg_ctl_step) -- in every block, the same instructions on the
+// same numbers, as ndt_pass_pro_kernel and loam_iterate_kernel do; block 0 writes the new state and the progress word.  State and
+// rows are double-buffered by launch parity; the two correspondence buffers are chosen by the state's own parity (an accepted
+// trial makes the buffer it wrote the current one).  The loop ends in the prologue of the launch after its last pass.
+// ------------------------------------------------------------------------------
+struct VgProArgs {
+    const double* rows_prev;     // [rows_prev_n][32]
+    const VgCtl* ctl_prev;
+    VgCtl* ctl_next;
+    VgOut* out;
+    double seq;
+    uint32_t rows_prev_n;
+    int32_t first;
+};
+static constexpr int kVgCtlWords = (int)((sizeof(VgCtl) + 3) / 4);
+static_assert(sizeof(VgCtl) % 4 == 0, "VgCtl is copied word by word");
+
+__global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_in, const VgProArgs pa) {
+    __shared__ double sh[29 * kLinStride];
+    __shared__ double sh_sum[8 * 32];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_ctl[kVgCtlWords];
+    __shared__ double sh_sums[32];
+    const unsigned long long t_in = wall_clock64();
+    const int t = threadIdx.x;
+    VgCtl* const c = reinterpret_cast<VgCtl*>(sh_ctl);
+    // one round trip: the state and the rows of the previous launch ([8 slices][32 components], 32 rows a thread for <= 256 rows)
+    const int comp = t & 31, slice = t >> 5;
+    double acc = 0.0;
+    {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const uint32_t row = (uint32_t)(slice + 8 * u);
+            v[u] = (!pa.first && row < pa.rows_prev_n) ? pa.rows_prev[(size_t)row * 32 + comp] : 0.0;
+        }
+        for (int w = t; w < kVgCtlWords; w += 256) sh_ctl[w] = reinterpret_cast<const uint32_t*>(pa.ctl_prev)[w];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += v[u];
+    }
+    if (!pa.first)
+        for (uint32_t r0 = 256; r0 < pa.rows_prev_n; r0 += 256) {      // (more than 65 536 source points: 512 rows)
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const uint32_t row = r0 + (uint32_t)(slice + 8 * u);
+                v[u] = row < pa.rows_prev_n ? pa.rows_prev[(size_t)row * 32 + comp] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+        }
+    sh_sum[slice * 32 + comp] = acc;
+    __syncthreads();
+    if (c->done) {      // finished in an earlier launch: hand the state on to whatever is queued behind
+        if (blockIdx.x == 0) for (int w = t; w < kVgCtlWords; w += 256) reinterpret_cast<uint32_t*>(pa.ctl_next)[w] = sh_ctl[w];
+        return;
+    }
+    if (!pa.first) {
+        if (t < 32) {
+            double s = sh_sum[t];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) s += sh_sum[k * 32 + t];
+            sh_sums[t] = s;
+        }
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long t_a = wall_clock64();
+            vg_opt::ctl_step(c, sh_sums);
+            c->ticks[0] += (uint32_t)(t_a - t_in); c->ticks[1] += (uint32_t)(wall_clock64() - t_a);
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            for (int w = t; w < kVgCtlWords; w += 256) reinterpret_cast<uint32_t*>(pa.ctl_next)[w] = sh_ctl[w];
+            if (t == 0) {
+                VgOut* const out = pa.out;
+                if (c->done) {
+                    out->x0 = c->x0;
+                    out->conv = c->conv; out->outer = c->outer; out->n_lin = c->n_lin; out->n_err = c->n_err; out->passes = c->passes; out->pad0 = 0;
+                    __threadfence_system();
+                    __hip_atomic_store(&out->seq, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    __hip_atomic_store(&out->progress, pa.seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        if (c->done) return;
+    }
+    // the pose of this pass and the correspondence buffers, as scalars
+    Pose16 T;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double v = c->xi.m[i];
+        T.m[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+    const int kind = __builtin_amdgcn_readfirstlane(c->kind), parity = __builtin_amdgcn_readfirstlane(c->parity);
+    VgicpArgs a = a_in;
+    if (parity) {
+        a.corr_slot = a_in.corr_slot_next; a.corr_M = a_in.corr_M_next;
+        a.corr_slot_next = a_in.corr_slot; a.corr_M_next = a_in.corr_M;
+    }
+    __syncthreads();      // (sh_sum is reused by the body)
+    if (kind == kVgPassLinearize) vgicp_lin_body<false>(a, T, sh, sh_sum);
+    else vgicp_lin_body<true>(a, T, sh, sh_sum);
+}
+
+struct VgCtlArg { uint32_t w[kVgCtlWords]; };
+__global__ __launch_bounds__(256) void vgicp_ctl_store_kernel(VgCtl* __restrict__ ctl, const VgCtlArg init) {
+    for (int t = threadIdx.x; t < kVgCtlWords; t += 256) reinterpret_cast<uint32_t*>(ctl)[t] = init.w[t];
 }
 
 // fold per-block partials (32 doubles each) into 32 doubles, fixed order
@@ -613,6 +730,29 @@ hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d
     const uint32_t nb = vgicp_blocks(a.n_src);
     hipLaunchKernelGGL(vgicp_linearize_kernel<false>, dim3(nb), dim3(256), 0, s, a, T);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, nb, d_out32, seq);
+    return hipGetLastError();
+}
+
+hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s) {
+    VgCtl c;
+    memset(&c, 0, sizeof c);
+    vg_opt::ctl_init(&c, guess, max_iters, lm_inner, lm_init_scale, rot_eps, trans_eps);
+    VgCtlArg arg;
+    memcpy(arg.w, &c, sizeof c);
+    hipLaunchKernelGGL(vgicp_ctl_store_kernel, dim3(1), dim3(256), 0, s, d_ctl2, arg);
+    return hipGetLastError();
+}
+// launch `index` of the device-resident loop: d_ctl2 = two VgCtl, d_rows2 = two buffers of 512 * 32 doubles
+hipError_t vgicp_launch_pass_pro(const VgicpArgs& a_in, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index) {
+    const uint32_t nb = vgicp_blocks(a_in.n_src);
+    VgicpArgs a = a_in;
+    a.partials = d_rows2 + (size_t)(index & 1) * 512 * 32;
+    VgProArgs pa;
+    pa.rows_prev = d_rows2 + (size_t)((index + 1) & 1) * 512 * 32;
+    pa.ctl_prev = index == 0 ? d_ctl2 : d_ctl2 + ((index + 1) & 1);
+    pa.ctl_next = d_ctl2 + (index & 1);
+    pa.out = d_out; pa.seq = seq; pa.rows_prev_n = nb; pa.first = index == 0 ? 1 : 0;
+    hipLaunchKernelGGL(vgicp_pass_pro_kernel, dim3(nb), dim3(256), 0, s, a, pa);
     return hipGetLastError();
 }
 

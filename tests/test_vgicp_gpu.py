@@ -61,6 +61,45 @@ def test_scan2map_matches_oracle(gpu, vg_world):
     np.testing.assert_allclose(reg.getFitnessScore(), oracle.fitness_score(w["scan"], w["map"], pose), rtol=1e-6)
 
 
+def test_device_resident_optimiser_equals_the_host_driven_one(gpu, vg_world):
+    """The Levenberg-Marquardt loop is one state machine (csrc/vgicp_opt.h) that runs on the device by default -- the fold of a pass's
+    sums and the optimiser's step are the prologue of the next pass's launch, no host round trip in between -- and as the reference's
+    loops on the host for sharded targets (pcr_params.reserved[6] = 1 selects that here).  Same decisions (convergence flag, outer
+    iterations, passes), and the same Matrix4f pose up to the last bit of the two libms' sine in so3_exp."""
+    from simpleslam_amd.pcr import default_params
+    w = vg_world
+    p_host = default_params()
+    p_host.reserved[6] = 1
+    dev, host = VgicpRegister(), VgicpRegister(params=p_host)
+    for seed, tr, rd in ((41, 0.3, 2.0), (42, 0.1, 0.5), (43, 0.6, 4.0), (44, 0.0, 0.0), (45, 1.5, 8.0)):
+        T0 = synth.perturb(w["truth"], seed, trans=tr, rot_deg=rd) if tr else w["truth"].copy()
+        pd, ph = T0.copy(), T0.copy()
+        cd = dev.scan2Map(w["scan"], w["map"], pd)
+        ch = host.scan2Map(w["scan"], w["map"], ph)
+        assert cd == ch, seed
+        sd, sh = dev.stats(), host.stats()
+        assert (sd["iterations"], sd["kernel_launches"]) == (sh["iterations"], sh["kernel_launches"]), (seed, sd, sh)
+        dt, dr = synth.pose_error(pd, ph)
+        assert dt <= 2e-6 and dr <= 2e-6, (seed, dt, dr)      # (a float ulp of the pose at 10 m is 1e-6)
+        np.testing.assert_allclose(dev.getFitnessScore(), host.getFitnessScore(), rtol=1e-5)
+    # many calls on one handle: launches enqueued beyond the end of one alignment must not leak into the next
+    first = w["init"].copy(); dev.scan2Map(w["scan"], w["map"], first)
+    for _ in range(20):
+        p = w["init"].copy(); dev.scan2Map(w["scan"], w["map"], p)
+        np.testing.assert_array_equal(p, first)
+    # an iteration cap that ends the loop in the middle of the search
+    from simpleslam_amd.pcr import default_params as dp
+    for cap in (1, 2, 3):
+        pa, pb = dp(), dp()
+        pa.vgicp_max_iters = cap; pb.vgicp_max_iters = cap; pb.reserved[6] = 1
+        ra, rb = VgicpRegister(params=pa), VgicpRegister(params=pb)
+        qa, qb = w["init"].copy(), w["init"].copy()
+        assert ra.scan2Map(w["scan"], w["map"], qa) == rb.scan2Map(w["scan"], w["map"], qb)
+        assert ra.stats()["iterations"] == rb.stats()["iterations"] == cap
+        dt, dr = synth.pose_error(qa, qb)
+        assert dt <= 2e-6 and dr <= 2e-6, (cap, dt, dr)
+
+
 def test_half_metre_voxels(gpu, vg_world):
     """BASELINE config 3 asks for 0.5 m voxels (the reference hard-codes 1.0: SURVEY.md F9)."""
     w = vg_world
