@@ -236,6 +236,20 @@ int pcr_ndt_opt_request(const pcr_ndt_opt* o, int* kind, double p6[6], double po
 int pcr_ndt_opt_feed(pcr_ndt_opt* o, const double sums[43]);
 int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, int* iterations, int* done);
 
+/* The VGICP optimiser on its own (host only, no GPU): fast_gicp's LsqRegistration::computeTransformation + step_lm
+ * (lsq_registration_impl.hpp:53-79, 125-171) as the state machine that pcr_scan2map runs on the device (csrc/vgicp_opt.h), driven
+ * from outside like pcr_ndt_opt_*: the caller evaluates what it asks for and feeds the 29 sums back.
+ *   request: kind 0 = linearize at pose_eval (fast_vgicp_impl.hpp:119-180); 1 = an LM trial: compute_error (:183-204) at pose_eval on
+ *            the correspondences of the linearisation at pose_lin, AND the linearisation at pose_eval; 2 = finished.  Poses column-major.
+ *   feed:    sums = H upper triangle row by row (21), b (6), error of the linearisation at pose_eval (1), the trial's error (1).
+ *   result:  the pose computeTransformation would return (before the Matrix4f cast of VgicpRegister.cpp:37), converged, outer iterations. */
+typedef struct pcr_vgicp_opt pcr_vgicp_opt;
+pcr_vgicp_opt* pcr_vgicp_opt_create(const double pose_guess[16], int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps);
+void pcr_vgicp_opt_destroy(pcr_vgicp_opt* o);
+int pcr_vgicp_opt_request(const pcr_vgicp_opt* o, int* kind, double pose_eval[16], double pose_lin[16]);
+int pcr_vgicp_opt_feed(pcr_vgicp_opt* o, const double sums[29]);
+int pcr_vgicp_opt_result(const pcr_vgicp_opt* o, double pose16[16], int* converged, int* outer_iterations, int* done);
+
 /* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
  * accumulation done, partial sums stored (+ the fold inside the prologue and three stamps of the dense search).  out receives

@@ -320,6 +320,9 @@ def _vg():
         L.oracle_vgicp_scan2map.restype = C.c_int
         L.oracle_vgicp_scan2map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                             C.POINTER(VgicpParams), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_vgicp_error.restype = C.c_double
+        L.oracle_vgicp_error.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_vgicp_linearize.restype = C.c_long
         L.oracle_vgicp_linearize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                              C.POINTER(VgicpParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -395,6 +398,18 @@ def vgicp_linearize(src, dst, pose, src_covs, dst_covs, params=None):
     nc = _vg().oracle_vgicp_linearize(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pc), C.byref(params),
                                       _p(sc), _p(dc), _p(H), _p(b), C.byref(err))
     return dict(H=H.reshape(6, 6), b=b, err=err.value, n=int(nc))
+
+
+def vgicp_error(src, dst, pose_lin, pose_eval, src_covs, dst_covs, params=None):
+    """compute_error at pose_eval on the correspondences of a linearisation at pose_lin (an LM trial, lsq_registration_impl.hpp:141)."""
+    src, dst = _f32(src), _f32(dst)
+    params = params or vgicp_params()
+    pl = np.ascontiguousarray(np.asarray(pose_lin, np.float64).T).reshape(16).copy()
+    pe = np.ascontiguousarray(np.asarray(pose_eval, np.float64).T).reshape(16).copy()
+    sc = np.ascontiguousarray(src_covs, np.float64)
+    dc = np.ascontiguousarray(dst_covs, np.float64)
+    return float(_vg().oracle_vgicp_error(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], _p(pl), _p(pe), C.byref(params),
+                                          _p(sc), _p(dc)))
 
 
 def vgicp_voxel_at(dst, dst_covs, res, p):

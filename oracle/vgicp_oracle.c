@@ -362,6 +362,19 @@ long oracle_vgicp_linearize(const float *src, size_t n_src, const float *dst, si
     return (long)nc;
 }
 
+/* compute_error (fast_vgicp_impl.hpp:183-204) at `pose_eval` on the correspondences of a linearisation at `pose_lin`: what an LM
+ * trial evaluates (lsq_registration_impl.hpp:141).  Test infrastructure for the optimiser state machine (csrc/vgicp_opt.h). */
+double oracle_vgicp_error(const float *src, size_t n_src, const float *dst, size_t n_dst, size_t stride, const double pose_lin[16],
+                          const double pose_eval[16], const oracle_vgicp_params *prm, const double *src_covs, const double *dst_covs)
+{
+    voxmap *vm = voxmap_build(dst, n_dst, stride, dst_covs, prm->resolution);
+    corr_t *corr = (corr_t *)malloc(sizeof(corr_t) * (n_src ? n_src : 1));
+    size_t nc = update_corr(vm, src, n_src, stride, src_covs, pose_lin, corr);
+    const double e = eval_cost(corr, nc, src, stride, pose_eval, NULL, NULL);
+    free(corr); voxmap_free(vm);
+    return e;
+}
+
 /* pcl::Registration::getFitnessScore(): mean squared 1-NN distance (float kd-tree) of the
  * source transformed by the final (f32) transformation; -1... PCL returns DBL_MAX when empty */
 double oracle_fitness_score(const float *src, size_t n_src, const float *dst, size_t n_dst, size_t stride, const double pose[16], double max_range)

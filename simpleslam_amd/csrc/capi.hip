@@ -1655,6 +1655,39 @@ int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, 
     return 0;
 }
 
+struct pcr_vgicp_opt { VgCtl c; };
+
+pcr_vgicp_opt* pcr_vgicp_opt_create(const double pose_guess[16], int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps) {
+    if (!pose_guess) return nullptr;
+    pcr_vgicp_opt* o = new pcr_vgicp_opt;
+    memset(&o->c, 0, sizeof o->c);
+    Pose16 g;
+    for (int i = 0; i < 16; ++i) g.m[i] = (double)(float)pose_guess[i];      // guess handed over as Matrix4f (VgicpRegister.cpp:36), as run_vgicp does
+    vg_opt::ctl_init(&o->c, g, max_iters, lm_inner, lm_init_scale, rot_eps, trans_eps);
+    return o;
+}
+void pcr_vgicp_opt_destroy(pcr_vgicp_opt* o) { delete o; }
+int pcr_vgicp_opt_request(const pcr_vgicp_opt* o, int* kind, double pose_eval[16], double pose_lin[16]) {
+    if (!o || !kind) return 1;
+    *kind = o->c.done ? 2 : o->c.kind;
+    if (pose_eval) for (int i = 0; i < 16; ++i) pose_eval[i] = o->c.xi.m[i];
+    if (pose_lin) for (int i = 0; i < 16; ++i) pose_lin[i] = o->c.x0.m[i];
+    return 0;
+}
+int pcr_vgicp_opt_feed(pcr_vgicp_opt* o, const double sums[29]) {
+    if (!o || !sums || o->c.done) return 1;
+    vg_opt::ctl_step(&o->c, sums);
+    return 0;
+}
+int pcr_vgicp_opt_result(const pcr_vgicp_opt* o, double pose16[16], int* converged, int* outer_iterations, int* done) {
+    if (!o) return 1;
+    if (pose16) for (int i = 0; i < 16; ++i) pose16[i] = o->c.x0.m[i];
+    if (converged) *converged = o->c.conv;
+    if (outer_iterations) *outer_iterations = o->c.outer;
+    if (done) *done = o->c.done;
+    return 0;
+}
+
 int pcr_get_trace(pcr_handle* h, int32_t* n_iters, double* JtJ, double* JtE, int64_t* n, double* x) {
     if (!h) return 1;
     if (!h->prm.record_trace) return fail(h, "trace not recorded: set pcr_params.record_trace");

@@ -327,3 +327,54 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
         # same decisions; the pose agrees to a few float ulps (the stand-alone derivative entry point of the oracle rebuilds the float
         # transform from p6 on its own, so the sums fed here are not bit for bit those of the oracle's inner loop)
         np.testing.assert_allclose(pose.reshape(4, 4).T, po, rtol=0, atol=5e-6)
+
+
+def test_vgicp_optimiser_driven_by_the_oracles_sums_arrives_where_the_oracle_does():
+    """csrc/vgicp_opt.h is fast_gicp's computeTransformation + step_lm turned inside out: a state machine that asks for one pass at a
+    time -- a linearisation, or an LM trial (the error on the last linearisation's correspondences plus the linearisation at the trial
+    pose).  On the GPU it runs in the prologue of the next pass's launch; here it runs on the host (pcr_vgicp_opt_*, no GPU involved) and
+    every pass is answered by the ORACLE's linearize / compute_error.  It must finish after the same outer iterations and error
+    evaluations, with the same flag and pose as the oracle's own loop (oracle/vgicp_oracle.c) -- bit for bit: same sums, same arithmetic."""
+    import ctypes as C
+    from simpleslam_amd import synth
+    from simpleslam_amd.pcr import load_library
+    L = load_library()
+    world, m = synth.make_map(20_000, seed=78)
+    scan, T = synth.make_scan(world, 0, seed=78, beams=16, azimuths=128)
+    dp = C.POINTER(C.c_double)
+    prm = oracle.vgicp_params(threads=4)
+    sc, dc = oracle.vgicp_covariances(scan, 20, 4), oracle.vgicp_covariances(m, 20, 4)
+    iu = np.triu_indices(6)
+    for seed, tr, rd, cap in ((1, 0.3, 2.0, None), (2, 0.8, 5.0, None), (3, 0.0, 0.0, None), (4, 0.3, 2.0, 2)):
+        T0 = synth.perturb(T, seed, trans=tr, rot_deg=rd) if tr else T.copy()
+        p = oracle.vgicp_params(threads=4)
+        if cap: p.max_iters = cap
+        po, co, info = oracle.vgicp_scan2map(scan, m, T0, p, sc, dc)
+        guess = np.ascontiguousarray(T0.T).reshape(16).copy()
+        o = L.pcr_vgicp_opt_create(guess.ctypes.data_as(dp), int(p.max_iters), int(p.lm_inner), float(p.lm_init), float(p.rot_eps), float(p.trans_eps))
+        assert o
+        try:
+            n_err = 0
+            for _ in range(2000):
+                kind, pe, pl = C.c_int(-1), np.zeros(16), np.zeros(16)
+                assert L.pcr_vgicp_opt_request(o, C.byref(kind), pe.ctypes.data_as(dp), pl.ctypes.data_as(dp)) == 0
+                if kind.value == 2:
+                    break
+                Te, Tl = pe.reshape(4, 4).T, pl.reshape(4, 4).T
+                lin = oracle.vgicp_linearize(scan, m, Te, sc, dc, p)
+                sums = np.zeros(29)
+                sums[:21] = lin["H"][iu]; sums[21:27] = lin["b"]; sums[27] = lin["err"]
+                if kind.value == 1:
+                    sums[28] = oracle.vgicp_error(scan, m, Tl, Te, sc, dc, p)
+                    n_err += 1
+                assert L.pcr_vgicp_opt_feed(o, sums.ctypes.data_as(dp)) == 0
+            else:
+                raise AssertionError("the optimiser did not finish")
+            pose, conv, outer, done = np.zeros(16), C.c_int(0), C.c_int(0), C.c_int(0)
+            assert L.pcr_vgicp_opt_result(o, pose.ctypes.data_as(dp), C.byref(conv), C.byref(outer), C.byref(done)) == 0 and done.value == 1
+        finally:
+            L.pcr_vgicp_opt_destroy(o)
+        assert bool(conv.value) == co, seed
+        assert (outer.value, n_err) == (info["outer"], info["error_evals"]), (seed, outer.value, n_err, info)
+        got = pose.reshape(4, 4).T.astype(np.float32).astype(np.float64)      # final_transformation_ is a Matrix4f
+        np.testing.assert_array_equal(got, po)
