@@ -688,44 +688,6 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     return 0;
 }
 
-void host_make_delta(const double d[6], double D[16]) {
-    // so3_exp (so3.hpp:58-77) -> Quaterniond::toRotationMatrix; translation d[3:6]
-    const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    double imag, real;
-    if (th2 < 1e-10) {
-        const double q4 = th2 * th2;
-        imag = 0.5 - 1.0 / 48.0 * th2 + 1.0 / 3840.0 * q4;
-        real = 1.0 - 1.0 / 8.0 * th2 + 1.0 / 384.0 * q4;
-    } else {
-        const double th = sqrt(th2), hf = 0.5 * th;
-        imag = sin(hf) / th; real = cos(hf);
-    }
-    const double w = real, x = imag * d[0], y = imag * d[1], z = imag * d[2];
-    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
-                 tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    for (int i = 0; i < 16; ++i) D[i] = 0;
-    D[0] = 1 - (tyy + tzz); D[4] = txy - twz; D[8] = txz + twy;
-    D[1] = txy + twz; D[5] = 1 - (txx + tzz); D[9] = tyz - twx;
-    D[2] = txz - twy; D[6] = tyz + twx; D[10] = 1 - (txx + tyy);
-    D[12] = d[3]; D[13] = d[4]; D[14] = d[5]; D[15] = 1;
-}
-
-void host_mul44(const double A[16], const double B[16], double C[16]) {
-    double o[16];
-    for (int c = 0; c < 4; ++c)
-        for (int r = 0; r < 4; ++r) { double s = 0; for (int k = 0; k < 4; ++k) s += A[k * 4 + r] * B[c * 4 + k]; o[c * 4 + r] = s; }
-    o[3] = o[7] = o[11] = 0; o[15] = 1;
-    memcpy(C, o, sizeof o);
-}
-
-bool host_is_converged(const double D[16], double rot_eps, double trans_eps) {
-    double rmax = 0, tmax = 0;
-    for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r) rmax = std::max(rmax, fabs(D[c * 4 + r] - (r == c ? 1.0 : 0.0)) * (1.0 / rot_eps));
-    for (int r = 0; r < 3; ++r) tmax = std::max(tmax, fabs(D[12 + r]) * (1.0 / trans_eps));
-    return std::max(rmax, tmax) < 1;
-}
-
 int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged) {
     if (!h->vg_target_ready) return fail(h, "no target prepared");
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
@@ -759,7 +721,6 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
 
     Pose16 x0;
     for (int i = 0; i < 16; ++i) x0.m[i] = (double)(float)pose[i];     // guess handed over as Matrix4f (VgicpRegister.cpp:36)
-    double lambda = -1.0;
     bool conv = false;
     h->vg_outer = h->vg_lin = h->vg_err = 0;
     // ---- device-resident loop (vgicp_opt.h): launches are enqueued ahead of the device, the host watches a progress word.  Not for
@@ -809,65 +770,28 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         x0 = out->x0; conv = out->conv != 0;
         h->vg_outer = out->outer; h->vg_lin = out->n_lin; h->vg_err = out->n_err;
     }
-    // The LM trial pass (vgicp_launch_error) also linearises at the trial pose: once a trial is accepted that pose IS the next
-    // linearisation point, so its H, b, error and correspondences are already there (one launch + round trip less per
-    // outer iteration; same values as a separate linearize() would return).
-    double lin[28];
-    bool have_lin = false;
-    for (int it = 0; !on_device && it < h->prm.vgicp_max_iters && !conv; ++it) {
-        h->vg_outer = it + 1;
-        if (!have_lin) {
+    // ---- host-driven loop: the same state machine (vgicp_opt.h), one host round trip per pass; sharded, every pass's sums cross
+    // the ranks.  The LM trial pass (vgicp_launch_error) also linearises at the trial pose: once a trial is accepted that pose IS the
+    // next linearisation point, so its H, b, error and correspondences are already there (same values as a separate linearize()
+    // would return) and the state's parity says which of the two correspondence buffers they are in ----
+    if (!on_device) {
+        VgCtl c;
+        memset(&c, 0, sizeof c);
+        vg_opt::ctl_init(&c, x0, h->prm.vgicp_max_iters, h->prm.vgicp_lm_inner, h->prm.vgicp_lm_init_scale, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps);
+        while (!c.done) {
+            VgicpArgs ap = a;
+            if (c.parity) { ap.corr_slot = a.corr_slot_next; ap.corr_M = a.corr_M_next; ap.corr_slot_next = a.corr_slot; ap.corr_M_next = a.corr_M; }
             h->seq += 1.0;
-            H_TRY(vgicp_launch_linearize(a, x0, h->out32_dev, h->stream, h->seq));
+            if (c.kind == kVgPassLinearize) H_TRY(vgicp_launch_linearize(ap, c.xi, h->out32_dev, h->stream, h->seq));
+            else H_TRY(vgicp_launch_error(ap, c.xi, h->out32_dev, h->stream, h->seq));
             if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
             if (shard && ranks_allreduce(h, h->out32_host, 29)) return 1;
-            ++h->vg_lin;
-            for (int k = 0; k < 28; ++k) lin[k] = h->out32_host[k];
+            double sums[29];
+            for (int k = 0; k < 29; ++k) sums[k] = h->out32_host[k];
+            vg_opt::ctl_step(&c, sums);
         }
-        have_lin = false;
-        double H[36], b[6], D[16];
-        int q = 0;
-        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[r * 6 + c] = H[c * 6 + r] = lin[q++]; }
-        for (int r = 0; r < 6; ++r) b[r] = lin[21 + r];
-        const double y0 = lin[27];
-        if (lambda < 0.0) { double mx = 0; for (int i = 0; i < 6; ++i) mx = std::max(mx, fabs(H[i * 7])); lambda = h->prm.vgicp_lm_init_scale * mx; }
-        double nu = 2.0;
-        bool ok = false;
-        for (int i = 0; i < h->prm.vgicp_lm_inner; ++i) {
-            double A[36], rhs[6], d[6];
-            memcpy(A, H, sizeof A);
-            for (int k = 0; k < 6; ++k) { A[k * 7] += lambda; rhs[k] = -b[k]; }
-            ldlt6_solve(A, rhs, d);
-            host_make_delta(d, D);
-            Pose16 xi;
-            host_mul44(D, x0.m, xi.m);
-            h->seq += 1.0;
-            H_TRY(vgicp_launch_error(a, xi, h->out32_dev, h->stream, h->seq));
-            if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
-            if (shard && ranks_allreduce(h, h->out32_host, 29)) return 1;
-            ++h->vg_err;
-            const double yi = h->out32_host[28];
-            double den = 0;
-            for (int k = 0; k < 6; ++k) den += d[k] * (lambda * d[k] - b[k]);
-            const double rho = (y0 - yi) / den;
-            if (rho < 0) {
-                if (host_is_converged(D, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps)) { ok = true; break; }
-                lambda = nu * lambda; nu = 2 * nu;
-                continue;
-            }
-            x0 = xi;
-            // the pass above linearised at xi: keep its sums and make its correspondences the current ones
-            for (int k = 0; k < 28; ++k) lin[k] = h->out32_host[k];
-            std::swap(a.corr_slot, a.corr_slot_next);
-            std::swap(a.corr_M, a.corr_M_next);
-            have_lin = true;
-            const double f = 1 - pow(2 * rho - 1, 3);
-            lambda = lambda * std::max(1.0 / 3.0, f);
-            ok = true;
-            break;
-        }
-        if (!ok) break;                                  // "lm not converged!!"
-        conv = host_is_converged(D, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps);
+        x0 = c.x0; conv = c.conv != 0;
+        h->vg_outer = c.outer; h->vg_lin = c.n_lin; h->vg_err = c.n_err;
     }
     if (a.escapes) {
         uint32_t esc = 0;
