@@ -226,7 +226,8 @@ int pcr_sc_query(pcr_sc* sc, long long id, long long* match, float* yaw_rad, dou
  * it asks for and feeds the 43 sums back.  An introspection entry point like pcr_ndt_derivatives: the CPU test suite drives it with the
  * oracle's derivatives and must arrive where the oracle's own loop arrives.
  *   request: kind 0 = score + gradient + Hessian at p6 (computeDerivatives), 1 = score + gradient only, 2 = computeHessian (double) at
- *            the same p6 as the previous request, 3 = finished.  pose16 (optional) = the float transform of p6, column-major.
+ *            the same p6 as the previous request, 3 = finished.  (Score + gradient are never asked for twice running at one p6: the
+ *            reference's clamped trial steps do repeat, and the state machine feeds itself the sums it already has.)  pose16 (optional) = the float transform of p6, column-major.
  *   feed:    sums = score, gradient[6], Hessian[36] (row-major; ignored entries may be anything finite).
  *   result:  the pose computeTransformation would return (Matrix4f values), converged flag, iterations. */
 typedef struct pcr_ndt_opt pcr_ndt_opt;
@@ -235,6 +236,9 @@ void pcr_ndt_opt_destroy(pcr_ndt_opt* o);
 int pcr_ndt_opt_request(const pcr_ndt_opt* o, int* kind, double p6[6], double pose16[16]);
 int pcr_ndt_opt_feed(pcr_ndt_opt* o, const double sums[43]);
 int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, int* iterations, int* done);
+/* evaluations = computeDerivatives calls of the reference's loop so far, hessians = its computeHessian calls, replayed = how many of the
+ * evaluations were requests for score + gradient at the point they had just been evaluated at, answered without asking (ndt_opt.h) */
+int pcr_ndt_opt_counts(const pcr_ndt_opt* o, int* evaluations, int* hessians, int* replayed);
 
 /* The VGICP optimiser on its own (host only, no GPU): fast_gicp's LsqRegistration::computeTransformation + step_lm
  * (lsq_registration_impl.hpp:53-79, 125-171) as the state machine that pcr_scan2map runs on the device (csrc/vgicp_opt.h), driven

@@ -1044,6 +1044,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     if (!on_device && !sharded_done) {
         NdtCtl c;
         ctl_init(&c, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters);
+        c.replay_off = getenv("PCR_NDT_NO_REPLAY") ? 1 : 0;
         double sums[43];
         while (!c.done) {
             if (n_src == 0) memset(sums, 0, sizeof sums);        // an empty scan: computeDerivatives sums nothing
@@ -1576,6 +1577,14 @@ int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, 
     if (converged) *converged = o->c.conv;
     if (iterations) *iterations = o->c.nr_it;
     if (done) *done = o->c.done;
+    return 0;
+}
+
+int pcr_ndt_opt_counts(const pcr_ndt_opt* o, int* evaluations, int* hessians, int* replayed) {
+    if (!o) return 1;
+    if (evaluations) *evaluations = o->c.n_deriv;
+    if (hessians) *hessians = o->c.n_hess;
+    if (replayed) *replayed = o->c.replayed;
     return 0;
 }
 

@@ -171,21 +171,55 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
             const double c2[3][3] = {{(double)s2[0] / kFix2, (double)s2[1] / kFix2, (double)s2[2] / kFix2},
                                      {(double)s2[1] / kFix2, (double)s2[3] / kFix2, (double)s2[4] / kFix2},
                                      {(double)s2[2] / kFix2, (double)s2[4] / kFix2, (double)s2[5] / kFix2}};
-            double sum[3], mean[3], cov[9];
+            double sum[3], sxx[9], mean[3], cov[9];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { sum[r] = dn * o[r] + c1[r]; mean[r] = sum[r] / dn; }
-            const double f = (dn - 1.0) / dn;
+            for (int r = 0; r < 3; ++r) {
+                sum[r] = dn * o[r] + c1[r];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double sxx = ((dn * o[r]) * o[c] + (o[r] * c1[c] + o[c] * c1[r])) + c2[r][c];
-                    cov[r * 3 + c] = ((sxx - 2 * (sum[r] * mean[c])) / dn + mean[r] * mean[c]) * f;
-                }
-            // SelfAdjointEigenSolver reads the lower triangle
-            const double C[6] = {cov[0], cov[3], cov[6], cov[4], cov[7], cov[8]};
+                for (int c = 0; c < 3; ++c) sxx[r * 3 + c] = ((dn * o[r]) * o[c] + (o[r] * c1[c] + o[c] * c1[r])) + c2[r][c];
+            }
             double w[3], V[3][3];
-            sym3_eig_asc(C, w, V);
+            for (int attempt = 0;; ++attempt) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) mean[r] = sum[r] / dn;
+                const double f = (dn - 1.0) / dn;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cov[r * 3 + c] = ((sxx[r * 3 + c] - 2 * (sum[r] * mean[c])) / dn + mean[r] * mean[c]) * f;
+                // SelfAdjointEigenSolver reads the lower triangle
+                const double C[6] = {cov[0], cov[3], cov[6], cov[4], cov[7], cov[8]};
+                sym3_eig_asc(C, w, V);
+                // A covariance that is singular but for rounding (duplicated points, collinear points, an exactly flat patch): whether
+                // the voxel is kept (:337-341) hangs on the SIGN of that rounding, i.e. on the order the reference added the points up in
+                // -- input order (:233-237).  Such a voxel is summed again in exactly that order, in double, about the origin: the sums,
+                // and with them the decision, are then the reference's bit for bit.  (Up to 64 points: beyond that the voxel keeps the
+                // order-independent sums -- exact on a binary lattice, where the crowded flat voxels of a synthetic map come from.)
+                const bool shaky = !(fabs(w[0]) > 1e-9 * fabs(w[2])) || w[0] < 0 || w[1] < 0;
+                if (attempt != 0 || !shaky || n > 64) break;
+                uint32_t last = 0;      // original index + 1 of the point added last
+#pragma unroll
+                for (int r = 0; r < 3; ++r) sum[r] = 0.0;
+#pragma unroll
+                for (int e2 = 0; e2 < 9; ++e2) sxx[e2] = 0.0;
+                for (int k = 0; k < n; ++k) {
+                    uint32_t best = 0xffffffffu;
+                    float4 bp = g.pts[s];
+                    for (uint32_t j = s; j < e; ++j) {
+                        const float4 q = g.pts[j];
+                        const uint32_t id = __float_as_uint(q.w) + 1u;
+                        if (id > last && id < best) { best = id; bp = q; }
+                    }
+                    last = best;
+                    const double x[3] = {(double)bp.x, (double)bp.y, (double)bp.z};
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        sum[r] += x[r];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sxx[r * 3 + c] += x[r] * x[c];
+                    }
+                }
+            }
             bool ok = !(w[0] < 0 || w[1] < 0 || w[2] <= 0);            // :337-341
             if (ok) {
                 const double minev = eig_mult * w[2];                   // :345-356
@@ -943,6 +977,8 @@ hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[
     NdtCtl c;
     memset(&c, 0, sizeof c);
     ndt_opt::ctl_init(&c, T0, p, step_size, trans_eps, max_iters);
+    static const bool no_replay = getenv("PCR_NDT_NO_REPLAY") != nullptr;
+    c.replay_off = no_replay ? 1 : 0;
     NdtCtlArg a;
     memcpy(a.w, &c, sizeof c);
     hipLaunchKernelGGL(ndt_ctl_store_kernel, dim3(1), dim3(512), 0, s, d_ctl, a);

@@ -46,6 +46,9 @@ struct NdtCtl {
     NdtPose final_T;
     int32_t done, passes;
     uint32_t ticks[4];      // profiling: 100 MHz ticks spent in fold / controller step / write-back, summed over the passes
+    // ---- the point (score, grad) were last evaluated at: a request for the same sums at the same point is answered from here ----
+    double x_eval[6];
+    int32_t eval_valid, replayed, replay_off, pad1;      // replay_off: PCR_NDT_NO_REPLAY (A/B runs): every request becomes a pass
 };
 
 // what the device-resident loop reports to the host (host-mapped memory; `seq` is written last)
@@ -324,6 +327,8 @@ NDT_HD inline void ctl_init(NdtCtl* c, const NdtPose& T0, const double p0[6], do
     c->open_interval = 1; c->interval_converged = 0; c->it = 0; c->nr_it = 0; c->conv = 0; c->n_deriv = c->n_hess = 0; c->bail = 0;
     c->done = 0; c->passes = 0;
     for (int i = 0; i < 4; ++i) c->ticks[i] = 0;
+    for (int i = 0; i < 6; ++i) c->x_eval[i] = 0;
+    c->eval_valid = 0; c->replayed = 0; c->replay_off = 0; c->pad1 = 0;
 }
 
 // the pose and the angle tables of the next pass from the six sine/cosine pairs of x_t (trig_pair)
@@ -332,24 +337,11 @@ NDT_HD_FLAT void ctl_tables(NdtCtl* c, const double sc[12]) {
     angle_tables_from_trig(sc, &c->ang);
 }
 
-// `sums` = score, gradient[6], Hessian[36] of the pass that ctl->kind asked for.  Leaves the next request in *c (or done).
-// Returns true when the next pass evaluates at a NEW point x_t: the caller then owes ctl_tables() (the trigonometry is kept out
-// of this function so that the device can spread it over lanes).
-NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
+// One step of the loops with the sums of the last request in c->score / grad / hess: leaves the next request in *c (or done).
+// Returns true when that request is at a NEW point x_t.
+NDT_HD_FLAT bool ctl_advance(NdtCtl* c) {
     const double mu = 1.e-4, nu = 0.9;
     const int max_it = 10;
-    if (c->done) return false;
-    c->passes += 1;
-    // ---- take the sums in ----
-    if (c->kind == kNdtPassHessian) {
-        c->n_hess += 1;
-        for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
-    } else {
-        c->n_deriv += 1;
-        c->score = sums[0];
-        for (int i = 0; i < 6; ++i) c->grad[i] = sums[1 + i];
-        for (int i = 0; i < 36; ++i) c->hess[i] = c->kind == kNdtPassDerivH ? sums[7 + i] : 0.0;      // (computeDerivatives zeroes it either way, :183)
-    }
     bool line_search_over = false;
     if (c->phase == kNdtPhaseLsFirst || c->phase == kNdtPhaseLsLoop) {
         // computeStepLengthMT after updateDerivatives at x_t (:832-852 the first time, :880-926 inside the loop)
@@ -431,6 +423,44 @@ NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
         for (int i = 0; i < 6; ++i) c->x_t[i] = c->p[i] + c->dir[i] * c->a_t;
         c->kind = kNdtPassDerivH; c->phase = kNdtPhaseLsFirst;
         return true;
+    }
+}
+
+// `sums` = score, gradient[6], Hessian[36] of the pass that ctl->kind asked for.  Leaves the next request in *c (or done).
+// Returns true when the next pass evaluates at a point whose pose and tables are not in *c yet: the caller then owes ctl_tables()
+// (the trigonometry is kept out of this function so that the device can spread it over lanes).
+//
+// A request for score + gradient at the point they were last evaluated at is not passed on: the pass would return, bit for bit, the
+// sums it returned before (same pose, same tables, same fixed-order sums), so they are fed again on the spot.  That is not a corner
+// case -- pclomp clamps every trial step into [epsilon / 2, step_size] (ndt_omp_impl.hpp:821-823, 905-907), and once the search
+// wants a longer step than step_size every further trial is that same clamped step: with the reference's constants a More-Thuente
+// search that runs to its cap evaluates ONE point nine times over.  The reference recomputes it each time; n_deriv counts what the
+// reference evaluates, `replayed` how many of those were answered from here.
+NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
+    if (c->done) return false;
+    c->passes += 1;
+    // ---- take the sums in ----
+    if (c->kind == kNdtPassHessian) {
+        c->n_hess += 1;
+        for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
+    } else {
+        c->n_deriv += 1;
+        c->score = sums[0];
+        for (int i = 0; i < 6; ++i) c->grad[i] = sums[1 + i];
+        for (int i = 0; i < 36; ++i) c->hess[i] = c->kind == kNdtPassDerivH ? sums[7 + i] : 0.0;      // (computeDerivatives zeroes it either way, :183)
+        for (int i = 0; i < 6; ++i) c->x_eval[i] = c->x_t[i];
+        c->eval_valid = 1;
+    }
+    bool moved = false;
+    for (;;) {
+        if (ctl_advance(c)) moved = true;
+        if (c->done) return false;
+        bool same = c->kind == kNdtPassDeriv && c->eval_valid != 0 && c->replay_off == 0;
+        for (int i = 0; i < 6; ++i) same = same && c->x_t[i] == c->x_eval[i];
+        if (!same) return moved;
+        // (x_t == x_eval compares values: +0 / -0 would pass as equal and give the same pose; NaN never passes)
+        c->n_deriv += 1; c->replayed += 1;
+        for (int i = 0; i < 36; ++i) c->hess[i] = 0.0;
     }
 }
 

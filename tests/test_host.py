@@ -296,6 +296,7 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
     scan, T = synth.make_scan(world, 0, seed=77, beams=16, azimuths=256)
     dp = C.POINTER(C.c_double)
     prm = oracle.ndt_params()
+    replayed_total = 0
     for seed, tr, rd in ((1, 0.1, 0.5), (2, 0.3, 1.5), (3, 0.0, 0.0)):
         T0 = synth.perturb(T, seed, trans=tr, rot_deg=rd) if tr else T.copy()
         po, co, info = oracle.ndt_scan2map(scan, m, T0, prm)
@@ -320,6 +321,11 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
                 raise AssertionError("the optimiser did not finish")
             pose, conv, its, done = np.zeros(16), C.c_int(0), C.c_int(0), C.c_int(0)
             assert L.pcr_ndt_opt_result(o, pose.ctypes.data_as(dp), C.byref(conv), C.byref(its), C.byref(done)) == 0 and done.value == 1
+            ev, hs, rep = C.c_int(0), C.c_int(0), C.c_int(0)
+            assert L.pcr_ndt_opt_counts(o, C.byref(ev), C.byref(hs), C.byref(rep)) == 0
+            # what the reference evaluates = what was asked for + what the state machine answered itself (a clamped trial step repeated)
+            assert ev.value == n_deriv + rep.value and hs.value == n_hess
+            n_deriv, replayed_total = ev.value, replayed_total + rep.value
         finally:
             L.pcr_ndt_opt_destroy(o)
         assert bool(conv.value) == co, seed
@@ -327,6 +333,7 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
         # same decisions; the pose agrees to a few float ulps (the stand-alone derivative entry point of the oracle rebuilds the float
         # transform from p6 on its own, so the sums fed here are not bit for bit those of the oracle's inner loop)
         np.testing.assert_allclose(pose.reshape(4, 4).T, po, rtol=0, atol=5e-6)
+    assert replayed_total > 0      # (the clamped More-Thuente steps of these cases do repeat)
 
 
 def test_vgicp_optimiser_driven_by_the_oracles_sums_arrives_where_the_oracle_does():
