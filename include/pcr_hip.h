@@ -123,7 +123,12 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
 int pcr_invalidate_target(pcr_handle* h);
 
 /* PointCloudRegister::getFitnessScore (PointCloudRegister.hpp:34; VgicpRegister.cpp:42-45):
- * mean squared 1-NN distance of the last aligned source.  Negative when unavailable. */
+ * mean squared 1-NN distance of the last aligned source.  Negative when unavailable.
+ * As in the reference the score is not part of scan2Map: the handle keeps a copy of the last aligned scan and its final pose, and
+ * this call evaluates the score (once; later calls return the cached value) against the target the handle holds at that moment --
+ * what PCL's getFitnessScore() does with input_, final_transformation_ and the current target tree.  1.797e308 (DBL_MAX) when no
+ * point has a neighbour or no target is prepared, like PCL.  (A handle of a sharded target evaluates it with the alignment instead:
+ * every rank takes part in the sum.) */
 double pcr_fitness(pcr_handle* h);
 
 /* ---- introspection used by tests and bench.py ---- */

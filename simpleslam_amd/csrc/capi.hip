@@ -100,6 +100,13 @@ struct pcr_handle {
     bool vg_target_ready = false;
     int vg_outer = 0, vg_lin = 0, vg_err = 0;
     DeviceBuf vg_ctl;                    // two VgCtl: the device-resident LM loop's state, by launch parity
+    // getFitnessScore() is a call of its own in the reference (VgicpRegister.cpp:42-45: PCL evaluates it when asked, from the source it
+    // still holds): an unsharded alignment keeps a copy of the scan and the final pose, and pcr_fitness() evaluates the score on demand
+    DeviceBuf fit_src;
+    const float* fit_copied_from = nullptr;   // the scan fit_src holds (copied on the side stream by vgicp_source_enqueue)
+    size_t fit_n = 0, fit_stride = 0;
+    double fit_pose[16];
+    bool fit_pending = false;
     VgOut* vg_out_host = nullptr;        // host-mapped: its result and progress word
     VgOut* vg_out_dev = nullptr;
 
@@ -607,6 +614,13 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
     if (e == hipSuccess && (e = vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
                                                  h->src_cov6.as<double>(), h->side_stream)) != hipSuccess)
         h->err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
+    h->fit_copied_from = nullptr;
+    if (e == hipSuccess && !sharded(h) && n_src > 0) {      // the scan, kept for a later pcr_fitness() (off the critical path here)
+        const size_t bytes = n_src * stride_floats * sizeof(float);
+        if ((e = h->fit_src.reserve(bytes)) != hipSuccess || (e = hipMemcpyAsync(h->fit_src.p, d_src, bytes, hipMemcpyDeviceToDevice, h->side_stream)) != hipSuccess)
+            h->err = std::string("keeping the scan for the fitness score: ") + hipGetErrorString(e);
+        else h->fit_copied_from = d_src;
+    }
     if (e == hipSuccess && (e = hipEventRecord(h->ev_side_done, h->side_stream)) != hipSuccess) h->err = std::string("hipEventRecord: ") + hipGetErrorString(e);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->side_stream); return 1; }
     h->side_pending = true; h->side_src = d_src; h->side_n = n_src; h->side_stride = stride_floats;
@@ -694,7 +708,14 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     if (ensure_out32(h)) return 1;
     // source covariances over the source's own index (fast_gicp_impl.hpp:103-108): already in flight when this is a
     // scan2map call, computed here otherwise
+    h->fit_pending = false;
+    const bool fit_side = h->fit_copied_from == d_src && d_src != nullptr;      // (the side stream copied this very scan)
+    h->fit_copied_from = nullptr;
     if (vgicp_source_settle(h, d_src, n_src, stride_floats)) return 1;
+    if (!sharded(h) && n_src > 0 && !fit_side) {
+        H_TRY(h->fit_src.reserve(n_src * stride_floats * sizeof(float)));
+        H_TRY(hipMemcpyAsync(h->fit_src.p, d_src, n_src * stride_floats * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
     H_TRY(h->corr_slot.reserve((n_src + 1) * sizeof(uint32_t)));
     H_TRY(h->corr_M.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(h->corr_slot2.reserve((n_src + 1) * sizeof(uint32_t)));
@@ -802,7 +823,15 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     }
     for (int i = 0; i < 16; ++i) pose[i] = (double)(float)x0.m[i];     // final_transformation_ is a Matrix4f
     if (converged) *converged = conv ? 1 : 0;
-    // pcl::Registration::getFitnessScore() of the aligned source (VgicpRegister.cpp:42-45)
+    h->stats.iterations = h->vg_outer; h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
+    h->stats.kernel_launches = h->vg_lin + h->vg_err;
+    if (!shard) {      // pcl::Registration::getFitnessScore() is evaluated when asked for (pcr_fitness), as in the reference
+        for (int i = 0; i < 16; ++i) h->fit_pose[i] = pose[i];
+        h->fit_n = n_src; h->fit_stride = stride_floats; h->fit_pending = true;
+        h->fitness = 1.7976931348623157e308;
+        return 0;
+    }
+    // sharded: every rank takes part in the sum, so the score is evaluated here, with the call (VgicpRegister.cpp:42-45)
     h->seq += 1.0;
     FitTile ft;
     memset(&ft, 0, sizeof ft);
@@ -1226,7 +1255,7 @@ void pcr_destroy(pcr_handle* h) {
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
-    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release(); h->vg_ctl.release();
+    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release(); h->vg_ctl.release(); h->fit_src.release();
     if (h->vg_out_host) (void)hipHostFree(h->vg_out_host);
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
@@ -1399,6 +1428,21 @@ double pcr_fitness(pcr_handle* h) {
     // PointCloudRegister::getFitnessScore() returns 0 unless overridden (PointCloudRegister.hpp:34);
     // only VgicpRegister overrides it (VgicpRegister.cpp:42-45)
     if (h->method != kVgicp) return 0.0;
+    if (h->fit_pending) {
+        // mean squared distance of the aligned scan to its nearest target points, against the target the handle holds NOW (PCL does
+        // the same: input_ transformed by final_transformation_, searched in the current target tree)
+        h->fit_pending = false;
+        h->err.clear();
+        h->fitness = 1.7976931348623157e308;
+        if (h->vg_target_ready && h->fit_n > 0) {
+            if (set_device(h) || ensure_out32(h)) return -1.0;
+            h->seq += 1.0;
+            if (fitness_launch(h->grid, h->fit_src.as<float>(), h->fit_n, h->fit_stride, h->fit_pose, 1.7976931348623157e308, h->vg_partials.as<double>(),
+                               h->out32_dev, h->stream, h->seq, nullptr) != hipSuccess) { h->err = "fitness_launch failed"; return -1.0; }
+            if (wait_result(h, &h->out32_host[31], h->seq)) return -1.0;
+            h->fitness = h->out32_host[1] > 0 ? h->out32_host[0] / h->out32_host[1] : 1.7976931348623157e308;
+        }
+    }
     return h->fitness;
 }
 
