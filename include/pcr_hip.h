@@ -242,12 +242,8 @@ int pcr_ndt_opt_request(const pcr_ndt_opt* o, int* kind, double p6[6], double po
 int pcr_ndt_opt_feed(pcr_ndt_opt* o, const double sums[43]);
 int pcr_ndt_opt_result(const pcr_ndt_opt* o, double pose16[16], int* converged, int* iterations, int* done);
 /* evaluations = computeDerivatives calls of the reference's loop so far, hessians = its computeHessian calls, replayed = how many of the
- * evaluations were requests for score + gradient at the point they had just been evaluated at, answered without asking, extra = requests
- * (kind 0) that only fetched the Hessian of an evaluation made without it (ndt_opt.h: the first evaluation of a line search goes
- * without its Hessian when the previous search iterated).  requests of kind 0/1 = evaluations - replayed + extra. */
-int pcr_ndt_opt_counts(const pcr_ndt_opt* o, int* evaluations, int* hessians, int* replayed, int* extra);
-/* hint for the FIRST line search (what pcr_scan2map carries over from the handle's previous call): nonzero = expect it to iterate */
-int pcr_ndt_opt_set_hint(pcr_ndt_opt* o, int previous_search_iterated);
+ * evaluations were requests for score + gradient at the point they had just been evaluated at, answered without asking (ndt_opt.h) */
+int pcr_ndt_opt_counts(const pcr_ndt_opt* o, int* evaluations, int* hessians, int* replayed);
 
 /* The VGICP optimiser on its own (host only, no GPU): fast_gicp's LsqRegistration::computeTransformation + step_lm
  * (lsq_registration_impl.hpp:53-79, 125-171) as the state machine that pcr_scan2map runs on the device (csrc/vgicp_opt.h), driven

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices", "pcr_map_generation", "pcr_scan2map_submap",
-    "pcr_ndt_opt_create", "pcr_ndt_opt_destroy", "pcr_ndt_opt_request", "pcr_ndt_opt_feed", "pcr_ndt_opt_result", "pcr_ndt_opt_counts", "pcr_ndt_opt_set_hint",
+    "pcr_ndt_opt_create", "pcr_ndt_opt_destroy", "pcr_ndt_opt_request", "pcr_ndt_opt_feed", "pcr_ndt_opt_result", "pcr_ndt_opt_counts",
     "pcr_vgicp_opt_create", "pcr_vgicp_opt_destroy", "pcr_vgicp_opt_request", "pcr_vgicp_opt_feed", "pcr_vgicp_opt_result",
     "pcr_sc_default_params", "pcr_sc_create", "pcr_sc_destroy", "pcr_sc_last_error", "pcr_sc_size", "pcr_sc_add", "pcr_sc_descriptor", "pcr_sc_distance",
     "pcr_sc_query",
@@ -122,8 +122,7 @@ def load_library():
     L.pcr_ndt_opt_request.argtypes = [vp, ip, dp, dp]
     L.pcr_ndt_opt_feed.argtypes = [vp, dp]
     L.pcr_ndt_opt_result.argtypes = [vp, dp, ip, ip, ip]
-    L.pcr_ndt_opt_counts.argtypes = [vp, ip, ip, ip, ip]
-    L.pcr_ndt_opt_set_hint.argtypes = [vp, C.c_int]
+    L.pcr_ndt_opt_counts.argtypes = [vp, ip, ip, ip]
     L.pcr_vgicp_opt_create.restype = vp
     L.pcr_vgicp_opt_create.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     L.pcr_vgicp_opt_destroy.restype = None

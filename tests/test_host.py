@@ -297,16 +297,12 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
     dp = C.POINTER(C.c_double)
     prm = oracle.ndt_params()
     replayed_total = 0
-    extra_total = 0
-    for seed, tr, rd, hint in ((1, 0.1, 0.5, 0), (2, 0.3, 1.5, 0), (3, 0.0, 0.0, 0), (1, 0.1, 0.5, 1), (2, 0.3, 1.5, 1), (3, 0.0, 0.0, 1), (4, 0.02, 0.1, 1)):
+    for seed, tr, rd in ((1, 0.1, 0.5), (2, 0.3, 1.5), (3, 0.0, 0.0)):
         T0 = synth.perturb(T, seed, trans=tr, rot_deg=rd) if tr else T.copy()
         po, co, info = oracle.ndt_scan2map(scan, m, T0, prm)
         guess = np.ascontiguousarray(T0.T).reshape(16).copy()
         o = L.pcr_ndt_opt_create(guess.ctypes.data_as(dp), float(prm.step_size), float(prm.trans_eps), int(prm.max_iters))
         assert o
-        # hint = 1: as if the handle's previous call had ended with a line search that iterated -- the first evaluation of every search
-        # then goes without its Hessian, and is fetched by one more request when the search stops at once after all
-        assert L.pcr_ndt_opt_set_hint(o, hint) == 0
         try:
             n_deriv = n_hess = 0
             for _ in range(600):
@@ -325,12 +321,11 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
                 raise AssertionError("the optimiser did not finish")
             pose, conv, its, done = np.zeros(16), C.c_int(0), C.c_int(0), C.c_int(0)
             assert L.pcr_ndt_opt_result(o, pose.ctypes.data_as(dp), C.byref(conv), C.byref(its), C.byref(done)) == 0 and done.value == 1
-            ev, hs, rep, ext = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
-            assert L.pcr_ndt_opt_counts(o, C.byref(ev), C.byref(hs), C.byref(rep), C.byref(ext)) == 0
+            ev, hs, rep = C.c_int(0), C.c_int(0), C.c_int(0)
+            assert L.pcr_ndt_opt_counts(o, C.byref(ev), C.byref(hs), C.byref(rep)) == 0
             # what the reference evaluates = what was asked for + what the state machine answered itself (a clamped trial step repeated)
-            # - the requests that only fetched a Hessian left out on speculation
-            assert ev.value == n_deriv + rep.value - ext.value and hs.value == n_hess
-            n_deriv, replayed_total, extra_total = ev.value, replayed_total + rep.value, extra_total + ext.value
+            assert ev.value == n_deriv + rep.value and hs.value == n_hess
+            n_deriv, replayed_total = ev.value, replayed_total + rep.value
         finally:
             L.pcr_ndt_opt_destroy(o)
         assert bool(conv.value) == co, seed
@@ -390,57 +385,3 @@ def test_vgicp_optimiser_driven_by_the_oracles_sums_arrives_where_the_oracle_doe
         assert (outer.value, n_err) == (info["outer"], info["error_evals"]), (seed, outer.value, n_err, info)
         got = pose.reshape(4, 4).T.astype(np.float32).astype(np.float64)      # final_transformation_ is a Matrix4f
         np.testing.assert_array_equal(got, po)
-
-
-def test_ndt_speculation_changes_passes_not_results():
-    """The first evaluation of a line search asks for the Hessian too (ndt_omp_impl.hpp:832) and the reference throws it away whenever
-    the search goes on to iterate (:928-929).  The state machine leaves it out when the previous search iterated and fetches it with
-    one more request (same point) if this search stops at once after all.  Whatever the hint: the same requests' worth of evaluations
-    as the oracle's loop, the same iterations, and bit for bit the same pose as without speculation."""
-    import ctypes as C
-    from simpleslam_amd import synth
-    from simpleslam_amd.pcr import load_library
-    L = load_library()
-    world, m = synth.make_map(60_000, seed=77, spacing=0.2)
-    scan, T = synth.make_scan(world, 0, seed=77, beams=16, azimuths=256)
-    dp = C.POINTER(C.c_double)
-    fetched = 0
-    for eps, step, seed, tr, rd in ((0.01, 0.1, 1, 0.1, 0.5), (0.001, 0.5, 1, 0.1, 0.5), (0.01, 0.1, 3, 0.0, 0.0), (0.1, 0.1, 4, 0.02, 0.1)):
-        prm = oracle.ndt_params()
-        prm.trans_eps, prm.step_size = eps, step
-        T0 = synth.perturb(T, seed, trans=tr, rot_deg=rd) if tr else T.copy()
-        _po, co, info = oracle.ndt_scan2map(scan, m, T0, prm)
-        guess = np.ascontiguousarray(T0.T).reshape(16).copy()
-        poses = {}
-        for hint in (0, 1):
-            o = L.pcr_ndt_opt_create(guess.ctypes.data_as(dp), float(prm.step_size), float(prm.trans_eps), int(prm.max_iters))
-            assert o and L.pcr_ndt_opt_set_hint(o, hint) == 0
-            try:
-                kinds = []
-                for _ in range(2000):
-                    kind, p6 = C.c_int(-1), np.zeros(6)
-                    assert L.pcr_ndt_opt_request(o, C.byref(kind), p6.ctypes.data_as(dp), None) == 0
-                    if kind.value == 3:
-                        break
-                    kinds.append(kind.value)
-                    d = oracle.ndt_derivatives(scan, m, p6, prm, double_hessian=(kind.value == 2))
-                    sums = np.zeros(43)
-                    sums[0] = d["score"]; sums[1:7] = d["grad"]
-                    sums[7:] = (d["hess_d"] if kind.value == 2 else d["hess"]).reshape(36)
-                    assert L.pcr_ndt_opt_feed(o, sums.ctypes.data_as(dp)) == 0
-                else:
-                    raise AssertionError("the optimiser did not finish")
-                pose, conv, its, done = np.zeros(16), C.c_int(0), C.c_int(0), C.c_int(0)
-                assert L.pcr_ndt_opt_result(o, pose.ctypes.data_as(dp), C.byref(conv), C.byref(its), C.byref(done)) == 0 and done.value == 1
-                ev, hs, rep, ext = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
-                assert L.pcr_ndt_opt_counts(o, C.byref(ev), C.byref(hs), C.byref(rep), C.byref(ext)) == 0
-            finally:
-                L.pcr_ndt_opt_destroy(o)
-            assert bool(conv.value) == co and its.value == info["iterations"]
-            assert (ev.value, hs.value) == (info["derivative_passes"], info["hessian_passes"])
-            assert sum(k != 2 for k in kinds) == ev.value - rep.value + ext.value
-            poses[hint] = pose.copy()
-            if hint:
-                fetched += ext.value
-        np.testing.assert_array_equal(poses[0], poses[1])
-    assert fetched > 0      # (some searches of these cases do stop at their first evaluation)
