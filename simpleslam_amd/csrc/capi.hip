@@ -535,11 +535,17 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
     return fail(h, "index could not be sized");
 }
 
-// The coarse levels pay for clouds with a long sparse tail -- raw or lightly filtered lidar scans, whose far points need
-// dozens of rings on the fine grid -- and cost a little (two more index builds, de-duplication) on a voxel-filtered map of
+// The coarse level pays for clouds with a long sparse tail -- raw or lightly filtered lidar scans, whose far points need
+// dozens of rings on the fine grid -- and costs a little (another index build, de-duplication) on a voxel-filtered map of
 // uniform density: measured 0.74 ms on one level vs 0.94 ms on three for the 1 M-point map, 7.7 ms vs 0.36 ms for the
-// 65 k-point scan.  Scan-sized clouds get three levels, map-sized ones one.
-int cov_levels(size_t n) { return n <= 300000 ? 3 : 1; }
+// 65 k-point scan.  Scan-sized clouds get a second level, map-sized ones stay on one.  Two levels six cells apart (0.5 m and 3 m)
+// beat the three levels four apart (0.5 / 2 / 8 m) this started with: the 8 m grid of a scan has a handful of cells holding most
+// of its points -- three blocks sorted the whole scan, 120 us -- and each level is an index build on the side stream; A/B of the
+// whole scan2map on one box: 3 x 4: 0.906 ms, 2 x 4: 0.917, 2 x 5: 0.890, 2 x 6: 0.875, 2 x 7: 0.900, 2 x 8: 0.880, 3 x 6: 0.975, 2 x 12: 1.25.
+// (PCR_COV_LEVELS / PCR_COV_RATIO override for such runs.)
+static int cov_levels_small() { static const int v = getenv("PCR_COV_LEVELS") ? atoi(getenv("PCR_COV_LEVELS")) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }
+static double cov_ratio() { static const double v = getenv("PCR_COV_RATIO") ? atof(getenv("PCR_COV_RATIO")) : 6.0; return v; }
+int cov_levels(size_t n) { return n <= 300000 ? cov_levels_small() : 1; }
 
 int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats);
 int vgicp_side_init(pcr_handle* h) {
@@ -556,7 +562,7 @@ int vgicp_side_init(pcr_handle* h) {
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
                       double shift0, GridHeader* hdr0_out, bool may_cut = false) {
     GridIndex* lv[3] = {&g, &l1, &l2};
-    const double cells[3] = {cell, 4.0 * cell, 16.0 * cell};
+    const double cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n);
     bool todo[3] = {true, levels > 1, levels > 2};
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -601,7 +607,7 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
     H_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
     H_TRY(hipStreamWaitEvent(h->side_stream, h->ev_side_in, 0));
     GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
-    const double cell = h->prm.vgicp_resolution, cells[3] = {cell, 4.0 * cell, 16.0 * cell};
+    const double cell = h->prm.vgicp_resolution, cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n_src);
     // from here on kernels reading the caller's d_src may be queued on the side stream: an error must not return before they
     // have drained (the caller is free to release d_src as soon as the call has failed)

@@ -62,10 +62,10 @@ __device__ __forceinline__ void ring_scan_run(const float4* __restrict__ pts, ui
     }
 }
 
-// One cloud indexed at up to three cell sizes (cell, 4 cell, 16 cell).  A lidar scan spans four orders of
-// magnitude of density; on a single grid the K-neighbourhood of a far point is dozens of rings wide and one such
-// lane holds its whole wave.  Rings 1 and 2 of each level guarantee radii of 1, 2, 4, 8, 16, 32 cells; only
-// the last level keeps growing.
+// One cloud indexed at up to three cell sizes (capi.hip: cov_levels -- a scan gets two, cell and 6 cell).  A lidar scan spans four
+// orders of magnitude of density; on a single grid the K-neighbourhood of a far point is dozens of rings wide and one such
+// lane holds its whole wave.  Rings 1 and 2 of each level guarantee radii of one and two of its cells; only the last level
+// keeps growing.
 struct GridLevels {
     const GridHeader* hdr[3];
     const float4* pts[3];
