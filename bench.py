@@ -126,7 +126,7 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         ref = lambda s, m, T: oracle.vgicp_scan2map(s, m, T, oracle.vgicp_params(resolution=0.5, threads=cores))[0]
         # one-off per target >= N_m (16 + 20*16 + 128) for the covariances + N_m (16 + 128) for the voxel map
         alg = lambda n_s, n_m: 608 * n_m
-        what = "target preparation (3-level index + covariance + voxel kernels), 608 B per map point"
+        what = "target preparation (index levels + covariance + voxel kernels), 608 B per map point"
         workload = "pcr=vgicp, 0.5 m voxels, 65536-pt scan vs 1000000-pt submap, target rebuilt per call, inputs in HBM"
     else:
         cfg, n_map, kw, mk = 5, 5_000_000, dict(beams=128, azimuths=1024), dict(spacing=0.22)
