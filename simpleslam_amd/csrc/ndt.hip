@@ -144,22 +144,54 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
             const int cx = (int)(t % (uint64_t)h.dims[0]), cy = (int)((t / (uint64_t)h.dims[0]) % (uint64_t)h.dims[1]),
                       cz = (int)(t / ((uint64_t)h.dims[0] * (uint64_t)h.dims[1]));
             const double ox = (h.org[0] + cx + 0.5) * h.cell, oy = (h.org[1] + cy + 0.5) * h.cell, oz = (h.org[2] + cz + 0.5) * h.cell;
-            long long s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
-            // four points per step, their loads issued together (one dependent load per iteration left the lanes of crowded cells
-            // waiting a memory round trip per point; the sums are integers, so the grouping does not change a bit)
-            for (uint32_t j = s; j < e; j += 4) {
-                float4 q[4];
+            // Order-independent exact sums: every term is rounded to an integer multiple of 2^-44 (2^-40 for the products) first.
+            // The integers are added up as DOUBLES while their sum provably stays below 2^53 (|dx| <= cell / 2, so n * cell <= 512 and
+            // n * cell^2 <= 16384 do it with a factor of two to spare): v_rndne_f64 + v_add_f64 per term.  The same integers in
+            // int64 cost a dozen instructions per term for the conversion alone (there is no f64 -> i64 instruction), and this loop
+            // was a third of the kernel's instructions; voxels too crowded or too large for the bound take that path.
+            double c1[3], c2s[6];
+            if ((double)n * h.cell <= 512.0 && (double)n * h.cell * h.cell <= 16384.0) {
+                double d1[3] = {0, 0, 0}, d2[6] = {0, 0, 0, 0, 0, 0};
+                // four points per step, their loads issued together (one dependent load per iteration left the lanes of crowded cells
+                // waiting a memory round trip per point; the sums are integers, so the grouping does not change a bit)
+                for (uint32_t j = s; j < e; j += 4) {
+                    float4 q[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = g.pts[j + u < e ? j + u : j];
+                    for (int u = 0; u < 4; ++u) q[u] = g.pts[j + u < e ? j + u : j];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (j + u < e) {
-                        const double dx = (double)q[u].x - ox, dy = (double)q[u].y - oy, dz = (double)q[u].z - oz;
-                        s1[0] += llrint(dx * kFix1); s1[1] += llrint(dy * kFix1); s1[2] += llrint(dz * kFix1);
-                        s2[0] += llrint(dx * dx * kFix2); s2[1] += llrint(dx * dy * kFix2); s2[2] += llrint(dx * dz * kFix2);
-                        s2[3] += llrint(dy * dy * kFix2); s2[4] += llrint(dy * dz * kFix2); s2[5] += llrint(dz * dz * kFix2);
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < e) {
+                            const double dx = (double)q[u].x - ox, dy = (double)q[u].y - oy, dz = (double)q[u].z - oz;
+                            d1[0] += rint(dx * kFix1); d1[1] += rint(dy * kFix1); d1[2] += rint(dz * kFix1);
+                            d2[0] += rint(dx * dx * kFix2); d2[1] += rint(dx * dy * kFix2); d2[2] += rint(dx * dz * kFix2);
+                            d2[3] += rint(dy * dy * kFix2); d2[4] += rint(dy * dz * kFix2); d2[5] += rint(dz * dz * kFix2);
+                        }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c1[k] = d1[k] / kFix1;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c2s[k] = d2[k] / kFix2;
+            } else {
+                long long s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+                for (uint32_t j = s; j < e; j += 4) {
+                    float4 q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = g.pts[j + u < e ? j + u : j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < e) {
+                            const double dx = (double)q[u].x - ox, dy = (double)q[u].y - oy, dz = (double)q[u].z - oz;
+                            s1[0] += llrint(dx * kFix1); s1[1] += llrint(dy * kFix1); s1[2] += llrint(dz * kFix1);
+                            s2[0] += llrint(dx * dx * kFix2); s2[1] += llrint(dx * dy * kFix2); s2[2] += llrint(dx * dz * kFix2);
+                            s2[3] += llrint(dy * dy * kFix2); s2[4] += llrint(dy * dz * kFix2); s2[5] += llrint(dz * dz * kFix2);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c1[k] = (double)s1[k] / kFix1;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c2s[k] = (double)s2[k] / kFix2;
             }
             // The reference accumulates sum(x) and sum(x x^T) about the ORIGIN and then evaluates
             //   cov = (sum_xx - 2 (sum_x mean^T)) / n + mean mean^T,  cov *= (n-1)/n      (:329-330, all nine entries)
@@ -167,10 +199,7 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
             // Same expression here, from the order-independent centred sums moved back to the origin: identical to the
             // reference whenever its own sums are exact (coordinates on a binary lattice), as close as its noise otherwise.
             const double dn = (double)n, o[3] = {ox, oy, oz};
-            const double c1[3] = {(double)s1[0] / kFix1, (double)s1[1] / kFix1, (double)s1[2] / kFix1};
-            const double c2[3][3] = {{(double)s2[0] / kFix2, (double)s2[1] / kFix2, (double)s2[2] / kFix2},
-                                     {(double)s2[1] / kFix2, (double)s2[3] / kFix2, (double)s2[4] / kFix2},
-                                     {(double)s2[2] / kFix2, (double)s2[4] / kFix2, (double)s2[5] / kFix2}};
+            const double c2[3][3] = {{c2s[0], c2s[1], c2s[2]}, {c2s[1], c2s[3], c2s[4]}, {c2s[2], c2s[4], c2s[5]}};
             double sum[3], sxx[9], mean[3], cov[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {

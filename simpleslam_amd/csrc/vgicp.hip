@@ -332,20 +332,37 @@ __global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const doub
         if (g.cell_start[key] != j) continue;                 // not the first point of its voxel
         const uint32_t e = g.cell_start[key + 1];
         const double ox = (c[0] + h.shift) * h.cell, oy = (c[1] + h.shift) * h.cell, oz = (c[2] + h.shift) * h.cell;   // lower corner
-        long long sm[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t i = j; i < e; ++i) {
-            const float4 p = g.pts[i];
-            sm[0] += llrint(((double)p.x - ox) * kFix); sm[1] += llrint(((double)p.y - oy) * kFix); sm[2] += llrint(((double)p.z - oz) * kFix);
-            const double* cc = cov6 + (size_t)__float_as_uint(p.w) * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) sc[k] += llrint(cc[k] * kFix);
-        }
         const uint32_t cnt = e - j;
         VgicpVoxel v;
         const double inv = 1.0 / (double)cnt;
-        v.mean[0] = ox + (double)sm[0] / kFix * inv; v.mean[1] = oy + (double)sm[1] / kFix * inv; v.mean[2] = oz + (double)sm[2] / kFix * inv;
+        // Every term is rounded to a multiple of 2^-44 first, so the sums are exact and independent of the order.  While they provably
+        // stay below 2^53 (offsets < cell, covariance entries <= 1 in magnitude after the regularisation) the integers are added
+        // up as doubles -- one v_rndne_f64 and one v_add_f64 per term, where the f64 -> i64 conversion alone costs a dozen instructions.
+        if ((double)cnt * (h.cell > 1.0 ? h.cell : 1.0) <= 256.0) {
+            double dm[3] = {0, 0, 0}, dc[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t i = j; i < e; ++i) {
+                const float4 p = g.pts[i];
+                dm[0] += rint(((double)p.x - ox) * kFix); dm[1] += rint(((double)p.y - oy) * kFix); dm[2] += rint(((double)p.z - oz) * kFix);
+                const double* cc = cov6 + (size_t)__float_as_uint(p.w) * 6;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v.cov[k] = (double)sc[k] / kFix * inv;
+                for (int k = 0; k < 6; ++k) dc[k] += rint(cc[k] * kFix);
+            }
+            v.mean[0] = ox + dm[0] / kFix * inv; v.mean[1] = oy + dm[1] / kFix * inv; v.mean[2] = oz + dm[2] / kFix * inv;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v.cov[k] = dc[k] / kFix * inv;
+        } else {
+            long long sm[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t i = j; i < e; ++i) {
+                const float4 p = g.pts[i];
+                sm[0] += llrint(((double)p.x - ox) * kFix); sm[1] += llrint(((double)p.y - oy) * kFix); sm[2] += llrint(((double)p.z - oz) * kFix);
+                const double* cc = cov6 + (size_t)__float_as_uint(p.w) * 6;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sc[k] += llrint(cc[k] * kFix);
+            }
+            v.mean[0] = ox + (double)sm[0] / kFix * inv; v.mean[1] = oy + (double)sm[1] / kFix * inv; v.mean[2] = oz + (double)sm[2] / kFix * inv;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v.cov[k] = (double)sc[k] / kFix * inv;
+        }
         v.w = sqrt((double)cnt);   // fast_vgicp_impl.hpp:149
         v.n = cnt; v.pad = 0;
         vox[j] = v;
