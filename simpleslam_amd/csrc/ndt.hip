@@ -141,8 +141,9 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
         const int n = (int)(e - s);
         uint32_t slot = 0;
         {
-            const int cx = (int)(t % (uint64_t)h.dims[0]), cy = (int)((t / (uint64_t)h.dims[0]) % (uint64_t)h.dims[1]),
-                      cz = (int)(t / ((uint64_t)h.dims[0] * (uint64_t)h.dims[1]));
+            // (32-bit: the list holds 32-bit cell numbers, and a 64-bit division is a hundred instructions of this instruction-bound kernel)
+            const uint32_t t32 = (uint32_t)t, d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = t32 / d0;
+            const int cx = (int)(t32 - row * d0), cz = (int)(row / d1), cy = (int)(row - (uint32_t)cz * d1);
             const double ox = (h.org[0] + cx + 0.5) * h.cell, oy = (h.org[1] + cy + 0.5) * h.cell, oz = (h.org[2] + cz + 0.5) * h.cell;
             // Order-independent exact sums: every term is rounded to an integer multiple of 2^-44 (2^-40 for the products) first.
             // The integers are added up as DOUBLES while their sum provably stays below 2^53 (|dx| <= cell / 2, so n * cell <= 512 and
