@@ -68,15 +68,18 @@ typedef struct pcr_params {
 
     int32_t record_trace;      /* 1: keep per-iteration normal equations for pcr_get_trace */
     /* reserved[]: all zero by default.  Development switches of the LOAM path (results are unchanged except where noted):
-     *   [0] ablation mask for profiling (only in a -DPCR_ABLATION build; results become meaningless)   [1] unused
+     *   [0] ablation mask for profiling (only in a -DPCR_ABLATION build; results become meaningless)
+     *   [1] = 1: NDT: every request of the line search becomes an evaluation pass, also one at the point just evaluated (what the
+     *            reference does; by default such a request is answered from the sums already held -- same numbers, see csrc/ndt_opt.h)
      *   [2] = 1: disable the temporal-coherence neighbour cache          [3] = 1: record the in-kernel timeline (pcr_get_timeline)
      *   [4] = 1: two-waves-per-SIMD variant of the iterate kernel -- ~3 % slower for one handle, ~25 % more scans/s when
      *            several handles register scans concurrently on one GPU (their blocks can then share the CUs)
      *   [5] != 0: first margin, in millimetres, of the region a LOAM target too sparse for the dense index is cut to around the
      *            scan (default 10 m; it grows whenever a query reaches a cut face -- a test hook for that path: a negative value
      *            cuts into the scan's own box, so that the first attempts must be widened)
-     *   [6] = 1: NDT: drive the optimiser from the host (one round trip per evaluation pass) instead of on the device; the
-     *            path sharded handles always take.  Same state machine (csrc/ndt_opt.h), same result to rounding. */
+     *   [6] = 1: NDT, VGICP: drive the optimiser from the host (one round trip per evaluation pass) instead of on the device; the
+     *            path handles sharded over a host-supplied collective always take.  Same state machines (csrc/ndt_opt.h,
+     *            csrc/vgicp_opt.h), same result to rounding. */
     int32_t reserved[7];
 } pcr_params;
 
@@ -89,7 +92,9 @@ typedef struct pcr_stats {
     int32_t kernel_launches;/* launches summed in kernel_ms */
     int32_t iterations;     /* linearisations performed */
     int64_t n_src, n_dst;
-    int32_t attempts;       /* LOAM: passes over the iteration loop (> 1: the cell table grew, or a cut index was widened) */
+    int32_t attempts;       /* LOAM: passes over the iteration loop (> 1: the cell table grew, or a cut index was widened);
+                             * NDT: evaluation passes the device loop launched -- fewer than kernel_launches (= the evaluations the
+                             * reference makes) when repeated line-search evaluations were answered without a pass */
     int32_t target_builds;  /* pcr_scan2map_submap: times this handle has (re)built its target structures (one per sub-map generation) */
 } pcr_stats;
 

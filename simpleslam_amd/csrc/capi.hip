@@ -1000,7 +1000,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         H_TRY(h->nd_sums.reserve(64 * sizeof(double)));
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream));
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.reserved[1]));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4, kBatch = 6;
         const volatile double* f_batch = &out->batch;
         for (int batch = 1, enq = 0;; ++batch) {
@@ -1031,7 +1031,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         NdtOut* out = h->nd_out_host;
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream));
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.reserved[1]));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 5;        // an iteration takes at most 1 + 10 + 1 passes; one launch more finishes
         int enq = 0;
         const int first = 3;      // (the host enqueues a pass in a quarter of the time the device needs for one: it only has to stay two ahead)
@@ -1079,7 +1079,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     if (!on_device && !sharded_done) {
         NdtCtl c;
         ctl_init(&c, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters);
-        c.replay_off = getenv("PCR_NDT_NO_REPLAY") ? 1 : 0;
+        c.replay_off = (getenv("PCR_NDT_NO_REPLAY") || h->prm.reserved[1]) ? 1 : 0;
         double sums[43];
         while (!c.done) {
             if (n_src == 0) memset(sums, 0, sizeof sums);        // an empty scan: computeDerivatives sums nothing
@@ -1095,6 +1095,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     if (converged) *converged = conv ? 1 : 0;
     h->nd_iters = nr_it; h->nd_score = score;
     h->stats.iterations = nr_it; h->stats.kernel_launches = h->nd_deriv + h->nd_hess;
+    h->stats.attempts = on_device ? h->nd_last_passes : 0;      // (what the device loop actually launched; 0: not that loop)
     h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
     return 0;
 }

@@ -1002,13 +1002,13 @@ hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtA
     return hipGetLastError();
 }
 
-hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s) {
+hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay_arg) {
     static_assert(sizeof(NdtCtl) % 4 == 0, "NdtCtl is copied word by word");
     NdtCtl c;
     memset(&c, 0, sizeof c);
     ndt_opt::ctl_init(&c, T0, p, step_size, trans_eps, max_iters);
     static const bool no_replay = getenv("PCR_NDT_NO_REPLAY") != nullptr;
-    c.replay_off = no_replay ? 1 : 0;
+    c.replay_off = (no_replay || no_replay_arg) ? 1 : 0;
     NdtCtlArg a;
     memcpy(a.w, &c, sizeof c);
     hipLaunchKernelGGL(ndt_ctl_store_kernel, dim3(1), dim3(512), 0, s, d_ctl, a);

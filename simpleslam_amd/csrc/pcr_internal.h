@@ -265,7 +265,7 @@ hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngle
 // device-resident optimiser (ndt_opt.h): controller state in HBM, result in host-mapped memory
 struct NdtCtl;
 struct NdtOut;
-hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s);
+hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay = 0);
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq);
 hipError_t ndt_launch_pass_pro(const NdtArgs& a, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index);
 hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums48, hipStream_t s);

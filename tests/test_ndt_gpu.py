@@ -222,3 +222,26 @@ def test_rank_deficient_voxels_follow_the_references_summation_order(gpu):
         assert abs(g["score"] - o["score"]) <= 1e-9 * abs(o["score"]), (k, g["score"], o["score"])
         np.testing.assert_allclose(g["grad"], o["grad"], rtol=1e-7, atol=1e-7 * np.abs(o["grad"]).max())
         np.testing.assert_allclose(g["hess_d"], o["hess_d"], rtol=1e-7, atol=1e-7 * np.abs(o["hess_d"]).max())
+
+
+def test_replayed_line_search_evaluations_change_nothing_but_the_number_of_passes(gpu, nd_world):
+    """pclomp clamps every trial step of the More-Thuente search into [epsilon / 2, step_size]; a search that wants a longer step than
+    step_size evaluates that one clamped step again and again -- the same point, hence (fixed-order sums) the same numbers.  By default the
+    state machine answers such a request from the sums it holds; pcr_params.reserved[1] = 1 makes every request a pass, as the reference
+    does.  Same flag, iterations and evaluation count, bit for bit the same pose -- and fewer passes."""
+    from simpleslam_amd.pcr import default_params
+    w = nd_world
+    p_all = default_params()
+    p_all.reserved[1] = 1
+    fast, slow = NdtRegister(), NdtRegister(params=p_all)
+    saved = 0
+    for seed, tr, rd in ((51, 0.1, 0.5), (52, 0.3, 1.5), (53, 0.05, 0.2), (54, 0.0, 0.0)):
+        T0 = synth.perturb(w["truth"], seed, trans=tr, rot_deg=rd) if tr else w["truth"].copy()
+        pf, ps = T0.copy(), T0.copy()
+        assert fast.scan2Map(w["scan"], w["map"], pf) == slow.scan2Map(w["scan"], w["map"], ps)
+        sf, ss = fast.stats(), slow.stats()
+        assert (sf["iterations"], sf["kernel_launches"]) == (ss["iterations"], ss["kernel_launches"]), (seed, sf, ss)
+        np.testing.assert_array_equal(pf, ps)
+        assert sf["attempts"] <= ss["attempts"] and ss["attempts"] == ss["kernel_launches"], (seed, sf, ss)
+        saved += ss["attempts"] - sf["attempts"]
+    assert saved > 0
