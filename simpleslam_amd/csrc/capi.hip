@@ -93,6 +93,8 @@ struct pcr_handle {
     bool side_pending = false;       // source work of (side_src, side_n, side_stride) is in flight on side_stream
     const float* side_src = nullptr; size_t side_n = 0, side_stride = 0;
     GridHeader cov_hdr0;             // header of the fine level of the last settle_cov_levels (density estimate)
+    double cov_scale_hint = 0.0;     // cell scale of the last map-sized target's covariance grid: built ahead of the density it is derived from
+    bool cov_l1_ahead = false;       // ... and whether that build is the one in h->cov_l1 now
     DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, corr_slot2, corr_M2, vg_partials;
     double seq = 0.0;                    // completion numbers of the host-mapped result blocks below
     double* out32_host = nullptr;        // host-mapped: 32 doubles written by sum_partials_kernel
@@ -560,7 +562,7 @@ int vgicp_side_init(pcr_handle* h) {
 
 // the fine index plus the coarse ones of the covariance search, settled with one round trip
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
-                      double shift0, GridHeader* hdr0_out, bool may_cut = false) {
+                      double shift0, GridHeader* hdr0_out, bool may_cut = false, double ahead_cell = 0.0, bool* ahead_ok = nullptr) {
     GridIndex* lv[3] = {&g, &l1, &l2};
     const double cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n);
@@ -573,7 +575,17 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
             if (l == 0 && hdr0_out) H_TRY(lv[l]->enqueue_density(h->stream));
             H_TRY(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
+        // (a one-level target's covariance grid at last call's cell size, enqueued behind the fine level so that one round trip
+        //  settles both; whether that size still suits the density is the caller's check)
+        GridHeader hdr_ahead;
+        const bool ahead = ahead_cell > 0.0 && levels == 1 && attempt == 0 && !(h->clamp.use && may_cut);
+        if (ahead) {
+            if (l1.build(d_pts, n, stride_floats, ahead_cell, h->stream, &h->err, 0.0, 0, nullptr) != hipSuccess) return 1;
+            H_TRY(hipMemcpyAsync(&hdr_ahead, l1.header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
+        }
         H_TRY(hipStreamSynchronize(h->stream));
+        if (ahead_ok) *ahead_ok = false;
+        if (ahead && !hdr_ahead.overflow) { l1.note_cells(hdr_ahead.n_cells); if (ahead_ok) *ahead_ok = true; }
         bool again = false;
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
@@ -666,7 +678,11 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     h->clamp.use = 0;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats;
     // (unsharded: a cloud too spread out for dense tables is cut to its bulk, settle_cov_levels; a rank of a sharded call refuses it)
-    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h))) return 1;
+    static const bool no_ahead = getenv("PCR_COV_NO_AHEAD") != nullptr;      // (A/B runs)
+    bool ahead_ok = false;
+    const double ahead_cell = (!no_ahead && cov_levels(n_dst) == 1 && h->cov_scale_hint >= 1.3) ? res * h->cov_scale_hint : 0.0;
+    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h), ahead_cell, &ahead_ok)) return 1;
+    if (h->clamp.use) ahead_ok = false;      // (the target was cut to its bulk in there: the grid built ahead covers the uncut cloud)
     h->have_target = true;
     H_TRY(h->tgt_cov6.reserve((n_dst + 1) * 6 * sizeof(double)));
     H_TRY(h->vox.reserve((n_dst + 1) * sizeof(VgicpVoxel)));
@@ -679,10 +695,16 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
         const double occ = grid_sum_sq(h->cov_hdr0) / (double)n_dst;
         const double scale = std::min(8.0, sqrt(10.0 / std::max(occ, 1e-3)));
         if (scale >= 1.3) {
-            if (settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * scale, 0, h->clamp.use ? &h->clamp : nullptr)) return 1;
+            // the grid built ahead serves if its cell is within 15 % of what this cloud's density asks for (the cell only decides how
+            // many candidates a search visits, never its result)
+            const bool keep = ahead_ok && fabs(h->cov_scale_hint / scale - 1.0) <= 0.15;
+            if (!keep) {
+                if (settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * scale, 0, h->clamp.use ? &h->clamp : nullptr)) return 1;
+                h->cov_scale_hint = scale;
+            }
             cov_grid = &h->cov_l1;
-        }
-    }
+        } else h->cov_scale_hint = 0.0;
+    } else h->cov_scale_hint = 0.0;
     CovCheck chk;
     const bool check = h->use_tile && h->have_halo;
     if (check) {
