@@ -760,18 +760,19 @@ __global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArg
     const unsigned long long t_in = wall_clock64();
     const int t = threadIdx.x;
     NdtCtl* const c = reinterpret_cast<NdtCtl*>(sh_ctl);
-    // ONE round trip: the state, and -- on the guess that the previous launch was a line-search pass, which ten of thirteen are --
-    // its 7 sums a row in the [64 slices][8 components] layout
-    const int compL = t & 7, sliceL = t >> 3;
-    double vL[4];
+    // ONE round trip: the state and the rows of the previous launch, in the [10 slices][48 components] layout whatever that launch was
+    // (since repeated line-search evaluations are no longer passes, most launches follow a pass with a Hessian; a line-search pass
+    // fills 7 of the 48 slots of a row and the rest is ignored)
+    const int comp = t % 48, slice = t / 48;      // 10 slices: t < 480
+    double v[26];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t row = (uint32_t)(sliceL + 64 * u);
-        vL[u] = (!pa.first && row < pa.rows_prev_n) ? pa.rows_prev[(size_t)row * 48 + compL] : 0.0;
+    for (int u = 0; u < 26; ++u) {
+        const uint32_t row = (uint32_t)(slice + 10 * u);
+        v[u] = (!pa.first && t < 480 && row < pa.rows_prev_n) ? pa.rows_prev[(size_t)row * 48 + comp] : 0.0;
     }
     for (int w = t; w < kCtlWords; w += kProBlock) sh_ctl[w] = reinterpret_cast<const uint32_t*>(pa.ctl_prev)[w];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(vL[u]));
+    for (int u = 0; u < 26; ++u) asm volatile("" ::"v"(v[u]));
     __syncthreads();
     if (c->done) {      // finished in an earlier launch: hand the state on, so that whatever is queued behind reads it too
         if (blockIdx.x == 0) for (int w = t; w < kCtlWords; w += kProBlock) reinterpret_cast<uint32_t*>(pa.ctl_next)[w] = sh_ctl[w];
@@ -779,16 +780,7 @@ __global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArg
     }
     if (!pa.first) {
         const bool light = c->kind == kNdtPassDeriv;
-        if (light) {
-            sh[sliceL * 8 + compL] = ((vL[0] + vL[1]) + vL[2]) + vL[3];
-        } else if (t < 480) {
-            const int comp = t % 48, slice = t / 48;      // 10 slices
-            double v[26];
-#pragma unroll
-            for (int u = 0; u < 26; ++u) {
-                const uint32_t row = (uint32_t)(slice + 10 * u);
-                v[u] = row < pa.rows_prev_n ? pa.rows_prev[(size_t)row * 48 + comp] : 0.0;
-            }
+        if (t < 480) {
             double acc = 0.0;
 #pragma unroll
             for (int u = 0; u < 26; ++u) acc += v[u];
@@ -796,15 +788,13 @@ __global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArg
         }
         __syncthreads();
         if (t < 48) {
-            double v = 0.0;
-            if (light) {
-                if (t < 7) { v = sh[t]; for (int s2 = 1; s2 < 64; ++s2) v += sh[s2 * 8 + t]; }
-            } else if (t < kNdtComp) {
-                v = sh[t];
+            double r = 0.0;
+            if (t < (light ? 7 : kNdtComp)) {
+                r = sh[t];
 #pragma unroll
-                for (int s2 = 1; s2 < 10; ++s2) v += sh[s2 * 48 + t];
+                for (int s2 = 1; s2 < 10; ++s2) r += sh[s2 * 48 + t];
             }
-            sh_sums[t] = v;      // (a light pass leaves the Hessian slots at zero: ctl_decide does not read them)
+            sh_sums[t] = r;      // (a light pass leaves the Hessian slots at zero: ctl_decide does not read them)
         }
         __syncthreads();
         unsigned long long t_a = 0;
