@@ -7,11 +7,17 @@ reference does, PCR/src/LoamRegister.cpp:110), inputs resident in HBM.  One "ste
 scan2Map call through the C ABI (pcr_scan2map_device).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank holds a full map
-replica and registers its own scans (scans are independent objects: no data-path
-collective) -> weak scaling, value = all ranks' scans / max-over-ranks time.
-`--shard-map` instead shards the map tiles across ranks with an RCCL all-reduce of the
-normal equations per iteration (BASELINE.json configs[3]); it is not the default line.
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this
+process IS a rank; started plainly (`python bench.py --gpus N`) it is the LAUNCHER: before anything
+touches the GPU it starts N fresh child processes (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* set), waits
+for them and relays rank 0's JSON line (launch_ranks).  `--dry-run` makes every rank report its
+environment instead of measuring (no GPU needed: the CPU suite drives the launcher that way).
+Every rank holds a full map replica and registers its own scans (scans are independent objects: no
+data-path collective) -> weak scaling, value = all ranks' scans / max-over-ranks time.
+`--shard-map` instead shards the map tiles across ranks with an RCCL all-reduce of the normal
+equations per iteration (BASELINE.json configs[3]: 10 M-point map by default); it is not the default
+line.  The line says how many ranks really ran: n_gpus = WORLD_SIZE, rccl_ranks = what the
+communicator reports.
 
 Prints ONE JSON line on rank 0.
 """
@@ -72,7 +78,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--map-points", type=int, default=1_000_000)
+    ap.add_argument("--map-points", type=int, default=None, help="default 1 000 000 (configs[1]); 10 000 000 with --shard-map (configs[3])")
+    ap.add_argument("--dry-run", action="store_true", help="every rank prints the environment it was started with and leaves: no GPU, no measurement")
+    ap.add_argument("--master-port", type=int, default=0, help="launcher only: rendezvous port of the ranks it starts (0 = pick a free one)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
     ap.add_argument("--shard-map", action="store_true", help="shard map tiles across ranks + RCCL all-reduce (config 4)")
@@ -86,7 +94,142 @@ def parse():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; value = the median window")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (vgicp) and configs[4] (ndt) lines embedded as \"extra\"")
     ap.add_argument("--extra-steps", type=int, default=40)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.map_points is None:
+        args.map_points = 10_000_000 if args.shard_map else 1_000_000
+    return args
+
+
+def rank_env():
+    return {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N ranks of this script, one per GPU, the way
+    torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), wait for them and print rank 0's
+    JSON line.  This process never imports torch and never touches the GPU: the ranks are fresh children (a process that has
+    initialised the GPU must not be replaced or forked).  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", PCR_BENCH_LAUNCHER="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0 = ""
+    try:
+        # rank 0's stdout carries the line; the others' goes to stderr.  A rank that dies takes the others with it (they would wait
+        # for it in a collective for ever): poll, and end exactly the processes started here.
+        import threading
+        box = {}
+        t = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        t.start()
+        rc = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.05)
+        if rc:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        t.join(10)
+        out0 = box.get("out", "") or ""
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if rc:
+        print(f"bench.py launcher: a rank exited with code {rc}", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def dry_run(args):
+    """--dry-run: what this rank was started with.  Rank 0 gathers every rank's report over gloo (which also proves the
+    rendezvous the real run would use) and prints one line."""
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+          "world_size": int(os.environ.get("WORLD_SIZE", "1")), "pid": os.getpid(), "env": rank_env(),
+          "launcher": os.environ.get("PCR_BENCH_LAUNCHER", "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "none")}
+    ws = me["world_size"]
+    if os.environ.get("PCR_BENCH_DRYRUN_FAIL_RANK") == str(me["rank"]):      # test hook: a rank that dies before the rendezvous
+        return 3
+    reports = [me]
+    if ws > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=me["rank"], world_size=ws)
+        reports = [None] * ws
+        dist.all_gather_object(reports, me)
+        dist.barrier()
+        dist.destroy_process_group()
+    if me["rank"] == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": ws, "gpus_arg": args.gpus, "shard_map": bool(args.shard_map),
+                          "map_points": args.map_points, "ranks": reports}), flush=True)
+    return 0
+
+
+def join_ranks(torch, dist, rank, local_rank, world_size, rehearse):
+    """Bind this rank to its GPU and join the process group.  -> (device, rccl_ranks): rccl_ranks is the number of ranks that took
+    part in an RCCL all-reduce issued right here (a sum of ones over the "nccl" group -- measured, not read from argv); 1 for a
+    single rank, 0 in a rehearsal (several ranks on ONE card exchange over gloo: RCCL refuses one device twice)."""
+    n_dev = torch.cuda.device_count()
+    if rehearse:
+        local_rank = local_rank % max(1, n_dev)
+    elif local_rank >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} is to use GPU {local_rank} but this node shows {n_dev}; "
+                         "PCR_BENCH_REHEARSE=1 lets the ranks share a card (a rehearsal of the launch path, not a measurement)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size == 1:
+        return dev, 1
+    if rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        return dev, 0
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(ones)
+    return dev, int(round(float(ones.item())))
+
+
+def gather_ranks(dist, world_size, info):
+    """every rank's `info` dict, in rank order, on every rank"""
+    if world_size == 1:
+        return [info]
+    out = [None] * world_size
+    dist.all_gather_object(out, info)
+    return out
+
+
+def launcher_name(world_size):
+    return os.environ.get("PCR_BENCH_LAUNCHER", "torch.distributed.run (external)" if world_size > 1 else "none")
 
 
 def secondary(args, method=None, steps=None, warmup=None, embedded=False):
@@ -107,17 +250,15 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
     if embedded:
         rank, world_size = 0, 1
     rehearse = os.environ.get("PCR_BENCH_REHEARSE") == "1" and world_size > 1
-    if rehearse:
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world_size)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+    if embedded:
+        torch.cuda.set_device(local_rank)
+        dev, rccl_ranks = torch.device("cuda", local_rank), 1
+    else:
+        dev, rccl_ranks = join_ranks(torch, dist, rank, local_rank, world_size, rehearse)
+        local_rank = dev.index
     if method == "vgicp":
         cfg, n_map, kw, mk = 3, 1_000_000, {}, {}
         reg = VgicpRegister(device=local_rank, vgicp_resolution=0.5)
@@ -176,7 +317,8 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if method == "vgicp" else "f32",
            "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
            "config": {"workload": workload, "scans_cycled": args.scans,
-                      "parallelism": f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"}}
+                      "parallelism": f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"},
+           "rccl_ranks": rccl_ranks, "gpus_arg": args.gpus, "launcher": launcher_name(world_size)}
     reg.set_profile(1)
     idx_ms = sol_ms = 0.0
     for i in range(8):
@@ -217,6 +359,10 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
+    if args.dry_run:
+        return dry_run(args)
     if args.method != "loam":
         return secondary(args)
     import torch
@@ -233,15 +379,8 @@ def main():
     # PCR_BENCH_REHEARSE=1: several ranks on ONE card (gloo for the barrier and the max over ranks) -- only to exercise the
     # launch path of the multi-GPU run on a one-GPU box; the line it prints is not a measurement of N GPUs.
     rehearse = os.environ.get("PCR_BENCH_REHEARSE") == "1" and world_size > 1
-    if rehearse:
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world_size > 1:
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world_size)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+    dev, rccl_ranks = join_ranks(torch, dist, rank, local_rank, world_size, rehearse)
+    local_rank = dev.index
 
     # ---- synthetic workload (same map on every rank; scans differ per rank) ----
     world, map_np = synth.make_map(args.map_points, seed=SEED + 2)
@@ -260,11 +399,12 @@ def main():
     d_map = d_map_full
     scaling = "weak"
     parallelism = f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"
+    rank_info = {"rank": rank, "device": local_rank, "map_points": int(map_np.shape[0])}
     if args.shard_map:
         from simpleslam_amd import shard
-        tile = shard.tile_for_rank(map_np, rank, world_size)
+        tile = shard.tile_for_method(map_np, rank, world_size, "loam")
         d_map = torch.from_numpy(tile.points).to(dev)
-        reg.set_query_tile(tile.lo, tile.hi)
+        reg.set_shard(tile.lo, tile.hi, tile.halo)
         if rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
             reg.comm_init_host(shard.gloo_collective(), rank, world_size)
         else:
@@ -272,10 +412,16 @@ def main():
             if world_size > 1:
                 dist.broadcast_object_list(uid, src=0)
             reg.comm_init(uid[0], rank, world_size)
-        d_scans = [torch.from_numpy(s).to(dev) for s in (synth.make_scan(world, j, seed=SEED + 2)[0] for j in range(args.scans))]
+        # the scans are the SAME on every rank (one scan is split over the tiles), so rank 0's set
+        scans = [synth.make_scan(world, j, seed=SEED + 2)[0] for j in range(args.scans)]
+        d_scans = [torch.from_numpy(s).to(dev) for s in scans]
         inits = [synth.perturb(synth.scan_pose(world, j, SEED + 2), SEED + 2 + j) for j in range(args.scans)]
         scaling = "strong"
-        parallelism = f"map tiles x{world_size} + RCCL all-reduce of JtJ/JtE"
+        ci = reg.comm_info()
+        rccl_ranks = ci["nranks"] if ci["transport"] == "rccl" else 0      # read back from the communicator the handle reduces over
+        parallelism = f"map tiles x{world_size} + all-reduce of JtJ/JtE per iteration over {ci['transport']}"
+        rank_info.update(tile_points=int(tile.points.shape[0]), tile_core_points=int(tile.n_core), tile_axis=int(tile.axis),
+                         tile_lo=float(tile.lo[tile.axis]), tile_hi=float(tile.hi[tile.axis]), transport=ci["transport"])
 
     def step(i):
         pose = inits[i % args.scans].copy()
@@ -310,6 +456,9 @@ def main():
         "config": {"workload": f"pcr=loam, {N_SCAN}-pt 64-beam scan vs {args.map_points}-pt submap, {args.iters} GN iters, "
                                "early exit off, index rebuilt per call, inputs in HBM",
                    "parallelism": parallelism, "scans_cycled": args.scans},
+        # how many ranks REALLY ran: n_gpus is WORLD_SIZE of the process group, rccl_ranks the size of the RCCL group that carried a
+        # collective (replicas: the barrier / max-over-ranks group; --shard-map: the handle's own communicator); gpus_arg is argv
+        "rccl_ranks": rccl_ranks, "gpus_arg": args.gpus, "launcher": launcher_name(world_size),
     }
 
     if rank == 0 and args.streams > 1 and not args.shard_map:
@@ -345,17 +494,36 @@ def main():
     #      map every rank has to take part in the calls (each one is a chain of collectives) ----
     k_ms, k_n, idx_ms, tot_ms = 0.0, 0, 0.0, 0.0
     reps = 16
-    if rank == 0 or (args.shard_map and world_size > 1):
-        reg.set_profile(2)
-        for i in range(reps):
-            step(i)
-            st = reg.stats()
-            k_ms += st["kernel_ms"]; k_n += st["kernel_launches"]; idx_ms += st["index_ms"]; tot_ms += st["total_ms"]
-        reg.set_profile(0)
+    reg.set_profile(2)
+    for i in range(reps):
+        step(i)
+        st = reg.stats()
+        k_ms += st["kernel_ms"]; k_n += st["kernel_launches"]; idx_ms += st["index_ms"]; tot_ms += st["total_ms"]
+    reg.set_profile(0)
+    avg_s = (k_ms / max(1, k_n)) * 1e-3
+    alg_bytes = 96 * N_SCAN + 216          # per linearisation launch (sharded: the scan is split, the launch is not shorter)
+    achieved = alg_bytes / avg_s / 1e9
+    rank_info.update(avg_launch_us=avg_s * 1e6, hbm_frac=achieved / HBM_PEAK_GBS, index_build_us=1e3 * idx_ms / reps,
+                     index_build_GBs=32 * d_map.shape[0] / (idx_ms / reps * 1e-3) / 1e9 if idx_ms > 0 else None)
+    out["ranks"] = gather_ranks(dist, world_size, rank_info)
+    if args.shard_map and world_size > 1:
+        # the origin of the curve: the SAME scans against the WHOLE map on one GPU (rank 0, an unsharded handle), while the others wait
+        if rank == 0:
+            reg1 = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0)
+            reg1.set_profile(0)
+
+            def step1(i):
+                pose = inits[i % args.scans].copy()
+                reg1.scan2Map(d_scans[i % args.scans], d_map_full, pose)
+            for i in range(min(args.warmup, 10)):
+                step1(i)
+            w1 = timed_windows(step1, lambda: torch.cuda.synchronize(), args.steps, 3)
+            e1 = float(np.median(w1))
+            out["n1"] = {"value": args.steps / e1, "unit": "scans/s", "ms_per_step": 1e3 * e1 / args.steps,
+                         "note": "same scans, whole map, one GPU, unsharded handle (the N = 1 point of this strong-scaling curve)"}
+            del reg1
+        dist.barrier()
     if rank == 0:
-        avg_s = (k_ms / max(1, k_n)) * 1e-3
-        alg_bytes = 96 * N_SCAN + 216          # per linearisation launch
-        achieved = alg_bytes / avg_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "loam_iterate_pmc.json")
         if os.path.exists(pmc):
@@ -368,7 +536,7 @@ def main():
                            "kernel": "loam_iterate_kernel", "avg_launch_us": avg_s * 1e6,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "index_build_us": 1e3 * idx_ms / reps,
-                           "index_build_GBs": 32 * args.map_points / (idx_ms / reps * 1e-3) / 1e9 if idx_ms > 0 else None,
+                           "index_build_GBs": 32 * d_map.shape[0] / (idx_ms / reps * 1e-3) / 1e9 if idx_ms > 0 else None,
                            # (this pass runs with an event pair around every launch -- pcr_set_profile(2) -- which stretches the call:
                            #  it is NOT comparable with ms_per_step, which is timed without any event)
                            "device_ms_per_scan_profiled": tot_ms / reps}
@@ -451,4 +619,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

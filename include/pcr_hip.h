@@ -294,6 +294,10 @@ int pcr_set_query_tile(pcr_handle* h, const double lo[3], const double hi[3]);
  * caller (e.g. torch.distributed broadcast).  librccl is dlopen'ed here, never before. */
 int pcr_comm_unique_id(void* out128);
 int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks);
+/* Who takes part in this handle's exchange: *transport = 0 none (unsharded), 1 RCCL, 2 the caller's collective.  With RCCL
+ * rank and nranks are read back from the communicator (ncclCommUserRank / ncclCommCount), not from the arguments it was
+ * created with -- bench.py reports them as "rccl_ranks". */
+int pcr_comm_info(const pcr_handle* h, int* rank, int* nranks, int* transport);
 /* The same exchange through a caller-supplied collective (MPI, gloo, threads of one process ...), used when no RCCL
  * communicator is set: fn must combine `count` doubles IN PLACE over all ranks -- op 0 = sum, 1 = max -- return 0 on
  * success, and leave bitwise-identical results on every rank (the ranks then solve redundantly and must agree).  It is

@@ -29,12 +29,14 @@ typedef int (*nccl_get_id_fn)(NcclId*);
 typedef int (*nccl_init_rank_fn)(void**, int, NcclId, int);
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*nccl_destroy_fn)(void*);
+typedef int (*nccl_comm_int_fn)(void*, int*);
 struct Rccl {
     void* lib = nullptr;
     nccl_get_id_fn get_id = nullptr;
     nccl_init_rank_fn init_rank = nullptr;
     nccl_allreduce_fn allreduce = nullptr;
     nccl_destroy_fn destroy = nullptr;
+    nccl_comm_int_fn comm_count = nullptr, comm_user_rank = nullptr;
     bool load(std::string* err) {
         if (lib) return true;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -44,6 +46,8 @@ struct Rccl {
         init_rank = (nccl_init_rank_fn)dlsym(lib, "ncclCommInitRank");
         allreduce = (nccl_allreduce_fn)dlsym(lib, "ncclAllReduce");
         destroy = (nccl_destroy_fn)dlsym(lib, "ncclCommDestroy");
+        comm_count = (nccl_comm_int_fn)dlsym(lib, "ncclCommCount");
+        comm_user_rank = (nccl_comm_int_fn)dlsym(lib, "ncclCommUserRank");
         if (!get_id || !init_rank || !allreduce || !destroy) { if (err) *err = "librccl lacks ncclGetUniqueId/CommInitRank/AllReduce"; return false; }
         return true;
     }
@@ -1872,6 +1876,21 @@ int pcr_comm_unique_id(void* out128) {
     int rc = g_rccl.get_id(&id);
     if (rc != 0) { g_create_error = "ncclGetUniqueId failed with code " + std::to_string(rc); return 1; }
     memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int pcr_comm_info(const pcr_handle* h, int* rank, int* nranks, int* transport) {
+    if (!h) return 1;
+    int r = h->rank, n = h->nranks, t = 0;
+    if (h->comm) {
+        // what the communicator itself reports, not what the caller passed to pcr_comm_init
+        t = 1;
+        if (g_rccl.comm_count && g_rccl.comm_count(h->comm, &n) != 0) return 1;
+        if (g_rccl.comm_user_rank && g_rccl.comm_user_rank(h->comm, &r) != 0) return 1;
+    } else if (h->host_ar) t = 2;
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    if (transport) *transport = t;
     return 0;
 }
 

@@ -1,0 +1,76 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N` must really run N ranks (missing #1).
+
+No GPU here: `--dry-run` makes every rank report the environment it was started with (gathered over the same 127.0.0.1
+rendezvous the measuring run uses) instead of measuring."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCR_BENCH_LAUNCHER")}
+    return env
+
+
+def _line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_gpus_n_starts_n_ranks(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-run"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = _line(r.stdout)
+    assert d["dry_run"] and d["n_gpus"] == n and d["gpus_arg"] == n
+    ranks = d["ranks"]
+    assert [x["rank"] for x in ranks] == list(range(n))
+    assert [x["local_rank"] for x in ranks] == list(range(n))
+    assert len({x["pid"] for x in ranks}) == n and os.getpid() not in {x["pid"] for x in ranks}
+    ports = {x["env"]["MASTER_PORT"] for x in ranks}
+    assert len(ports) == 1 and int(ports.pop()) > 0
+    for x in ranks:
+        assert x["world_size"] == n and x["env"]["WORLD_SIZE"] == str(n)
+        assert x["env"]["MASTER_ADDR"] == "127.0.0.1"
+        assert x["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert x["launcher"] == "bench.py"
+
+
+def test_shard_map_defaults_to_config4_map():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--shard-map", "--dry-run"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = _line(r.stdout)
+    assert d["shard_map"] and d["map_points"] == 10_000_000 and d["n_gpus"] == 2
+
+
+def test_single_rank_needs_no_launcher():
+    r = subprocess.run([sys.executable, BENCH, "--dry-run"], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["ranks"][0]["launcher"] == "none" and d["map_points"] == 1_000_000
+
+
+def test_under_torch_distributed_run_the_process_is_a_rank():
+    """the driver's N > 1 command: torch.distributed.run starts the ranks, bench.py must not start more"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", BENCH, "--gpus", "2", "--dry-run"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and len(d["ranks"]) == 2
+    assert all(x["launcher"].startswith("external") for x in d["ranks"])
+
+
+def test_a_failing_rank_fails_the_launch():
+    """rank 1 dies before the rendezvous: the launcher ends rank 0 (which would wait for it for ever), exits nonzero, prints no line"""
+    env = _clean_env()
+    env["PCR_BENCH_DRYRUN_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
