@@ -326,7 +326,7 @@ int pcr_get_params(const pcr_handle* h, pcr_params* out);
 
 /* The fitness score of the reference's test/align.cpp:29-61: the source transformed by `pose` (float, as
  * pcl::transformPointCloud), 1-NN in the handle's current target, mean of the squared distances that are <= max_sq
- * (align.cpp uses 1.0); *n_in = points counted.  score = DBL_MAX when none is.  Any method's handle with a target. */
+ * (align.cpp uses 1.0); *n_in = points counted.  score = -1 when none is (align.cpp:56-59).  Any method's handle with a target. */
 int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, const double pose[16],
                       double max_sq, double* score, int64_t* n_in);
 

@@ -162,6 +162,9 @@ namespace {
 
 #define H_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(_e); return 1; } } while (0)
 
+// inside a loop that has launches reading the caller's buffers queued ahead of the device: an error must not return before they drained
+#define H_TRY_DRAIN(x) do { hipError_t _e = (x); if (_e != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(_e); (void)hipStreamSynchronize(h->stream); return 1; } } while (0)
+
 int fail(pcr_handle* h, const std::string& msg) { h->err = msg; return 1; }
 
 bool sharded(const pcr_handle* h) { return h->comm != nullptr || h->host_ar != nullptr; }
@@ -795,28 +798,29 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         H_TRY(vgicp_launch_ctl_init(d_ctl, x0, h->prm.vgicp_max_iters, h->prm.vgicp_lm_inner, h->prm.vgicp_lm_init_scale, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps, h->stream));
         // every outer iteration takes at most lm_inner passes, plus the first linearisation and the launch that finishes
         const long limit = (long)h->prm.vgicp_max_iters * std::max(1, h->prm.vgicp_lm_inner) + 3;
+        if ((double)limit >= kProgressWindow) return fail(h, "vgicp_max_iters * vgicp_lm_inner exceeds the device loop's pass window (2^20)");
         long enq = 0;
         // (a pass is ~14 us, and the word that says one has begun is written ~6 us into it: with fewer than three launches ahead of
         // that word the queue runs dry while the host enqueues; a launch beyond the end costs ~5 us)
-        for (; enq < 4 && enq < limit; ++enq) H_TRY(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
+        for (; enq < 4 && enq < limit; ++enq) H_TRY_DRAIN(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
         const volatile double* f_seq = &out->seq;
         const volatile double* f_prog = &out->progress;
         long spins = 0;
         for (;;) {
             if (*f_seq == seq) break;
             const double pr = *f_prog;
-            const long consumed = (pr >= seq * 4096.0 && pr < (seq + 1.0) * 4096.0) ? (long)(pr - seq * 4096.0) : 0;
+            const long consumed = (pr >= seq * kProgressWindow && pr < (seq + 1.0) * kProgressWindow) ? (long)(pr - seq * kProgressWindow) : 0;
             if (enq - consumed < 3 && enq < limit) {
-                H_TRY(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq)); ++enq;
+                H_TRY_DRAIN(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq)); ++enq;
                 continue;
             }
             __builtin_ia32_pause();
             if (++spins > 400000 || h->profile != 0) {          // a slow device (or a profiler): wait for what is queued, then look again
                 H_TRY(hipStreamSynchronize(h->stream));
                 if (*f_seq == seq) break;
-                if (enq >= limit) return fail(h, "vgicp: the optimiser did not finish within its pass budget");
+                if (enq >= limit) return fail(h, "vgicp: the optimiser did not finish within its pass budget");      // (stream just drained)
                 spins = 0;
-                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
+                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY_DRAIN(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1059,6 +1063,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         const double seq = h->seq;
         H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.reserved[1]));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 5;        // an iteration takes at most 1 + 10 + 1 passes; one launch more finishes
+        if ((double)limit >= kProgressWindow) return fail(h, "ndt_max_iters exceeds the device loop's pass window (2^20 passes)");
         int enq = 0;
         const int first = 3;      // (the host enqueues a pass in a quarter of the time the device needs for one: it only has to stay two ahead)
         static const bool two_launches = getenv("PCR_NDT_TWO_LAUNCHES") != nullptr;      // the round's earlier form (pass kernel + fold/controller kernel), for A/B runs
@@ -1066,7 +1071,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
             if (two_launches) return ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq);
             return ndt_launch_pass_pro(r.a, d_ctl, h->nd_partials.as<double>(), h->nd_out_dev, h->stream, seq, index);
         };
-        for (; enq < first; ++enq) H_TRY(launch(enq));
+        for (; enq < first; ++enq) H_TRY_DRAIN(launch(enq));
         const volatile double* f_seq = &out->seq;
         const volatile double* f_prog = &out->progress;
         long spins = 0;
@@ -1074,9 +1079,9 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         while (!finished) {
             if (*f_seq == seq) { finished = true; break; }
             const double pr = *f_prog;
-            const int consumed = (pr >= seq * 4096.0 && pr < (seq + 1.0) * 4096.0) ? (int)(pr - seq * 4096.0) : 0;
+            const int consumed = (pr >= seq * kProgressWindow && pr < (seq + 1.0) * kProgressWindow) ? (int)(pr - seq * kProgressWindow) : 0;
             if (enq - consumed < 2 && enq < limit) {       // two passes ahead of the device: a pass enqueued beyond the end costs ~10 us of device time
-                H_TRY(launch(enq)); ++enq;
+                H_TRY_DRAIN(launch(enq)); ++enq;
                 continue;
             }
             __builtin_ia32_pause();
@@ -1085,7 +1090,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
                 if (*f_seq == seq) { finished = true; break; }
                 if (enq >= limit) return fail(h, "ndt: the optimiser did not finish within its pass budget");
                 spins = 0;
-                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY(launch(enq));
+                for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY_DRAIN(launch(enq));
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1138,10 +1143,15 @@ int agree_prepared(pcr_handle* h, int rc_local) {
     return 0;
 }
 
+// a new registration starts: whatever pcr_fitness() could evaluate belongs to the previous one (a call that fails during
+// target preparation must not leave the new scan's points paired with the old pose)
+void drop_fitness_state(pcr_handle* h) { h->fit_pending = false; h->fit_n = 0; h->fit_copied_from = nullptr; h->fitness = -1.0; }
+
 int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst, size_t stride_bytes,
                 double pose[16], int* converged, bool on_device) {
     if (!h) return 1;
     h->err.clear();
+    drop_fitness_state(h);
     h->map_id = 0; h->map_gen = 0;      // whatever target structures exist after this call were not built from a pcr_map generation
     if (!pose) return fail(h, "pose_inout is NULL");
     if ((n_src && !src) || (n_dst && !dst)) return fail(h, "NULL cloud with nonzero size");
@@ -1371,7 +1381,12 @@ int pcr_scan2map_submap(pcr_handle* h, const void* src, size_t n_src, int src_on
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     const bool current = h->map_id == id && h->map_gen == gen && h->have_target &&
                          (h->method == kLoam ? h->grid.valid && !h->clamp.use : (h->method == kNdt ? h->nd_target_ready : h->vg_target_ready));
-    if (!current) {
+    // Sharded: prepare_target_from() ends in a collective (agree_prepared), so either every rank rebuilds or none does -- a rank
+    // whose tile index was cut, or whose map is at another generation, must not enter that exchange while its peers are already
+    // summing normal equations.  One MAX over the ranks of "I have to rebuild" decides for all.
+    double need = current ? 0.0 : 1.0;
+    if (sharded(h) && ranks_allreduce(h, &need, 1, 1)) return 1;
+    if (need != 0.0) {
         if (prepare_target_from(h, static_cast<const float*>(d_dst), n_dst, stride_bytes)) return 1;
         h->map_id = id; h->map_gen = gen;
         h->target_builds += 1;
@@ -1387,6 +1402,7 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
+    drop_fitness_state(h);
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (h->method == kNdt) return run_ndt(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restr
             __threadfence_system();
             __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
-            __hip_atomic_store(&out->progress, seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out->progress, seq * kProgressWindow + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArg
                     __threadfence_system();
                     __hip_atomic_store(&out->seq, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
-                    __hip_atomic_store(&out->progress, pa.seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&out->progress, pa.seq * kProgressWindow + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }

@@ -57,6 +57,9 @@ struct GridView {            // what kernels need to query the index
 };
 
 static constexpr int kPad = 2;           // pad cells per side (see grid_index.hip)
+// progress word of the device-resident optimisers (NdtOut / VgOut): call number * kProgressWindow + passes consumed.  The pass budget
+// of a call ((ndt_max_iters + 3) * 13 + 5, vgicp_max_iters * lm_inner + 3) must stay inside the window: checked where it is computed.
+static constexpr double kProgressWindow = 1048576.0;
 static constexpr int kBBoxBlocks = 256;  // partial bounding boxes
 
 struct Pose16 { double m[16]; };

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_i
                     __threadfence_system();
                     __hip_atomic_store(&out->seq, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
-                    __hip_atomic_store(&out->progress, pa.seq * 4096.0 + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&out->progress, pa.seq * kProgressWindow + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }

@@ -236,14 +236,19 @@ class PointCloudRegister:
         self._seen = {}
 
     def _cloud_cached(self, x):
+        """(pointer, n, stride, on_device, keepalive) of a device tensor, remembered by identity through a WEAK reference (no tensor
+        is kept alive by this object) and revalidated on every hit: same storage pointer, shape, strides and dtype."""
         if hasattr(x, "data_ptr"):
+            import weakref
             hit = self._seen.get(id(x))
-            if hit is not None and hit[0] is x and hit[1][0].value == x.data_ptr():
+            if hit is not None and hit[0]() is x and hit[2] == (x.data_ptr(), tuple(x.shape), x.stride(), x.dtype):
                 return hit[1]
             c = _cloud(x)
             if len(self._seen) > 64:
-                self._seen.clear()
-            self._seen[id(x)] = (x, c)
+                self._seen = {k: v for k, v in self._seen.items() if v[0]() is not None}
+                if len(self._seen) > 64:
+                    self._seen.clear()
+            self._seen[id(x)] = (weakref.ref(x), c[:4] + (None,), (x.data_ptr(), tuple(x.shape), x.stride(), x.dtype))
             return c
         return _cloud(x)
 
