@@ -264,7 +264,7 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         reg = VgicpRegister(device=local_rank, vgicp_resolution=0.5)
         pert = {}
         cores = host_cores()
-        ref = lambda s, m, T: oracle.vgicp_scan2map(s, m, T, oracle.vgicp_params(resolution=0.5, threads=cores))[0]
+        ref = lambda s, m, T, th: oracle.vgicp_scan2map(s, m, T, oracle.vgicp_params(resolution=0.5, threads=th))[0]
         # one-off per target >= N_m (16 + 20*16 + 128) for the covariances + N_m (16 + 128) for the voxel map
         alg = lambda n_s, n_m: 608 * n_m
         what = "target preparation (index levels + covariance + voxel kernels), 608 B per map point"
@@ -273,8 +273,10 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         cfg, n_map, kw, mk = 5, 5_000_000, dict(beams=128, azimuths=1024), dict(spacing=0.22)
         reg = NdtRegister(device=local_rank)
         pert = dict(trans=0.1, rot_deg=0.5)
-        ref = lambda s, m, T: oracle.ndt_scan2map(s, m, T, oracle.ndt_params())[0]      # the NDT oracle is serial
-        cores = 1
+        # computeDerivatives on `cores` threads as the reference runs it (ndt_omp_impl.hpp:206, NdtRegister.cpp:18); the voxel grid,
+        # computeHessian and the line-search bookkeeping are serial there and here
+        ref = lambda s, m, T, th: oracle.ndt_scan2map(s, m, T, oracle.ndt_params(threads=th))[0]
+        cores = host_cores()
         alg = lambda n_s, n_m: 16 * n_m          # voxel build reads every map point once (+104 B per voxel written)
         what = "target preparation (index + voxel Gaussians), 16 B per map point"
         workload = "pcr=ndt, 1.0 m cells, 131072-pt 128-beam scan vs 5000000-pt submap, target rebuilt per call, inputs in HBM"
@@ -329,20 +331,32 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
                        "kernel": what, "target_prep_ms": idx_ms, "align_ms": sol_ms}
     out["roofline"]["note"] = "target_prep_ms / align_ms come from a separate 8-scan pass with phase events (pcr_set_profile 1)"
     if not args.no_cpu_baseline and world_size == 1:      # the CPU leg is timed at N = 1 only
-        n_done, t_cpu, et, er, nan_both, nan_one = 0, 0.0, [], [], 0, 0
-        while n_done < 2 or (t_cpu < args.cpu_budget_s and n_done < args.scans):
-            j = n_done % args.scans
-            c0 = time.perf_counter(); pref = ref(scans[j], map_np, inits[j]); t_cpu += time.perf_counter() - c0
-            pg = step(j)
-            n_done += 1
-            if not (np.isfinite(pg).all() and np.isfinite(pref).all()):
-                nan_both += int(not np.isfinite(pg).all() and not np.isfinite(pref).all())
-                nan_one += int(np.isfinite(pg).all() != np.isfinite(pref).all())
-                continue
-            dt, dr = synth.pose_error(pg, pref)
-            et.append(dt); er.append(dr)
+        def cpu_leg(threads, budget, parity):
+            n_done, t_cpu, et, er, nan_both, nan_one = 0, 0.0, [], [], 0, 0
+            while n_done < 2 or (t_cpu < budget and n_done < args.scans):
+                j = n_done % args.scans
+                c0 = time.perf_counter(); pref = ref(scans[j], map_np, inits[j], threads); t_cpu += time.perf_counter() - c0
+                n_done += 1
+                if not parity:
+                    continue
+                pg = step(j)
+                if not (np.isfinite(pg).all() and np.isfinite(pref).all()):
+                    nan_both += int(not np.isfinite(pg).all() and not np.isfinite(pref).all())
+                    nan_one += int(np.isfinite(pg).all() != np.isfinite(pref).all())
+                    continue
+                dt, dr = synth.pose_error(pg, pref)
+                et.append(dt); er.append(dr)
+            return n_done, t_cpu, et, er, nan_both, nan_one
+
+        by_cores = {}
+        for th in sorted({1, min(4, cores)} - {cores}):      # 1 thread and the reference's default `cores` = 4 (config/params.json:5)
+            n_d, t_c, *_ = cpu_leg(th, args.cpu_budget_s / 2, False)
+            by_cores[str(th)] = {"value": n_d / t_c, "scans": n_d, "wall_s": t_c}
+        n_done, t_cpu, et, er, nan_both, nan_one = cpu_leg(cores, args.cpu_budget_s, True)
+        by_cores[str(cores)] = {"value": n_done / t_cpu, "scans": n_done, "wall_s": t_cpu}
         out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-                               "sample": f"{n_done} of the same scans through the oracle, {t_cpu:.1f} s wall, threads = {cores}"}
+                               "sample": f"{n_done} of the same scans through the oracle, {t_cpu:.1f} s wall, OpenMP threads = {cores}",
+                               "by_cores": by_cores}
         out["pose_rmse_vs_cpu"] = {"trans_m": float(np.sqrt(np.mean(np.square(et)))) if et else None,
                                    "rot_rad": float(np.sqrt(np.mean(np.square(er)))) if er else None, "scans": len(et),
                                    # pclomp's line search can return NaN (ndt_omp_impl.hpp:773-932); both sides then agree on it

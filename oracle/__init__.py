@@ -432,7 +432,7 @@ def fitness_score(src, dst, pose, max_range=1.7976931348623157e308):
 # ---------------------------------------------------------------------------
 class NdtParams(C.Structure):
     _fields_ = [("resolution", C.c_double), ("step_size", C.c_double), ("outlier_ratio", C.c_double), ("trans_eps", C.c_double),
-                ("max_iters", C.c_int), ("min_points", C.c_int), ("eig_mult", C.c_double)]
+                ("max_iters", C.c_int), ("min_points", C.c_int), ("eig_mult", C.c_double), ("threads", C.c_int), ("pad_", C.c_int)]
 
 
 def _nd():

@@ -39,12 +39,14 @@ typedef struct {
     int max_iters;          /* 35   ndt_omp_impl.hpp:72 */
     int min_points;         /* 6    voxel_grid_covariance_omp.h:210 */
     double eig_mult;        /* 0.01 voxel_grid_covariance_omp.h:211 */
+    int threads;            /* num_threads_ = `cores` (PCR/src/NdtRegister.cpp:18; ndt_omp_impl.hpp:206): computeDerivatives only */
+    int pad_;
 } oracle_ndt_params;
 
 void oracle_ndt_default_params(oracle_ndt_params *p)
 {
     p->resolution = 1.0; p->step_size = 0.1; p->outlier_ratio = 0.55; p->trans_eps = 0.1; p->max_iters = 35;
-    p->min_points = 6; p->eig_mult = 0.01;
+    p->min_points = 6; p->eig_mult = 0.01; p->threads = 1; p->pad_ = 0;
 }
 
 /* ---- voxel grid ---- */
@@ -261,71 +263,108 @@ static gauss_t gauss_consts(const oracle_ndt_params *prm)
     return g;
 }
 
-/* computeDerivatives (:180-285) with the float inner math of updateDerivatives (:485-537) */
+/* computeDerivatives (:180-285) with the float inner math of updateDerivatives (:485-537).
+ * The reference runs the loop over the points on num_threads_ OpenMP threads (schedule(guided, 8), :206), every point writing
+ * its own score / gradient / Hessian into scores[idx], score_gradients[idx], hessians[idx] (:270-272), and then adds those up
+ * SERIALLY in point order (:277-282, "Ensure that the result is invariant against the summing up order").  So do we: the
+ * result is bit-identical for every thread count, which tests/test_oracle_vgicp_ndt.py pins. */
+static void derivatives_point(const ndt_grid *g, const float *xp, const float *tp, const gauss_t *gc, int compute_hessian, const ang_t *ang,
+                              double *score_out, double g_pt[6], double h_pt[36])
+{
+    const float gauss_d2 = (float)gc->d2;
+    const leaf_t *nb[7];
+    int nn = neighborhood7(g, tp, nb);
+    /* computePointDerivatives, float (:399-440): x4 = (float)x */
+    float x4[3] = {(float)(double)xp[0], (float)(double)xp[1], (float)(double)xp[2]};
+    float pg[3][6];
+    memset(pg, 0, sizeof pg); pg[0][0] = pg[1][1] = pg[2][2] = 1.0f;
+    float xj[8], xh[15];
+    for (int r = 0; r < 8; ++r) { float s = ang->j_ang[r][0] * x4[0]; s += ang->j_ang[r][1] * x4[1]; s += ang->j_ang[r][2] * x4[2]; xj[r] = s; }
+    pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
+    for (int r = 0; r < 15; ++r) { float s = ang->h_ang[r][0] * x4[0]; s += ang->h_ang[r][1] * x4[1]; s += ang->h_ang[r][2] * x4[2]; xh[r] = s; }
+    /* point_hessian_ blocks: ph[i][j] = 3-vector for parameters (i,j), i,j in 3..5 */
+    float ph[6][6][3];
+    memset(ph, 0, sizeof ph);
+    const float a_[3] = {0, xh[0], xh[1]}, b_[3] = {0, xh[2], xh[3]}, c_[3] = {0, xh[4], xh[5]}, d_[3] = {xh[6], xh[7], xh[8]},
+                e_[3] = {xh[9], xh[10], xh[11]}, f_[3] = {xh[12], xh[13], xh[14]};
+    memcpy(ph[3][3], a_, 12); memcpy(ph[4][3], b_, 12); memcpy(ph[5][3], c_, 12);
+    memcpy(ph[3][4], b_, 12); memcpy(ph[4][4], d_, 12); memcpy(ph[5][4], e_, 12);
+    memcpy(ph[3][5], c_, 12); memcpy(ph[4][5], e_, 12); memcpy(ph[5][5], f_, 12);
+    double score_pt = 0;
+    memset(g_pt, 0, 6 * sizeof(double)); memset(h_pt, 0, 36 * sizeof(double));
+    for (int k = 0; k < nn; ++k) {
+        const leaf_t *cell = nb[k];
+        double xt[3] = {(double)tp[0] - cell->mean[0], (double)tp[1] - cell->mean[1], (double)tp[2] - cell->mean[2]};
+        float x4t[3] = {(float)xt[0], (float)xt[1], (float)xt[2]};
+        float ci[3][3];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) ci[r][c] = (float)cell->icov[r * 3 + c];
+        float xc[3];   /* x_trans4 * c_inv4 */
+        for (int c = 0; c < 3; ++c) { float s = x4t[0] * ci[0][c]; s += x4t[1] * ci[1][c]; s += x4t[2] * ci[2][c]; xc[c] = s; }
+        float dot = x4t[0] * xc[0]; dot += x4t[1] * xc[1]; dot += x4t[2] * xc[2];
+        float e = expf(-gauss_d2 * dot * 0.5f);
+        float score_inc = (float)(-gc->d1 * (double)e);
+        e = gauss_d2 * e;
+        if (e > 1 || e < 0 || e != e) continue;
+        e = (float)((double)e * gc->d1);
+        float cpg[3][6];  /* c_inv4 * point_gradient4 */
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 6; ++c) { float s = ci[r][0] * pg[0][c]; s += ci[r][1] * pg[1][c]; s += ci[r][2] * pg[2][c]; cpg[r][c] = s; }
+        float xcpg[6];
+        for (int c = 0; c < 6; ++c) { float s = x4t[0] * cpg[0][c]; s += x4t[1] * cpg[1][c]; s += x4t[2] * cpg[2][c]; xcpg[c] = s; }
+        for (int c = 0; c < 6; ++c) g_pt[c] += (double)(e * xcpg[c]);
+        if (compute_hessian) {
+            float pgcpg[6][6];  /* point_gradient4^T * c_inv4_x_point_gradient4 */
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { float s = pg[0][r] * cpg[0][c]; s += pg[1][r] * cpg[1][c]; s += pg[2][r] * cpg[2][c]; pgcpg[r][c] = s; }
+            for (int i = 0; i < 6; ++i) {
+                float xph[6];
+                for (int j = 0; j < 6; ++j) { float s = xc[0] * ph[i][j][0]; s += xc[1] * ph[i][j][1]; s += xc[2] * ph[i][j][2]; xph[j] = s; }
+                for (int j = 0; j < 6; ++j)
+                    h_pt[i * 6 + j] += (double)(e * (-gauss_d2 * xcpg[i] * xcpg[j] + xph[j] + pgcpg[j][i]));
+            }
+        }
+        score_pt += (double)score_inc;
+    }
+    *score_out = score_pt;
+}
+
+static __thread int g_ndt_threads = 1;      /* set per call from oracle_ndt_params.threads (the entry points below) */
+
 static double compute_derivatives(const ndt_grid *g, const float *src, size_t n, size_t stride, const float *trans, const double p[6],
                                   const gauss_t *gc, int compute_hessian, ang_t *ang, double grad[6], double hess[36])
 {
     memset(grad, 0, 6 * sizeof(double)); memset(hess, 0, 36 * sizeof(double));
     angle_derivatives(p, ang);
     double score = 0;
-    const float gauss_d2 = (float)gc->d2;
-    for (size_t idx = 0; idx < n; ++idx) {
-        const float *xp = src + idx * stride;
-        const float *tp = trans + idx * 3;
-        const leaf_t *nb[7];
-        int nn = neighborhood7(g, tp, nb);
-        /* computePointDerivatives, float (:399-440): x4 = (float)x */
-        float x4[3] = {(float)(double)xp[0], (float)(double)xp[1], (float)(double)xp[2]};
-        float pg[3][6];
-        memset(pg, 0, sizeof pg); pg[0][0] = pg[1][1] = pg[2][2] = 1.0f;
-        float xj[8], xh[15];
-        for (int r = 0; r < 8; ++r) { float s = ang->j_ang[r][0] * x4[0]; s += ang->j_ang[r][1] * x4[1]; s += ang->j_ang[r][2] * x4[2]; xj[r] = s; }
-        pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
-        for (int r = 0; r < 15; ++r) { float s = ang->h_ang[r][0] * x4[0]; s += ang->h_ang[r][1] * x4[1]; s += ang->h_ang[r][2] * x4[2]; xh[r] = s; }
-        /* point_hessian_ blocks: ph[i][j] = 3-vector for parameters (i,j), i,j in 3..5 */
-        float ph[6][6][3];
-        memset(ph, 0, sizeof ph);
-        const float a_[3] = {0, xh[0], xh[1]}, b_[3] = {0, xh[2], xh[3]}, c_[3] = {0, xh[4], xh[5]}, d_[3] = {xh[6], xh[7], xh[8]},
-                    e_[3] = {xh[9], xh[10], xh[11]}, f_[3] = {xh[12], xh[13], xh[14]};
-        memcpy(ph[3][3], a_, 12); memcpy(ph[4][3], b_, 12); memcpy(ph[5][3], c_, 12);
-        memcpy(ph[3][4], b_, 12); memcpy(ph[4][4], d_, 12); memcpy(ph[5][4], e_, 12);
-        memcpy(ph[3][5], c_, 12); memcpy(ph[4][5], e_, 12); memcpy(ph[5][5], f_, 12);
-        double score_pt = 0, g_pt[6] = {0}, h_pt[36] = {0};
-        for (int k = 0; k < nn; ++k) {
-            const leaf_t *cell = nb[k];
-            double xt[3] = {(double)tp[0] - cell->mean[0], (double)tp[1] - cell->mean[1], (double)tp[2] - cell->mean[2]};
-            float x4t[3] = {(float)xt[0], (float)xt[1], (float)xt[2]};
-            float ci[3][3];
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) ci[r][c] = (float)cell->icov[r * 3 + c];
-            float xc[3];   /* x_trans4 * c_inv4 */
-            for (int c = 0; c < 3; ++c) { float s = x4t[0] * ci[0][c]; s += x4t[1] * ci[1][c]; s += x4t[2] * ci[2][c]; xc[c] = s; }
-            float dot = x4t[0] * xc[0]; dot += x4t[1] * xc[1]; dot += x4t[2] * xc[2];
-            float e = expf(-gauss_d2 * dot * 0.5f);
-            float score_inc = (float)(-gc->d1 * (double)e);
-            e = gauss_d2 * e;
-            if (e > 1 || e < 0 || e != e) continue;
-            e = (float)((double)e * gc->d1);
-            float cpg[3][6];  /* c_inv4 * point_gradient4 */
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 6; ++c) { float s = ci[r][0] * pg[0][c]; s += ci[r][1] * pg[1][c]; s += ci[r][2] * pg[2][c]; cpg[r][c] = s; }
-            float xcpg[6];
-            for (int c = 0; c < 6; ++c) { float s = x4t[0] * cpg[0][c]; s += x4t[1] * cpg[1][c]; s += x4t[2] * cpg[2][c]; xcpg[c] = s; }
-            for (int c = 0; c < 6; ++c) g_pt[c] += (double)(e * xcpg[c]);
-            if (compute_hessian) {
-                float pgcpg[6][6];  /* point_gradient4^T * c_inv4_x_point_gradient4 */
-                for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { float s = pg[0][r] * cpg[0][c]; s += pg[1][r] * cpg[1][c]; s += pg[2][r] * cpg[2][c]; pgcpg[r][c] = s; }
-                for (int i = 0; i < 6; ++i) {
-                    float xph[6];
-                    for (int j = 0; j < 6; ++j) { float s = xc[0] * ph[i][j][0]; s += xc[1] * ph[i][j][1]; s += xc[2] * ph[i][j][2]; xph[j] = s; }
-                    for (int j = 0; j < 6; ++j)
-                        h_pt[i * 6 + j] += (double)(e * (-gauss_d2 * xcpg[i] * xcpg[j] + xph[j] + pgcpg[j][i]));
-                }
-            }
-            score_pt += (double)score_inc;
+    const int threads = g_ndt_threads > 1 ? g_ndt_threads : 1;
+    if (threads == 1 || n < 64) {
+        for (size_t idx = 0; idx < n; ++idx) {
+            double s_pt, g_pt[6], h_pt[36];
+            derivatives_point(g, src + idx * stride, trans + idx * 3, gc, compute_hessian, ang, &s_pt, g_pt, h_pt);
+            score += s_pt;
+            for (int c = 0; c < 6; ++c) grad[c] += g_pt[c];
+            for (int c = 0; c < 36; ++c) hess[c] += h_pt[c];
         }
-        score += score_pt;
-        for (int c = 0; c < 6; ++c) grad[c] += g_pt[c];
-        for (int c = 0; c < 36; ++c) hess[c] += h_pt[c];
+        return score;
     }
+    /* scores[idx], score_gradients[idx], hessians[idx] of :189-197, then the ordered sum of :277-282 */
+    const int w = compute_hessian ? 43 : 7;
+    double *per = (double *)malloc(n * (size_t)w * sizeof(double));
+    if (!per) { g_ndt_threads = 1; return compute_derivatives(g, src, n, stride, trans, p, gc, compute_hessian, ang, grad, hess); }
+#pragma omp parallel for num_threads(threads) schedule(guided, 8)
+    for (long long idx = 0; idx < (long long)n; ++idx) {
+        double s_pt, g_pt[6], h_pt[36];
+        derivatives_point(g, src + (size_t)idx * stride, trans + (size_t)idx * 3, gc, compute_hessian, ang, &s_pt, g_pt, h_pt);
+        double *o = per + (size_t)idx * w;
+        o[0] = s_pt;
+        for (int c = 0; c < 6; ++c) o[1 + c] = g_pt[c];
+        if (compute_hessian) for (int c = 0; c < 36; ++c) o[7 + c] = h_pt[c];
+    }
+    for (size_t idx = 0; idx < n; ++idx) {
+        const double *o = per + idx * w;
+        score += o[0];
+        for (int c = 0; c < 6; ++c) grad[c] += o[1 + c];
+        if (compute_hessian) for (int c = 0; c < 36; ++c) hess[c] += o[7 + c];
+    }
+    free(per);
     return score;
 }
 
@@ -551,6 +590,7 @@ static void euler_xyz_f(const float R[9], float out[3])
 int oracle_ndt_scan2map(const float *src, size_t n_src, const float *dst, size_t n_dst, size_t stride, double pose[16],
                         const oracle_ndt_params *prm, long info[3], double *final_score)
 {
+    g_ndt_threads = prm && prm->threads > 1 ? prm->threads : 1;
     ndt_ctx c; memset(&c, 0, sizeof c);
     ndt_grid *g = ndt_grid_build(dst, n_dst, stride, prm);
     c.g = g; c.src = src; c.n = n_src; c.stride = stride; c.gc = gauss_consts(prm);
@@ -598,6 +638,7 @@ int oracle_ndt_scan2map(const float *src, size_t n_src, const float *dst, size_t
 double oracle_ndt_derivatives(const float *src, size_t n_src, const float *dst, size_t n_dst, size_t stride, const double p[6],
                               const oracle_ndt_params *prm, double grad[6], double hess[36], double *hess_d)
 {
+    g_ndt_threads = prm && prm->threads > 1 ? prm->threads : 1;
     ndt_grid *g = ndt_grid_build(dst, n_dst, stride, prm);
     gauss_t gc = gauss_consts(prm);
     ang_t ang; float R[9], t[3];

@@ -221,3 +221,20 @@ def test_submap_oracle_selection_and_transform():
     ref, _ = oracle.voxel_filter(cat, 0.5)
     assert sub.shape == ref.shape
     np.testing.assert_allclose(sub, ref, rtol=0, atol=1e-5)
+
+
+def test_ndt_oracle_thread_count_invariance():
+    """computeDerivatives runs on `cores` threads in the reference (ndt_omp_impl.hpp:206) but adds the per-point results up serially
+    in point order (:277-282): the threaded oracle must return the serial oracle's numbers bit for bit."""
+    from simpleslam_amd import synth
+    world, m = synth.make_map(40_000, seed=11)
+    scan, T = synth.make_scan(world, 0, seed=11, beams=16, azimuths=256)
+    T0 = synth.perturb(T, 3, trans=0.1, rot_deg=0.5)
+    p1, c1, i1 = oracle.ndt_scan2map(scan, m, T0, oracle.ndt_params(threads=1))
+    for th in (2, 4):
+        p, c, i = oracle.ndt_scan2map(scan, m, T0, oracle.ndt_params(threads=th))
+        assert c == c1 and i == i1
+        assert np.array_equal(p, p1)
+    d1 = oracle.ndt_derivatives(scan, m, [0.1, 0.0, 0.05, 0.01, -0.02, 0.03], oracle.ndt_params(threads=1))
+    d4 = oracle.ndt_derivatives(scan, m, [0.1, 0.0, 0.05, 0.01, -0.02, 0.03], oracle.ndt_params(threads=4))
+    assert d1["score"] == d4["score"] and np.array_equal(d1["grad"], d4["grad"]) and np.array_equal(d1["hess"], d4["hess"])
