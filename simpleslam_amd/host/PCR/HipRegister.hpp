@@ -12,7 +12,10 @@
 #include <utility>
 #include <vector>
 
+#include <cstdio>
+
 #include "../../../include/pcr_hip.h"
+#include "../config/params.hpp"
 
 namespace PCR {
 
@@ -42,9 +45,16 @@ struct pose_t {                                // Eigen::Isometry3d: 4x4 column-
 class PointCloudRegister {
 protected:
     bool isConverge = false;
-    int cores = 1;                             // cfg["cores"]: OpenMP team of the CPU reference; unused on the GPU
+    int cores = 1;                             // cfg["cores"]: OpenMP team of the CPU reference; the GPU path has no use for it
+    std::string lastError_;
+    // the reference logs through its spdlog singleton (`this->lg->error(...)`, LoamRegister.cpp:174); here: stderr
+    void logError(const std::string& msg) { lastError_ = msg; std::fprintf(stderr, "[error] %s\n", msg.c_str()); }
 public:
     using Ptr = std::shared_ptr<PointCloudRegister>;
+    // PointCloudRegister.hpp:28-32: `cores = cfg["cores"].get<int>()` -- when a configuration has been loaded (config::Params::load)
+    PointCloudRegister() { if (config::Params::loaded()) cores = config::Params::getInstance()["cores"].get<int>(); }
+    int getCores() const { return cores; }
+    const std::string& lastError() const { return lastError_; }
     virtual scalar_t getFitnessScore() { return 0; }
     virtual bool scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res) = 0;
     virtual ~PointCloudRegister() {}
@@ -64,20 +74,29 @@ public:
     HipRegister& operator=(const HipRegister&) = delete;
     ~HipRegister() override { pcr_destroy(h_); }
 
+    // Error behaviour of the reference: scan2Map never throws -- it logs and returns false (LoamRegister.cpp:173-176,222; `res` keeps
+    // what the iterations had reached, here the caller's guess).  lastError() holds the library's message.
     bool scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res) override {
         int conv = 0;
-        if (pcr_scan2map(h_, src->points.data(), src->size(), dst->points.data(), dst->size(), sizeof(PointXYZI), res.data(), &conv))
-            throw std::runtime_error(pcr_last_error(h_));
+        if (pcr_scan2map(h_, src->points.data(), src->size(), dst->points.data(), dst->size(), sizeof(PointXYZI), res.data(), &conv)) {
+            logError(pcr_last_error(h_));
+            return isConverge = false;
+        }
+        lastError_.clear();
         isConverge = conv != 0;
         return isConverge;
     }
-    // static-map localisation (test/loc.cpp): index the map once
+    // static-map localisation (test/loc.cpp): index the map once.  (No counterpart in the reference's interface: failures throw.)
     void setTarget(const PC_cPtr& dst) {
         if (pcr_set_target(h_, dst->points.data(), dst->size(), sizeof(PointXYZI), 0)) throw std::runtime_error(pcr_last_error(h_));
     }
     bool align(const PC_cPtr& src, pose_t& res) {
         int conv = 0;
-        if (pcr_align(h_, src->points.data(), src->size(), sizeof(PointXYZI), 0, res.data(), &conv)) throw std::runtime_error(pcr_last_error(h_));
+        if (pcr_align(h_, src->points.data(), src->size(), sizeof(PointXYZI), 0, res.data(), &conv)) {
+            logError(pcr_last_error(h_));
+            return isConverge = false;
+        }
+        lastError_.clear();
         isConverge = conv != 0;
         return isConverge;
     }
@@ -128,7 +147,11 @@ inline bool HipRegister::scan2Map(const PC_cPtr& src, const SubMap& dst, pose_t&
     // The handle keeps the target structures it builds from the sub-map for as long as the map stays at the same generation
     // (pcr_scan2map_submap): LidarOdometry registers several scans between two MapManager::updateMap calls.
     int conv = 0;
-    if (pcr_scan2map_submap(h_, src->points.data(), src->size(), 0, dst.handle(), res.data(), &conv)) throw std::runtime_error(pcr_last_error(h_));
+    if (pcr_scan2map_submap(h_, src->points.data(), src->size(), 0, dst.handle(), res.data(), &conv)) {
+        logError(pcr_last_error(h_));
+        return isConverge = false;
+    }
+    lastError_.clear();
     isConverge = conv != 0;
     return isConverge;
 }

@@ -1,6 +1,6 @@
 // align_harness.cpp -- ROS/PCL-free counterpart of the reference's test/align.cpp:
-//   align_harness <target.f32> <source.f32> <loam|ndt|vgicp> [init_pose.txt]
-// loads two clouds (raw float32 x y z intensity records instead of PCDs), reads the optional initial pose (4x4 row-major text,
+//   align_harness <target.pcd|.f32> <source.pcd|.f32> <loam|ndt|vgicp> [init_pose.txt]
+// loads two clouds (PCD files as align.cpp:97-107 does -- pcp/pcd_io.hpp -- or raw float32 x y z intensity records), reads the optional initial pose (4x4 row-major text,
 // align.cpp:85-93), voxel-filters BOTH clouds at 0.1 m (align.cpp:128-129), runs ONE scan2Map through the plugin mirror
 // (align.cpp:144), and prints what align.cpp logs: the cloud sizes before and after the filter, the elapsed time, the gated
 // fitness score (mean squared nearest-neighbour distance over the points within 1 m, align.cpp:29-61) and the final 4x4.
@@ -11,8 +11,15 @@
 #include <string>
 
 #include "PCR/HipRegister.hpp"
+#include "pcp/pcd_io.hpp"
 
 static PCR::PC_Ptr load(const char* path) {
+    const std::string name = path;
+    if (name.size() >= 4 && name.compare(name.size() - 4, 4, ".pcd") == 0) {
+        auto pc = std::make_shared<PCR::PointCloud>();
+        if (pcp::loadPCDFile(name, *pc) == -1) throw std::runtime_error(std::string("failed to load: ") + path);      // align.cpp:98-101
+        return pc;
+    }
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error(std::string("failed to load: ") + path);
     auto pc = std::make_shared<PCR::PointCloud>();

@@ -134,3 +134,75 @@ def test_kdtree_bench_reports_build_and_query_times(gpu, world_small, tmp_path):
     assert a.startswith(f"grid index: {w['map'].shape[0]} points, build") and float(a.split()[-2]) > 0
     assert f"{w['map'].shape[0]} queries" in b and "ns/query" in b
     assert int(b.split()[-4]) > 0.8 * w["map"].shape[0]                         # most map points find 5 neighbours within 1 m among the map
+
+
+def _pose_of(stdout):
+    return np.array([[float(v) for v in ln.split()] for ln in stdout.strip().splitlines()[-4:]])
+
+
+def test_loc_harness_reads_params_json_and_pcd_at_config1_sizes(gpu, world_100k, tmp_path):
+    """`loc_harness params.json scan.pcd init.txt` -- what test/loc.cpp reads (cores, downSampleVoxelGridSize, pcd_file, frontend.pcr;
+    a PCD map, MapManager.cpp:68) -- at BASELINE configs[0]'s sizes (65 536 x 100 k, pcr = loam, cores = 1): the pose of the Python
+    mirror bit for bit, the oracle's within the north-star tolerance."""
+    import oracle
+    from simpleslam_amd import synth
+    from tests import loc_inputs
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    w = world_100k
+    loc_inputs.write_pcd(tmp_path / "map.pcd", w["map"], "binary_pcl")           # the padded 32-byte records PCL itself writes
+    loc_inputs.write_pcd(tmp_path / "scan.pcd", w["scan"], "binary")
+    loc_inputs.write_params(tmp_path / "params.json", tmp_path / "map.pcd", pcr="loam", cores=1, grid=0.5)
+    np.savetxt(tmp_path / "init.txt", w["init"], fmt="%.17g")
+    out = subprocess.run([exe, str(tmp_path / "params.json"), str(tmp_path / "scan.pcd"), str(tmp_path / "init.txt"), "--no-downsample"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    first = out.stdout.strip().splitlines()[0]
+    assert first.startswith("pcr loam  cores 1  grid 0.5  map 100000 -> 100000  scan 65536 -> 65536  converged 1"), first
+    pose_cpp = _pose_of(out.stdout)
+    pose_py = w["init"].copy()
+    assert LoamRegister().scan2Map(w["scan"], w["map"], pose_py)
+    np.testing.assert_array_equal(pose_cpp, pose_py)
+    ref, conv, _ = oracle.loam_scan2map(w["scan"], w["map"], w["init"], oracle.loam_params(threads=1))
+    dt, dr = synth.pose_error(pose_cpp, ref)
+    assert conv and dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+
+
+@pytest.mark.parametrize("method", ["loam", "ndt", "vgicp"])
+def test_loc_harness_downsamples_like_the_frontend(gpu, world_small, tmp_path, method):
+    """the default flow of test/loc.cpp: map voxel-filtered at downSampleVoxelGridSize when it is loaded (MapManager.cpp:78), the scan
+    before every registration (LidarOdometry.cpp:170-171), the registrar chosen by frontend.pcr (LidarOdometry.cpp:44-54)"""
+    from simpleslam_amd import make_register
+    from tests import loc_inputs
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    w = world_small
+    loc_inputs.write_pcd(tmp_path / "map.pcd", w["map"], "ascii")
+    loc_inputs.write_pcd(tmp_path / "scan.pcd", w["scan"], "binary_compressed")
+    loc_inputs.write_params(tmp_path / "params.json", tmp_path / "map.pcd", pcr=method, cores=4, grid=0.4)
+    np.savetxt(tmp_path / "init.txt", w["init"], fmt="%.17g")
+    out = subprocess.run([exe, str(tmp_path / "params.json"), str(tmp_path / "scan.pcd"), str(tmp_path / "init.txt")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    reg = make_register(method)
+    # (the ascii PCD holds %.9g decimals: they read back to the same floats)
+    m_ds, s_ds = reg.voxelDownSample(w["map"][:, :4].copy(), 0.4), reg.voxelDownSample(w["scan"][:, :4].copy(), 0.4)
+    first = out.stdout.strip().splitlines()[0]
+    assert f"pcr {method}  cores 4" in first and f"map {w['map'].shape[0]} -> {m_ds.shape[0]}  scan {w['scan'].shape[0]} -> {s_ds.shape[0]}" in first, first
+    # the harness hands 32-byte pcl::PointXYZI records over, the arrays here are 16-byte rows: same coordinates, same pose
+    pose_py = w["init"].copy()
+    conv = reg.scan2Map(s_ds, m_ds, pose_py)
+    assert f"converged {int(conv)}" in first
+    np.testing.assert_array_equal(_pose_of(out.stdout), pose_py)
+
+
+def test_loc_harness_refuses_an_unknown_pcr_and_a_missing_map(gpu, world_small, tmp_path):
+    from tests import loc_inputs
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    w = world_small
+    loc_inputs.write_pcd(tmp_path / "scan.pcd", w["scan"], "binary")
+    np.savetxt(tmp_path / "init.txt", w["init"], fmt="%.17g")
+    loc_inputs.write_params(tmp_path / "p1.json", tmp_path / "scan.pcd", pcr="icp")
+    bad = subprocess.run([exe, str(tmp_path / "p1.json"), str(tmp_path / "scan.pcd"), str(tmp_path / "init.txt")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "such pcr type(icp) is not exist" in bad.stderr            # LidarOdometry.cpp:50-54
+    loc_inputs.write_params(tmp_path / "p2.json", tmp_path / "nowhere.pcd", pcr="loam")
+    bad = subprocess.run([exe, str(tmp_path / "p2.json"), str(tmp_path / "scan.pcd"), str(tmp_path / "init.txt")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "can't load globalmap from" in bad.stderr                   # MapManager.cpp:68-73
