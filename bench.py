@@ -481,7 +481,7 @@ def main():
         import threading
         from simpleslam_amd import pcr as _pcr
         prm = _pcr.default_params(device=local_rank, loam_iters=args.iters, loam_early_exit=0)
-        prm.reserved[4] = 1          # the two-waves-per-SIMD variant of the iterate kernel: blocks of different handles share the CUs
+        prm.loam_coresident = 1          # the two-waves-per-SIMD variant of the iterate kernel: blocks of different handles share the CUs
         regs = [LoamRegister(params=prm) for _ in range(args.streams)]
         per = max(1, args.steps // args.streams)
         for r in regs:
@@ -503,7 +503,7 @@ def main():
         torch.cuda.synchronize()
         ct = time.perf_counter() - c0
         out["concurrent"] = {"streams": args.streams, "value": per * args.streams / ct, "unit": "scans/s",
-                             "scans": per * args.streams, "note": "independent handles (pcr_params.reserved[4] = 1), one stream and one host thread each, same GPU"}
+                             "scans": per * args.streams, "note": "independent handles (pcr_params.loam_coresident = 1), one stream and one host thread each, same GPU"}
     # ---- roofline of the dominant kernel (loam_iterate_kernel), live, HIP events on its stream.  Rank 0 reports it; with a sharded
     #      map every rank has to take part in the calls (each one is a chain of collectives) ----
     k_ms, k_n, idx_ms, tot_ms = 0.0, 0, 0.0, 0.0

@@ -67,20 +67,25 @@ typedef struct pcr_params {
     double vgicp_lm_init_scale;/* 1e-9 */
 
     int32_t record_trace;      /* 1: keep per-iteration normal equations for pcr_get_trace */
-    /* reserved[]: all zero by default.  Development switches of the LOAM path (results are unchanged except where noted):
-     *   [0] ablation mask for profiling (only in a -DPCR_ABLATION build; results become meaningless)
-     *   [1] = 1: NDT: every request of the line search becomes an evaluation pass, also one at the point just evaluated (what the
-     *            reference does; by default such a request is answered from the sums already held -- same numbers, see csrc/ndt_opt.h)
-     *   [2] = 1: disable the temporal-coherence neighbour cache          [3] = 1: record the in-kernel timeline (pcr_get_timeline)
-     *   [4] = 1: two-waves-per-SIMD variant of the iterate kernel -- ~3 % slower for one handle, ~25 % more scans/s when
-     *            several handles register scans concurrently on one GPU (their blocks can then share the CUs)
-     *   [5] != 0: first margin, in millimetres, of the region a LOAM target too sparse for the dense index is cut to around the
-     *            scan (default 10 m; it grows whenever a query reaches a cut face -- a test hook for that path: a negative value
-     *            cuts into the scan's own box, so that the first attempts must be widened)
-     *   [6] = 1: NDT, VGICP: drive the optimiser from the host (one round trip per evaluation pass) instead of on the device; the
-     *            path handles sharded over a host-supplied collective always take.  Same state machines (csrc/ndt_opt.h,
-     *            csrc/vgicp_opt.h), same result to rounding. */
-    int32_t reserved[7];
+
+    /* ---- switches (all 0 by default; none of them changes a result except where noted).  The library reads NO environment
+     * variable: what used to be PCR_* variables and pcr_params.reserved[] are these fields, or exist only in a development build
+     * (make DEV=1, csrc/pcr_internal.h: dev_env). ---- */
+    int32_t index_no_hints;    /* 1: every target index is built from scratch -- fresh bounding box, no tile layout taken over from the
+                                *    previous build of this handle (three build launches instead of two; no state crosses calls) */
+    int32_t ndt_evaluate_repeats; /* 1: NDT: every request of the line search becomes an evaluation pass, also one at the point just
+                                *    evaluated (what the reference does; by default such a request is answered from the sums already
+                                *    held -- same numbers, csrc/ndt_opt.h) */
+    int32_t loam_disable_cache;/* 1: LOAM: no temporal-coherence neighbour cache, every iteration searches (same result bit for bit) */
+    int32_t record_timeline;   /* 1: LOAM: record the in-kernel timeline of every launch (pcr_get_timeline) */
+    int32_t loam_coresident;   /* 1: LOAM: the two-waves-per-SIMD variant of the iterate kernel -- ~3 % slower for one handle, ~25 % more
+                                *    scans/s when several handles register scans concurrently on one GPU (their blocks share the CUs) */
+    int32_t loam_clamp_margin_mm; /* != 0: LOAM: first margin, in millimetres, of the region a target too sparse for the dense index is
+                                *    cut to around the scan (default 10 m; it grows whenever a query reaches a cut face).  Negative values cut
+                                *    into the scan's own box: a test hook that makes the widening path reachable with ordinary clouds */
+    int32_t host_optimiser;    /* 1: NDT, VGICP: drive the optimiser from the host (one round trip per evaluation pass) instead of on the
+                                *    device; the path handles sharded over a host-supplied collective always take.  Same state machines
+                                *    (csrc/ndt_opt.h, csrc/vgicp_opt.h), same result to rounding */
 } pcr_params;
 
 /* Per-call device timings, from HIP events on the handle's stream. */
@@ -264,7 +269,7 @@ int pcr_vgicp_opt_request(const pcr_vgicp_opt* o, int* kind, double pose_eval[16
 int pcr_vgicp_opt_feed(pcr_vgicp_opt* o, const double sums[29]);
 int pcr_vgicp_opt_result(const pcr_vgicp_opt* o, double pose16[16], int* converged, int* outer_iterations, int* done);
 
-/* Profiling aid: with pcr_params.reserved[3] = 1 thread 0 of every linearisation block records seven
+/* Profiling aid: with pcr_params.record_timeline = 1 thread 0 of every linearisation block records seven
  * s_memrealtime stamps (100 MHz ticks): entry, prologue done, misses posted, search done, plane+cache done,
  * accumulation done, partial sums stored (+ the fold inside the prologue and three stamps of the dense search).  out receives
  * [launches][blocks][16] u64; call with out = NULL to size it. */

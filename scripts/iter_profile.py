@@ -1,5 +1,5 @@
 """Per-iteration view of one LOAM scan2map (65 536 x 1 M, 10 iterations): cache hits / searches per linearisation (trace) and the
-in-kernel timeline of every launch (pcr_params.reserved[3] = 1)."""
+in-kernel timeline of every launch (pcr_params.record_timeline = 1)."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import torch
@@ -17,7 +17,7 @@ print('accepted rows  ', tr['n'])
 print('cache hits     ', tr['cache_hits'])
 print('searches       ', tr['searches'])
 p = pcr.default_params(loam_iters=10, loam_early_exit=0)
-p.reserved[3] = 1
+p.record_timeline = 1
 reg = LoamRegister(params=p)
 for i in range(3):
     pose = T0.copy(); reg.scan2Map(ds, dm, pose)

@@ -1,6 +1,6 @@
-"""searched-stage duration of the first (full-search) launch under the ablation masks of pcr_params.reserved[0].
-Needs a library built with the switches compiled in:  make -C simpleslam_amd/csrc clean all EXTRA=-DPCR_ABLATION"""
-import sys, numpy as np
+"""searched-stage duration of the first (full-search) launch under the ablation masks (environment variable PCR_ABLATE of a DEVELOPMENT build).
+Needs a library built with the switches compiled in:  make -C simpleslam_amd/csrc clean all DEV=1 EXTRA=-DPCR_ABLATION"""
+import os, sys, numpy as np
 sys.path.insert(0, '.')
 import torch
 from simpleslam_amd import LoamRegister, synth, pcr
@@ -11,7 +11,7 @@ T0 = synth.perturb(T, S)
 dm, ds = torch.from_numpy(m).cuda(), torch.from_numpy(scan).cuda()
 for mask, what in ((0, 'full'), (32, 'distance only (no insertion)'), (16, 'loads only (no distance, no insertion)'), (1, 'no search at all')):
     p = pcr.default_params(loam_iters=3, loam_early_exit=0)
-    p.reserved[3] = 1; p.reserved[0] = mask
+    p.record_timeline = 1; os.environ["PCR_ABLATE"] = str(mask)
     reg = LoamRegister(params=p)
     for i in range(3):
         pose = T0.copy()

@@ -1,4 +1,4 @@
-"""In-kernel timeline of loam_iterate_kernel (pcr_params.reserved[3] = 1): where the microseconds of one launch go."""
+"""In-kernel timeline of loam_iterate_kernel (pcr_params.record_timeline = 1): where the microseconds of one launch go."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import torch
@@ -8,7 +8,7 @@ w, m = synth.make_map(1_000_000, seed=S)
 scan, T = synth.make_scan(w, 0, seed=S)
 T0 = synth.perturb(T, S)
 p = pcr.default_params(loam_iters=10, loam_early_exit=0)
-p.reserved[3] = 1
+p.record_timeline = 1
 reg = LoamRegister(params=p)
 dm, ds = torch.from_numpy(m).cuda(), torch.from_numpy(scan).cuda()
 for i in range(3):

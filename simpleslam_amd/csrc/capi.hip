@@ -237,10 +237,10 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
     h->last_blocks = a->n_partials;
     a->trace = h->prm.record_trace ? h->loam_trace.as<LoamTrace>() : nullptr;
     a->result = h->result_dev;
-    a->ablate = h->prm.reserved[0];
-    a->coresident = h->prm.reserved[4] == 1;
-    if (h->prm.reserved[2] == 0 && h->nn_cache.reserve((n_src + 1) * 192) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
-    if (h->prm.reserved[3] == 1 && h->timeline.reserve((size_t)(std::max(1, h->prm.loam_iters) + 1) * kMaxPartials * kTimelineSlots * sizeof(unsigned long long)) == hipSuccess)
+    a->ablate = dev_env("PCR_ABLATE") ? atoi(dev_env("PCR_ABLATE")) : 0;      // (only a -DPCR_ABLATION development build looks at it)
+    a->coresident = h->prm.loam_coresident == 1;
+    if (h->prm.loam_disable_cache == 0 && h->nn_cache.reserve((n_src + 1) * 192) == hipSuccess) a->nn_cache = (NnCacheEntry*)h->nn_cache.p;
+    if (h->prm.record_timeline == 1 && h->timeline.reserve((size_t)(std::max(1, h->prm.loam_iters) + 1) * kMaxPartials * kTimelineSlots * sizeof(unsigned long long)) == hipSuccess)
         a->timeline = h->timeline.as<unsigned long long>();
     a->use_tile = h->use_tile;
     for (int d = 0; d < 3; ++d) { a->tile_lo[d] = h->tile_lo[d]; a->tile_hi[d] = h->tile_hi[d]; }
@@ -249,7 +249,8 @@ void fill_loam_args(pcr_handle* h, LoamArgs* a, const float* d_src, size_t n_src
 int build_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
     double cell = 1.0;
     if (h->method == kLoam) cell = grid_cell_for(h->prm.loam_knn_max_sq);
-    // (the bounding box of the previous target is tried first: GridIndex::hint_ok)
+    // (the bounding box of the previous target is tried first: GridIndex::hint_ok -- unless pcr_params.index_no_hints)
+    h->grid.no_hints = h->prm.index_no_hints != 0;
     hipError_t e = h->grid.build(d_dst, n_dst, stride_floats, cell, h->stream, &h->err, 0.0, 0, h->clamp.use ? &h->clamp : nullptr, h->method == kLoam);
     if (e != hipSuccess) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
@@ -364,9 +365,9 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
     if (ensure_loam_buffers(h)) return 1;
     const int iters = std::max(0, h->prm.loam_iters);
     const bool shard = sharded(h);
-    // (pcr_params.reserved[5]: first margin in millimetres, a test hook that makes the widening path reachable with ordinary clouds)
+    // (pcr_params.loam_clamp_margin_mm: first margin in millimetres, a test hook that makes the widening path reachable with ordinary clouds)
     // (may be negative: the scan's box is padded by two index cells already, so only a region cut INTO the scan makes queries reach its edge)
-    h->clamp_margin = h->prm.reserved[5] != 0 ? 1e-3 * h->prm.reserved[5] : kClampMargin;
+    h->clamp_margin = h->prm.loam_clamp_margin_mm != 0 ? 1e-3 * h->prm.loam_clamp_margin_mm : kClampMargin;
     const double margin_cap = kClampMargin * (1 << kClampRetries);
     for (int attempt = 0; attempt < 24; ++attempt) {
         bool rank_fail = false;
@@ -552,8 +553,8 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
 // of its points -- three blocks sorted the whole scan, 120 us -- and each level is an index build on the side stream; A/B of the
 // whole scan2map on one box: 3 x 4: 0.906 ms, 2 x 4: 0.917, 2 x 5: 0.890, 2 x 6: 0.875, 2 x 7: 0.900, 2 x 8: 0.880, 3 x 6: 0.975, 2 x 12: 1.25.
 // (PCR_COV_LEVELS / PCR_COV_RATIO override for such runs.)
-static int cov_levels_small() { static const int v = getenv("PCR_COV_LEVELS") ? atoi(getenv("PCR_COV_LEVELS")) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }
-static double cov_ratio() { static const double v = getenv("PCR_COV_RATIO") ? atof(getenv("PCR_COV_RATIO")) : 6.0; return v; }
+static int cov_levels_small() { static const int v = dev_env("PCR_COV_LEVELS") ? atoi(dev_env("PCR_COV_LEVELS")) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }
+static double cov_ratio() { static const double v = dev_env("PCR_COV_RATIO") ? atof(dev_env("PCR_COV_RATIO")) : 6.0; return v; }
 int cov_levels(size_t n) { return n <= 300000 ? cov_levels_small() : 1; }
 
 int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats);
@@ -685,7 +686,7 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     h->clamp.use = 0;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats;
     // (unsharded: a cloud too spread out for dense tables is cut to its bulk, settle_cov_levels; a rank of a sharded call refuses it)
-    static const bool no_ahead = getenv("PCR_COV_NO_AHEAD") != nullptr;      // (A/B runs)
+    static const bool no_ahead = dev_env("PCR_COV_NO_AHEAD") != nullptr;      // (A/B runs)
     bool ahead_ok = false;
     const double ahead_cell = (!no_ahead && cov_levels(n_dst) == 1 && h->cov_scale_hint >= 1.3) ? res * h->cov_scale_hint : 0.0;
     if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h), ahead_cell, &ahead_ok)) return 1;
@@ -780,8 +781,8 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     bool conv = false;
     h->vg_outer = h->vg_lin = h->vg_err = 0;
     // ---- device-resident loop (vgicp_opt.h): launches are enqueued ahead of the device, the host watches a progress word.  Not for
-    // sharded targets (every pass's sums cross the ranks) and not when pcr_params.reserved[6] asks for the host loop below ----
-    const bool on_device = n_src > 0 && !shard && h->prm.reserved[6] == 0 && h->prm.vgicp_max_iters > 0;
+    // sharded targets (every pass's sums cross the ranks) and not when pcr_params.host_optimiser asks for the host loop below ----
+    const bool on_device = n_src > 0 && !shard && h->prm.host_optimiser == 0 && h->prm.vgicp_max_iters > 0;
     if (on_device) {
         if (!h->vg_out_host) {
             H_TRY(hipHostMalloc((void**)&h->vg_out_host, sizeof(VgOut), hipHostMallocMapped));
@@ -902,6 +903,7 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
     if (!(res > 0)) return fail(h, "ndt_resolution must be positive");
     // the voxel lattice is VoxelGridCovariance's own (leaf index = floor(p * inverse_leaf) - min_b in float,
     // voxel_grid_covariance_omp_impl.hpp:218-220): GridHeader.pcl_mode, no pad cells
+    h->grid.no_hints = h->prm.index_no_hints != 0;
     if (deferred) {
         if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true) != hipSuccess) return 1;
     } else if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
@@ -1016,12 +1018,12 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     int conv = 0, nr_it = 0;
     double score = 0;
     // ---- device-resident loop: passes are enqueued ahead of the device, the host watches a progress word.  Not for sharded
-    // targets (every pass's sums cross the ranks through the host) and not when pcr_params.reserved[6] asks for the host loop ----
+    // targets (every pass's sums cross the ranks through the host) and not when pcr_params.host_optimiser asks for the host loop ----
     // Sharded over RCCL the loop stays on the device as well: fold -> ncclAllReduce on the handle's stream -> controller step, in
     // batches of a fixed number of passes -- whether another batch is due is decided from the controller state the ranks share, so
     // every rank enqueues the same collectives.  (A host-supplied collective needs the host in every pass: the host loop below.)
-    const bool dev_sharded = sharded(h) && h->comm && !h->host_ar && n_src > 0 && h->prm.reserved[6] == 0;
-    bool on_device = n_src > 0 && !sharded(h) && h->prm.reserved[6] == 0;
+    const bool dev_sharded = sharded(h) && h->comm && !h->host_ar && n_src > 0 && h->prm.host_optimiser == 0;
+    bool on_device = n_src > 0 && !sharded(h) && h->prm.host_optimiser == 0;
     h->nd_grid_checked = false; h->nd_grid_bad = false;
     bool sharded_done = false;
     if (dev_sharded) {
@@ -1030,7 +1032,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         H_TRY(h->nd_sums.reserve(64 * sizeof(double)));
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.reserved[1]));
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4, kBatch = 6;
         const volatile double* f_batch = &out->batch;
         for (int batch = 1, enq = 0;; ++batch) {
@@ -1061,12 +1063,12 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         NdtOut* out = h->nd_out_host;
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.reserved[1]));
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 5;        // an iteration takes at most 1 + 10 + 1 passes; one launch more finishes
         if ((double)limit >= kProgressWindow) return fail(h, "ndt_max_iters exceeds the device loop's pass window (2^20 passes)");
         int enq = 0;
         const int first = 3;      // (the host enqueues a pass in a quarter of the time the device needs for one: it only has to stay two ahead)
-        static const bool two_launches = getenv("PCR_NDT_TWO_LAUNCHES") != nullptr;      // the round's earlier form (pass kernel + fold/controller kernel), for A/B runs
+        static const bool two_launches = dev_env("PCR_NDT_TWO_LAUNCHES") != nullptr;      // the round's earlier form (pass kernel + fold/controller kernel), for A/B runs
         auto launch = [&](int index) -> hipError_t {
             if (two_launches) return ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq);
             return ndt_launch_pass_pro(r.a, d_ctl, h->nd_partials.as<double>(), h->nd_out_dev, h->stream, seq, index);
@@ -1095,7 +1097,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         h->nd_last_passes = out->passes;
-        if (getenv("PCR_NDT_TICKS")) fprintf(stderr, "ndt passes %d: fold %.2f us/pass, controller %.2f us/pass (decide %.2f, tables %.2f)\n", out->passes, out->ticks[0] * 0.01 / std::max(1, out->passes), out->ticks[1] * 0.01 / std::max(1, out->passes), out->ticks[2] * 0.01 / std::max(1, out->passes), out->ticks[3] * 0.01 / std::max(1, out->passes));
+        if (dev_env("PCR_NDT_TICKS")) fprintf(stderr, "ndt passes %d: fold %.2f us/pass, controller %.2f us/pass (decide %.2f, tables %.2f)\n", out->passes, out->ticks[0] * 0.01 / std::max(1, out->passes), out->ticks[1] * 0.01 / std::max(1, out->passes), out->ticks[2] * 0.01 / std::max(1, out->passes), out->ticks[3] * 0.01 / std::max(1, out->passes));
         h->nd_grid_bad = out->grid_overflow || out->grid_stale;
         h->nd_grid_empty = out->grid_empty != 0;
         h->nd_grid_cells = out->grid_cells;
@@ -1110,7 +1112,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     if (!on_device && !sharded_done) {
         NdtCtl c;
         ctl_init(&c, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters);
-        c.replay_off = (getenv("PCR_NDT_NO_REPLAY") || h->prm.reserved[1]) ? 1 : 0;
+        c.replay_off = h->prm.ndt_evaluate_repeats ? 1 : 0;
         double sums[43];
         while (!c.done) {
             if (n_src == 0) memset(sums, 0, sizeof sums);        // an empty scan: computeDerivatives sums nothing
@@ -1167,7 +1169,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         // NdtRegister::scan2Map calls setInputTarget every time, which rebuilds the voxel grid (NdtRegister.cpp:23)
         // Unsharded: the index is enqueued unchecked (previous box as a hint, cell table as it is) and the alignment's own result
         // says whether that held; if not, once more with the checked build.
-        const bool try_deferred = !sharded(h) && n_src > 0 && h->prm.reserved[6] == 0;
+        const bool try_deferred = !sharded(h) && n_src > 0 && h->prm.host_optimiser == 0;
         double pose_in[16];
         memcpy(pose_in, pose, sizeof pose_in);
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1740,7 +1742,7 @@ int pcr_get_trace_counts(pcr_handle* h, int64_t* cache_hits, int64_t* searches) 
 
 int pcr_get_timeline(pcr_handle* h, uint64_t* out, size_t capacity, int* launches, int* blocks) {
     if (!h) return 1;
-    if (h->prm.reserved[3] != 1 || !h->timeline.p) return fail(h, "timeline not recorded: set pcr_params.reserved[3] = 1");
+    if (h->prm.record_timeline != 1 || !h->timeline.p) return fail(h, "timeline not recorded: set pcr_params.record_timeline = 1");
     const int nl = std::max(1, h->prm.loam_iters), nb = (int)h->last_blocks;
     if (launches) *launches = nl;
     if (blocks) *blocks = nb;

@@ -714,7 +714,7 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift,
                             int pcl_mode, const ClampBox* clamp, bool allow_hint) {
     valid = false;
-    const bool force_atomic_path = getenv("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
+    const bool force_atomic_path = dev_env("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
     PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
@@ -753,11 +753,11 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     int tshift;
     if (cells_hint) { tshift = 2; while ((cells_hint >> tshift) > tiles_target && tshift < 11) ++tshift; }
     else { tshift = 8; while (((uint64_t)cap_eff >> tshift) + 2 > 2048 && tshift < 11) ++tshift; }
-    if (const char* e = getenv("PCR_TILE_SHIFT")) tshift = std::max(2, atoi(e));      // (development: tile size sweep)
+    if (const char* e = dev_env("PCR_TILE_SHIFT")) tshift = std::max(2, atoi(e));      // (development: tile size sweep)
     while (((uint64_t)cap_eff >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
     const bool tiled_path = tshift <= kMaxTileShift && !force_atomic_path;
-    if (getenv("PCR_INDEX_DEBUG")) fprintf(stderr, "index build: n %zu cell %.3g capacity %zu cells_hint %llu cap_eff %zu tshift %d hint_ok %d lay_ok %d\n", n, cell, cell_capacity, (unsigned long long)cells_hint, cap_eff, tshift, (int)hint_ok, (int)lay_ok);
-    const bool reuse_header = allow_hint && hint_ok && tiled_path && hint_pcl == pcl_mode && hint_shift == shift && !cb.use && hint_cell == cell && tiled_shift == tshift;
+    if (dev_env("PCR_INDEX_DEBUG")) fprintf(stderr, "index build: n %zu cell %.3g capacity %zu cells_hint %llu cap_eff %zu tshift %d hint_ok %d lay_ok %d\n", n, cell, cell_capacity, (unsigned long long)cells_hint, cap_eff, tshift, (int)hint_ok, (int)lay_ok);
+    const bool reuse_header = allow_hint && !no_hints && hint_ok && tiled_path && hint_pcl == pcl_mode && hint_shift == shift && !cb.use && hint_cell == cell && tiled_shift == tshift;
     hint_ok = false;      // until the host has seen this build's header (confirm())
     used_hint = reuse_header;
     hint_cell = cell; hint_shift = shift; hint_pcl = pcl_mode;
@@ -780,14 +780,14 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         }
         const bool vec = (stride_floats % 4 == 0) && ((uintptr_t)d_pts % 16 == 0);
         int bin_per = kBinPerDefault;
-        if (const char* e = getenv("PCR_BIN_PER")) bin_per = atoi(e);      // (development: chunk size sweep)
+        if (const char* e = dev_env("PCR_BIN_PER")) bin_per = atoi(e);      // (development: chunk size sweep)
         const size_t bin_chunk = (size_t)256 * bin_per;
         const int bin_blocks = (int)std::min<size_t>(4096, (n + bin_chunk - 1) / bin_chunk ? (n + bin_chunk - 1) / bin_chunk : 1);
         const int place_blocks = (int)std::min<size_t>(2048, (n + 1023) / 1024 ? (n + 1023) / 1024 : 1);
         const int tile_blocks = (int)max_bins;
         // Layout hint (see grid_bin_kernel<.., kPlace>): the previous build of this index left, next to its header, where each tile's
         // points may go; a build that reuses the header places by it and skips the placing pass.  PCR_INDEX_NO_LAYOUT=1 switches it off.
-        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && getenv("PCR_INDEX_NO_LAYOUT") == nullptr;
+        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && dev_env("PCR_INDEX_NO_LAYOUT") == nullptr;
         PCR_TRY(layout[0].reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(layout[1].reserve((kMaxBins + 8) * sizeof(uint32_t)));
         if (use_layout) {      // room for every tile's slack (the device also checks every store against the capacity it is told)

@@ -25,7 +25,7 @@
 
 namespace pcr {
 
-// The phase-skipping switches of pcr_params.reserved[0] (scripts/timeline_ablate.py) exist only in a build with
+// The phase-skipping switches of a development build (PCR_ABLATE, scripts/timeline_ablate.py) exist only in a build with
 // -DPCR_ABLATION: in the candidate loop their tests alone were two scalar branches per slot.
 #ifdef PCR_ABLATION
 static constexpr bool kAblation = true;
@@ -1031,7 +1031,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
 // ------------------------------------------------------------------------------
 // kGroup = candidates in flight per lane of the per-lane search.  <8, 1> is the default (one wave per SIMD -- which is all
 // that 65 536 queries give anyway); <4, 2> fits two waves per SIMD so that the blocks of ANOTHER handle's launch can share the
-// CUs: a little slower alone, more scans/s with several handles in flight (pcr_params.reserved[4] = 1).
+// CUs: a little slower alone, more scans/s with several handles in flight (pcr_params.loam_coresident = 1).
 template <int kGroup, int kWavesPerSimd>
 __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const LoamArgs a, const int k) {
     __shared__ double sh_sum[8 * 32];

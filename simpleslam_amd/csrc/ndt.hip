@@ -997,7 +997,7 @@ hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[
     NdtCtl c;
     memset(&c, 0, sizeof c);
     ndt_opt::ctl_init(&c, T0, p, step_size, trans_eps, max_iters);
-    static const bool no_replay = getenv("PCR_NDT_NO_REPLAY") != nullptr;
+    static const bool no_replay = dev_env("PCR_NDT_NO_REPLAY") != nullptr;
     c.replay_off = (no_replay || no_replay_arg) ? 1 : 0;
     NdtCtlArg a;
     memcpy(a.w, &c, sizeof c);

@@ -5,7 +5,19 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "../../include/pcr_hip.h"
+
+// Development switches (sweeps, A/B runs, debug prints: PCR_TILE_SHIFT, PCR_BIN_PER, PCR_INDEX_ATOMIC, PCR_INDEX_NO_LAYOUT,
+// PCR_INDEX_DEBUG, PCR_COV_LEVELS, PCR_COV_RATIO, PCR_COV_NO_AHEAD, PCR_NDT_TWO_LAUNCHES, PCR_NDT_TICKS, PCR_NDT_NO_REPLAY, PCR_ABLATE)
+// exist only in a library built with `make DEV=1` (-DPCR_DEV_SWITCHES): the product reads no environment variable, what a caller
+// may select is a named field of pcr_params.
+#ifdef PCR_DEV_SWITCHES
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 namespace pcr {
 
@@ -126,12 +138,12 @@ struct LoamArgs {
     struct NnCacheEntry* nn_cache;   // [n_src] neighbours of the previous iteration (loam.hip), or null
     int32_t use_tile;
     double tile_lo[3], tile_hi[3];
-    // profiling aid (pcr_params.reserved[0]): skip phases to price them.  bit0: candidate loop,
+    // profiling aid (development builds: PCR_ABLATE): skip phases to price them.  bit0: candidate loop,
     // bit1: plane fit and everything after it, bit2: prologue solve.  Results are then meaningless.
     int32_t ablate;
-    int32_t coresident;      // pcr_params.reserved[4] = 1: the two-waves-per-SIMD variant of the iterate kernel (loam.hip)
+    int32_t coresident;      // pcr_params.loam_coresident = 1: the two-waves-per-SIMD variant of the iterate kernel (loam.hip)
     int32_t rank_fail;       // sharded: this rank has no usable index (its grid view is a dummy marked overflow); told to the others
-    // profiling aid (pcr_params.reserved[3] = 1): [launch][block][kTimelineSlots] s_memrealtime stamps (100 MHz) taken by thread 0
+    // profiling aid (pcr_params.record_timeline = 1): [launch][block][kTimelineSlots] s_memrealtime stamps (100 MHz) taken by thread 0
     unsigned long long* timeline;
 };
 
@@ -159,6 +171,7 @@ struct GridIndex {
     int hint_pcl = 0;                           // lattice kind of the build the hint comes from (a hint serves only a build of the same kind)
     int hint_margin = 0;                        // cells added around a fresh box in x and y (0 until a hint has failed once)
     bool used_hint = false;                     // the last build() reused the header
+    bool no_hints = false;                      // pcr_params.index_no_hints: never reuse a header or a tile layout
     // Layout hint: where each tile's points may go in `tiled` (an eighth more room than the tile held + 32), written by the last block
     // of every tiled build for the next one; two buffers, alternating.  Used only together with a reused header.
     DeviceBuf layout[2];

@@ -9,7 +9,7 @@
 // passes stands one call of vg_ctl_step: it takes the sums in and leaves the pose of the next pass in VgCtl, or `done`.
 //
 // On the device the step is the prologue of the next pass's launch (vgicp_pass_pro_kernel): no host round trip per pass.  The
-// host-driven loop of capi.hip (sharded targets, pcr_params.reserved[6]) is the same arithmetic written as the reference's loops.
+// host-driven loop of capi.hip (sharded targets, pcr_params.host_optimiser) is the same arithmetic written as the reference's loops.
 #pragma once
 #include <math.h>
 #include <stdint.h>

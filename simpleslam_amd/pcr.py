@@ -33,7 +33,9 @@ class PcrParams(C.Structure):
         ("vgicp_resolution", C.c_double), ("vgicp_k_corr", C.c_int32), ("vgicp_max_iters", C.c_int32),
         ("vgicp_lm_inner", C.c_int32), ("vgicp_rot_eps", C.c_double), ("vgicp_trans_eps", C.c_double),
         ("vgicp_lm_init_scale", C.c_double),
-        ("record_trace", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("record_trace", C.c_int32),
+        ("index_no_hints", C.c_int32), ("ndt_evaluate_repeats", C.c_int32), ("loam_disable_cache", C.c_int32), ("record_timeline", C.c_int32),
+        ("loam_coresident", C.c_int32), ("loam_clamp_margin_mm", C.c_int32), ("host_optimiser", C.c_int32),
     ]
 
 
@@ -446,7 +448,7 @@ class LoamRegister(PointCloudRegister):
 
     def timeline(self):
         """[launch][block][8] stamps in microseconds relative to each launch's earliest block entry
-        (needs pcr_params.reserved[3] = 1).  Columns 0-7: entry, prologue, posted, searched, plane, accumulated, stored, partial sums folded (inside the
+        (needs pcr_params.record_timeline = 1).  Columns 0-7: entry, prologue, posted, searched, plane, accumulated, stored, partial sums folded (inside the
         prologue); 8-10 (dense search only): row ranges in LDS, first candidate chunk arrived, candidate stream done; 11: normal
         equations solved (inside the prologue)."""
         nl, nb = C.c_int(0), C.c_int(0)

@@ -32,7 +32,7 @@ def test_bitwise_repeatable_and_cache_exact(gpu, full):
     p2, _ = _run(full, full["init"])
     np.testing.assert_array_equal(p1, p2)                       # fixed-order reductions
     prm = pcr.default_params(loam_iters=10, loam_early_exit=0)
-    prm.reserved[2] = 1                                          # neighbour cache off: every iteration searches
+    prm.loam_disable_cache = 1                                          # neighbour cache off: every iteration searches
     reg = LoamRegister(params=prm)
     p3 = full["init"].copy()
     reg.scan2Map(full["d_scan"], full["d_map"], p3)

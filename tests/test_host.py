@@ -79,6 +79,19 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_the_product_library_reads_no_environment_variable():
+    """what a caller may select is a named field of pcr_params; the PCR_* switches of sweeps and A/B runs exist only in a
+    development build (make DEV=1).  The shipped library does not even import getenv."""
+    import subprocess
+    r = subprocess.run(["nm", "-D", "--undefined-only", LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "getenv" not in r.stdout
+    p = default_params()
+    for f in ("index_no_hints", "ndt_evaluate_repeats", "loam_disable_cache", "record_timeline", "loam_coresident", "loam_clamp_margin_mm", "host_optimiser"):
+        assert getattr(p, f) == 0
+    assert not hasattr(p, "reserved")
+
+
 def test_synth_is_deterministic_and_sized():
     w1, m1 = synth.make_map(20000, seed=3)
     w2, m2 = synth.make_map(20000, seed=3)

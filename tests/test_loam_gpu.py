@@ -279,12 +279,12 @@ def test_golden_fixture(gpu):
 
 def test_temporal_cache_is_exact(gpu, world_100k):
     """Iterations after the first reuse cached neighbours when provably valid; disabling the
-    cache (pcr_params.reserved[2]) must not change a single bit of the result."""
+    cache (pcr_params.loam_disable_cache) must not change a single bit of the result."""
     from simpleslam_amd.pcr import default_params
     w = world_100k
     p_on = default_params(loam_iters=10, loam_early_exit=0, record_trace=1)
     p_off = default_params(loam_iters=10, loam_early_exit=0, record_trace=1)
-    p_off.reserved[2] = 1
+    p_off.loam_disable_cache = 1
     a, b = LoamRegister(params=p_on), LoamRegister(params=p_off)
     pa, pb = w["init"].copy(), w["init"].copy()
     a.scan2Map(w["scan"], w["map"], pa)
@@ -355,7 +355,7 @@ def test_rccl_allreduce_path_single_rank(gpu, world_small):
 
 
 def test_coresident_kernel_variant_and_concurrent_handles(gpu, world_100k):
-    """pcr_params.reserved[4] = 1 selects the two-waves-per-SIMD build of the iterate kernel: same result bit for bit;
+    """pcr_params.loam_coresident = 1 selects the two-waves-per-SIMD build of the iterate kernel: same result bit for bit;
     and independent handles may register scans from different host threads at the same time."""
     import threading
     from simpleslam_amd import pcr
@@ -363,7 +363,7 @@ def test_coresident_kernel_variant_and_concurrent_handles(gpu, world_100k):
     base = w["init"].copy()
     LoamRegister(loam_iters=10, loam_early_exit=0).scan2Map(w["scan"], w["map"], base)
     prm = pcr.default_params(loam_iters=10, loam_early_exit=0)
-    prm.reserved[4] = 1
+    prm.loam_coresident = 1
     regs = [LoamRegister(params=prm) for _ in range(3)]
     poses = [w["init"].copy() for _ in regs]
 
@@ -390,7 +390,7 @@ def test_cache_is_exact_when_queries_cross_the_tile_boundary(gpu, world_100k):
     out = []
     for disable_cache in (0, 1):
         prm = pcr.default_params(loam_iters=6, loam_early_exit=0, record_trace=1)
-        prm.reserved[2] = disable_cache
+        prm.loam_disable_cache = disable_cache
         reg = LoamRegister(params=prm)
         reg.set_query_tile(lo, hi)
         # a first call with another scan and pose leaves entries of a different registration behind
@@ -507,7 +507,7 @@ def test_far_outlier_in_the_target(gpu, world_small):
 def test_cut_index_is_widened_when_a_query_reaches_its_edge(gpu, world_small):
     """The region a too-sparse target is cut to around the scan must never change the answer: the kernels count the queries
     that come within a cell of a cut face and the call is redone on a wider region until none does.  With the first margin
-    set to -2.5 m (pcr_params.reserved[5], a test hook; default +10 m: the region then cuts INTO the scan's box) the first
+    set to -2.5 m (pcr_params.loam_clamp_margin_mm, a test hook; default +10 m: the region then cuts INTO the scan's box) the first
     attempts lose neighbours at the edge of the region and are thrown away; the pose that comes back is the one the full
     index gives, bit for bit."""
     from simpleslam_amd import pcr
@@ -517,7 +517,7 @@ def test_cut_index_is_widened_when_a_query_reaches_its_edge(gpu, world_small):
     ref = w["init"].copy()
     c_ref = LoamRegister().scan2Map(w["scan"], m, ref)             # default margin: nothing reaches the edge
     prm = pcr.default_params()
-    prm.reserved[5] = -2500
+    prm.loam_clamp_margin_mm = -2500
     reg = LoamRegister(params=prm)
     p = w["init"].copy()
     assert reg.scan2Map(w["scan"], m, p) == c_ref

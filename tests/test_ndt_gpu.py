@@ -131,13 +131,13 @@ def test_edge_cases_match_oracle(gpu, nd_world):
 
 def test_device_resident_optimiser_equals_the_host_driven_one(gpu, nd_world):
     """The Newton / More-Thuente loop is one state machine (csrc/ndt_opt.h) that runs on the device by default (no host round
-    trip between evaluation passes) and on the host for sharded targets (pcr_params.reserved[6] = 1 selects it here).  Same
+    trip between evaluation passes) and on the host for sharded targets (pcr_params.host_optimiser = 1 selects it here).  Same
     decisions -- convergence flag, iterations, derivative and Hessian passes -- and the same Matrix4f pose up to the last bits
     of the 6x6 solve (elimination on the device, the restated JacobiSVD on the host) and of the two libms' sine."""
     from simpleslam_amd.pcr import default_params
     w = nd_world
     p_host = default_params()
-    p_host.reserved[6] = 1
+    p_host.host_optimiser = 1
     dev, host = NdtRegister(), NdtRegister(params=p_host)
     for seed, tr, rd in ((31, 0.1, 0.5), (32, 0.15, 0.8), (33, 0.05, 0.3), (34, 0.4, 2.0), (35, 0.0, 0.0)):
         T0 = synth.perturb(w["truth"], seed, trans=tr, rot_deg=rd) if tr else w["truth"].copy()
@@ -227,12 +227,12 @@ def test_rank_deficient_voxels_follow_the_references_summation_order(gpu):
 def test_replayed_line_search_evaluations_change_nothing_but_the_number_of_passes(gpu, nd_world):
     """pclomp clamps every trial step of the More-Thuente search into [epsilon / 2, step_size]; a search that wants a longer step than
     step_size evaluates that one clamped step again and again -- the same point, hence (fixed-order sums) the same numbers.  By default the
-    state machine answers such a request from the sums it holds; pcr_params.reserved[1] = 1 makes every request a pass, as the reference
+    state machine answers such a request from the sums it holds; pcr_params.ndt_evaluate_repeats = 1 makes every request a pass, as the reference
     does.  Same flag, iterations and evaluation count, bit for bit the same pose -- and fewer passes."""
     from simpleslam_amd.pcr import default_params
     w = nd_world
     p_all = default_params()
-    p_all.reserved[1] = 1
+    p_all.ndt_evaluate_repeats = 1
     fast, slow = NdtRegister(), NdtRegister(params=p_all)
     saved = 0
     for seed, tr, rd in ((51, 0.1, 0.5), (52, 0.3, 1.5), (53, 0.05, 0.2), (54, 0.0, 0.0)):

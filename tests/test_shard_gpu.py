@@ -333,7 +333,7 @@ def test_rccl_transport_with_a_one_rank_communicator(gpu, nd_w, vg_w, method):
     Reg = NdtRegister if method == "ndt" else VgicpRegister
     kw = {} if method == "ndt" else dict(vgicp_resolution=0.5)
     p_host = default_params(**kw)
-    p_host.reserved[6] = 1                                         # NDT: the host-driven loop
+    p_host.host_optimiser = 1                                         # NDT: the host-driven loop
     plain, one = Reg(params=p_host), Reg(params=p_host)
     one.comm_init(shard.unique_id(), 0, 1)
     pa, pb = w["init"].copy(), w["init"].copy()

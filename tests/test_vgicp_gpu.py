@@ -64,12 +64,12 @@ def test_scan2map_matches_oracle(gpu, vg_world):
 def test_device_resident_optimiser_equals_the_host_driven_one(gpu, vg_world):
     """The Levenberg-Marquardt loop is one state machine (csrc/vgicp_opt.h) that runs on the device by default -- the fold of a pass's
     sums and the optimiser's step are the prologue of the next pass's launch, no host round trip in between -- and as the reference's
-    loops on the host for sharded targets (pcr_params.reserved[6] = 1 selects that here).  Same decisions (convergence flag, outer
+    loops on the host for sharded targets (pcr_params.host_optimiser = 1 selects that here).  Same decisions (convergence flag, outer
     iterations, passes), and the same Matrix4f pose up to the last bit of the two libms' sine in so3_exp."""
     from simpleslam_amd.pcr import default_params
     w = vg_world
     p_host = default_params()
-    p_host.reserved[6] = 1
+    p_host.host_optimiser = 1
     dev, host = VgicpRegister(), VgicpRegister(params=p_host)
     for seed, tr, rd in ((41, 0.3, 2.0), (42, 0.1, 0.5), (43, 0.6, 4.0), (44, 0.0, 0.0), (45, 1.5, 8.0)):
         T0 = synth.perturb(w["truth"], seed, trans=tr, rot_deg=rd) if tr else w["truth"].copy()
@@ -91,7 +91,7 @@ def test_device_resident_optimiser_equals_the_host_driven_one(gpu, vg_world):
     from simpleslam_amd.pcr import default_params as dp
     for cap in (1, 2, 3):
         pa, pb = dp(), dp()
-        pa.vgicp_max_iters = cap; pb.vgicp_max_iters = cap; pb.reserved[6] = 1
+        pa.vgicp_max_iters = cap; pb.vgicp_max_iters = cap; pb.host_optimiser = 1
         ra, rb = VgicpRegister(params=pa), VgicpRegister(params=pb)
         qa, qb = w["init"].copy(), w["init"].copy()
         assert ra.scan2Map(w["scan"], w["map"], qa) == rb.scan2Map(w["scan"], w["map"], qb)
