@@ -468,7 +468,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "windows_ms": [1e3 * v for v in wins], "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
         "config": {"workload": f"pcr=loam, {N_SCAN}-pt 64-beam scan vs {args.map_points}-pt submap, {args.iters} GN iters, "
-                               "early exit off, index rebuilt per call, inputs in HBM",
+                               "early exit off, index rebuilt per call (previous call's bounding box and tile layout reused as checked hints), inputs in HBM",
                    "parallelism": parallelism, "scans_cycled": args.scans},
         # how many ranks REALLY ran: n_gpus is WORLD_SIZE of the process group, rccl_ranks the size of the RCCL group that carried a
         # collective (replicas: the barrier / max-over-ranks group; --shard-map: the handle's own communicator); gpus_arg is argv
@@ -571,6 +571,58 @@ def main():
             out["index_kept"] = {"value": 1.0 / dt, "unit": "scans/s", "ms_per_step": dt * 1e3, "scans": n_keep, "windows_ms": [w * 1e3 for w in kw],
                                  "note": "target index built once per sub-map generation (pcr_scan2map_submap / pcr_set_target + pcr_align), not per call; never reported as value"}
             reg.invalidateTarget()
+
+        # ---- what the headline carries, said in the line ----
+        # (a) index_hints: `value` is measured with the target index rebuilt on every call, but the build reuses the bounding box and the
+        #     tile layout of the PREVIOUS call's target as hints (checked on the device; a sub-map changes by a key frame at a time).  The
+        #     same scans with pcr_params.index_no_hints = 1 -- fresh box, no layout, no state across calls -- are timed beside it.
+        # (b) host_buffers: the drop-in adapter hands HOST clouds to pcr_scan2map; that path pays the PCIe copy of the
+        #     map on every call.  Timed from pageable memory and from a range the caller page-locked with pcr_host_pin.  Never `value`.
+        if not args.shard_map:
+            from simpleslam_amd import pcr as _pcr
+            out["index_hints"] = True
+            reg_nh = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0, index_no_hints=1)
+            reg_nh.set_profile(0)
+
+            def step_nh(i):
+                pose = inits[i % args.scans].copy(); reg_nh.scan2Map(d_scans[i % args.scans], d_map, pose)
+            for i in range(10):
+                step_nh(i)
+            n_nh = max(20, args.steps // 2)
+            w_nh = timed_windows(step_nh, lambda: torch.cuda.synchronize(), n_nh, 3)
+            e_nh = float(np.median(w_nh)) / n_nh
+            reg_nh.set_profile(1)
+            idx_nh = 0.0
+            for i in range(8):
+                step_nh(i); idx_nh += reg_nh.stats()["index_ms"] / 8
+            out["no_index_hints"] = {"value": 1.0 / e_nh, "unit": "scans/s", "ms_per_step": 1e3 * e_nh, "index_build_us": 1e3 * idx_nh,
+                                     "note": "pcr_params.index_no_hints = 1: bounding box pass + three build launches on every call, nothing carried across calls"}
+            del reg_nh
+            host = {}
+            n_hb = max(10, args.steps // 4)
+            map_pinned = np.array(map_np, copy=True)
+            scans_host = [np.ascontiguousarray(s) for s in scans]
+            for name, m_host in (("pageable", map_np), ("pinned", map_pinned)):
+                if name == "pinned":
+                    _pcr.host_pin(map_pinned)
+                    for s in scans_host:
+                        _pcr.host_pin(s)
+
+                def step_h(i):
+                    pose = inits[i % args.scans].copy(); reg.scan2Map(scans_host[i % args.scans], m_host, pose)
+                    return pose
+                for i in range(5):
+                    step_h(i)
+                w_h = timed_windows(step_h, lambda: torch.cuda.synchronize(), n_hb, 3)
+                e_h = float(np.median(w_h)) / n_hb
+                host[name] = {"value": 1.0 / e_h, "unit": "scans/s", "ms_per_step": 1e3 * e_h,
+                              "bytes_uploaded_per_scan": int(m_host.nbytes + scans_host[0].nbytes)}
+            _pcr.host_unpin(map_pinned)
+            for s in scans_host:
+                _pcr.host_unpin(s)
+            host["note"] = ("pcr_scan2map with HOST clouds (16-byte points): map + scan cross PCIe on every call; pinned = ranges page-locked by the "
+                            "caller with pcr_host_pin.  PCIe-bound: bytes / ~55 GB/s is the floor under the copy")
+            out["host_buffers"] = host
 
         # ---- pose parity + CPU baseline: the oracle (a port of the reference's loop, rebuilt kd-tree per call) on this host's
         #      cores, at 1 thread, at the reference's default `cores` = 4 (config/params.json:5) and at all cores, plus the same

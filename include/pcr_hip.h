@@ -118,6 +118,15 @@ const char* pcr_last_error(const pcr_handle* h);
 int pcr_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, size_t n_dst,
                  size_t stride_bytes, double pose_inout[16], int* converged);
 
+/* Page-lock a host buffer that will be handed to pcr_scan2map / pcr_set_target / pcr_align (and the other entry points taking host
+ * clouds) repeatedly -- e.g. the sub-map's point array between two MapManager updates: the upload then reads the caller's pages
+ * directly (~55 GB/s over PCIe 5 x16) instead of going through the runtime's staging of pageable memory.  Explicit on purpose:
+ * the registration holds for exactly the range [ptr, ptr + bytes) until pcr_host_unpin(ptr), which MUST precede freeing or
+ * reallocating the buffer -- the library never keys anything on a pointer it merely remembers.  Process-wide, any
+ * thread; the CONTENT is still copied on every call.  Errors: nonzero, message in pcr_last_error(NULL). */
+int pcr_host_pin(const void* ptr, size_t bytes);
+int pcr_host_unpin(const void* ptr);
+
 /* Same with DEVICE-resident buffers (HBM pointers valid on the handle's device). */
 int pcr_scan2map_device(pcr_handle* h, const void* d_src, size_t n_src, const void* d_dst, size_t n_dst,
                         size_t stride_bytes, double pose_inout[16], int* converged);

@@ -1887,6 +1887,48 @@ int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t strid
     return 0;
 }
 
+// ---- host buffers handed to pcr_scan2map / pcr_set_target / pcr_align: page-locking them is the caller's call ----
+// hipMemcpyAsync from pageable memory goes through the runtime's own staging buffers; from a registered range the copy engine reads the
+// caller's pages directly.  The registration is keyed on what the caller SAYS -- (pointer, size), pinned until pcr_host_unpin -- never on
+// what the library guesses from a pointer it has seen before: a buffer that was freed and allocated again at the same address would be
+// read through stale page mappings (the hazard of SURVEY F10, one level down).
+namespace {
+struct PinnedRange { const void* p; size_t bytes; };
+std::mutex g_pin_mu;
+std::vector<PinnedRange> g_pinned;
+}  // namespace
+
+int pcr_host_pin(const void* ptr, size_t bytes) {
+    g_create_error.clear();
+    if (!ptr || !bytes) { g_create_error = "pcr_host_pin: NULL or empty range"; return 1; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const PinnedRange& r : g_pinned)
+        if (r.p == ptr) {
+            if (r.bytes == bytes) return 0;      // the same range again: nothing to do
+            g_create_error = "pcr_host_pin: this address is already pinned with another size (pcr_host_unpin it first)";
+            return 1;
+        }
+    const hipError_t e = hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e); return 1; }
+    g_pinned.push_back(PinnedRange{ptr, bytes});
+    return 0;
+}
+
+int pcr_host_unpin(const void* ptr) {
+    g_create_error.clear();
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pinned.size(); ++i)
+        if (g_pinned[i].p == ptr) {
+            (void)hipDeviceSynchronize();      // no copy out of the range may still be in flight
+            const hipError_t e = hipHostUnregister(const_cast<void*>(ptr));
+            g_pinned.erase(g_pinned.begin() + (long)i);
+            if (e != hipSuccess) { (void)hipGetLastError(); g_create_error = std::string("hipHostUnregister: ") + hipGetErrorString(e); return 1; }
+            return 0;
+        }
+    g_create_error = "pcr_host_unpin: this address was not pinned with pcr_host_pin";
+    return 1;
+}
+
 int pcr_comm_unique_id(void* out128) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (!out128 || !g_rccl.load(&g_create_error)) return 1;

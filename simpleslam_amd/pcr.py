@@ -49,7 +49,7 @@ class PcrStats(C.Structure):
 
 # every symbol include/pcr_hip.h declares
 ABI_SYMBOLS = [
-    "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device",
+    "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device", "pcr_host_pin", "pcr_host_unpin",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
     "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info",
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
@@ -102,6 +102,8 @@ def load_library():
     L.pcr_last_error.restype = C.c_char_p
     L.pcr_scan2map.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, dp, ip]
     L.pcr_scan2map_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, dp, ip]
+    L.pcr_host_pin.argtypes = [vp, C.c_size_t]
+    L.pcr_host_unpin.argtypes = [vp]
     L.pcr_set_target.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
     L.pcr_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, ip]
     L.pcr_invalidate_target.argtypes = [vp]
@@ -516,6 +518,21 @@ def make_register(pcr_type, **overrides):
     if pcr_type not in table:
         raise RuntimeError(f"such pcr type({pcr_type}) is not exist, please implemented your self!")
     return table[pcr_type](**overrides)
+
+
+def host_pin(array):
+    """pcr_host_pin on a numpy array's buffer (kept pinned until host_unpin(array); the array must stay alive and unresized)."""
+    a = np.asarray(array)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("only contiguous arrays can be pinned")
+    if load_library().pcr_host_pin(a.ctypes.data_as(C.c_void_p), a.nbytes) != 0:
+        raise PcrError(load_library().pcr_last_error(None).decode())
+
+
+def host_unpin(array):
+    a = np.asarray(array)
+    if load_library().pcr_host_unpin(a.ctypes.data_as(C.c_void_p)) != 0:
+        raise PcrError(load_library().pcr_last_error(None).decode())
 
 
 def comm_unique_id():
