@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="> 1: additionally time S independent handles (one HIP stream and one host thread each) registering "
                          "scans concurrently on the same GPU; reported as \"concurrent\", never as \"value\"")
+    ap.add_argument("--full-target", action="store_true", help="vgicp / ndt: prepare the whole target on every call (pcr_params.full_target = 1) instead of the scan's region, for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=8.0, help="wall-clock bound of EACH CPU leg (per thread count / index flavour / method)")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; value = the median window")
@@ -261,7 +262,7 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         local_rank = dev.index
     if method == "vgicp":
         cfg, n_map, kw, mk = 3, 1_000_000, {}, {}
-        reg = VgicpRegister(device=local_rank, vgicp_resolution=0.5)
+        reg = VgicpRegister(device=local_rank, vgicp_resolution=0.5, full_target=int(args.full_target))
         pert = {}
         cores = host_cores()
         ref = lambda s, m, T, th: oracle.vgicp_scan2map(s, m, T, oracle.vgicp_params(resolution=0.5, threads=th))[0]
@@ -271,7 +272,7 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         workload = "pcr=vgicp, 0.5 m voxels, 65536-pt scan vs 1000000-pt submap, target rebuilt per call, inputs in HBM"
     else:
         cfg, n_map, kw, mk = 5, 5_000_000, dict(beams=128, azimuths=1024), dict(spacing=0.22)
-        reg = NdtRegister(device=local_rank)
+        reg = NdtRegister(device=local_rank, full_target=int(args.full_target))
         pert = dict(trans=0.1, rot_deg=0.5)
         # computeDerivatives on `cores` threads as the reference runs it (ndt_omp_impl.hpp:206, NdtRegister.cpp:18); the voxel grid,
         # computeHessian and the line-search bookkeeping are serial there and here

@@ -83,6 +83,9 @@ typedef struct pcr_params {
     int32_t loam_clamp_margin_mm; /* != 0: LOAM: first margin, in millimetres, of the region a target too sparse for the dense index is
                                 *    cut to around the scan (default 10 m; it grows whenever a query reaches a cut face).  Negative values cut
                                 *    into the scan's own box: a test hook that makes the widening path reachable with ordinary clouds */
+    int32_t full_target;       /* 1: NDT, VGICP: pcr_scan2map prepares the WHOLE target (every covariance, every voxel Gaussian), as the
+                                *    reference does, instead of only the region the scan can reach (same result: a call whose pose leaves
+                                *    the region is repeated on the whole target anyway) */
     int32_t host_optimiser;    /* 1: NDT, VGICP: drive the optimiser from the host (one round trip per evaluation pass) instead of on the
                                 *    device; the path handles sharded over a host-supplied collective always take.  Same state machines
                                 *    (csrc/ndt_opt.h, csrc/vgicp_opt.h), same result to rounding */
@@ -101,6 +104,9 @@ typedef struct pcr_stats {
                              * NDT: evaluation passes the device loop launched -- fewer than kernel_launches (= the evaluations the
                              * reference makes) when repeated line-search evaluations were answered without a pass */
     int32_t target_builds;  /* pcr_scan2map_submap: times this handle has (re)built its target structures (one per sub-map generation) */
+    int32_t region_repeats; /* NDT, VGICP pcr_scan2map: calls of this handle so far whose pose left the region the target had been prepared for and
+                             * that were therefore repeated on the whole target (pcr_params.full_target) */
+    int32_t pad_;
 } pcr_stats;
 
 void pcr_default_params(pcr_params* p);

@@ -150,6 +150,11 @@ struct pcr_handle {
     DeviceBuf dummy_grid;            // a GridHeader marked overflow + empty: the grid view of a rank whose index failed
     DeviceBuf cov_viol;              // VGICP halo check: number of neighbourhoods that reach past the halo
     double clamp_margin = 10.0;      // LOAM ClampBox: room around the scan, doubled when a query reached a cut face
+    // region of interest of a target prepared for one scan (RoiView): two marking buffers used alternately, the dilated mask, the escape counter
+    DeviceBuf roi_mark[2], roi_tmp[2], roi_mask, roi_esc;
+    int roi_idx = 0, roi_mshift = 0;
+    bool roi_on = false;             // the target structures the handle holds cover only the region of the scan they were prepared for
+    long long roi_repeats = 0;       // calls that left the region and were repeated on the whole target
 
     // timing
     hipEvent_t ev_start = nullptr, ev_index = nullptr, ev_end = nullptr;
@@ -678,8 +683,45 @@ int vgicp_source_settle(pcr_handle* h, const float* d_src, size_t n_src, size_t 
     return 0;
 }
 
-int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats) {
+// The scan a target is being prepared for (pcr_scan2map of an unsharded handle), or nullptr: everything is prepared.
+struct RoiScan { const float* d_src; size_t n_src, stride_floats; const double* pose; };
+
+// Marks the macro cells of h->grid's lattice that `scan` can reach from its initial pose and fills `view`: base_m metres in any direction
+// plus kRoiPerMetre metres per metre of distance from the sensor (a rotation of 0.05 rad = 2.9 degrees moves a point 100 m away by 5 m).
+// The pose goes through a Matrix4f first, as VGICP and NDT hand their guess over as one.
+static constexpr double kRoiPerMetre = 0.05;
+int roi_enqueue(pcr_handle* h, const RoiScan& scan, double cell, double base_m, RoiView* view) {
+    int ms = 0;      // macro cell of about 2 m
+    while (ms < 5 && cell * (double)(1 << ms) < 2.0 * (1.0 - 1e-9)) ++ms;
+    h->roi_mshift = ms;
+    const size_t bytes = h->grid.cell_capacity + 4096;      // macro cells <= cells <= capacity (a build that needs more raises header.overflow)
+    for (DeviceBuf* b : {&h->roi_mark[0], &h->roi_mark[1]}) {
+        const void* before = b->p;
+        H_TRY(b->reserve(bytes));
+        if (b->p != before) H_TRY(hipMemsetAsync(b->p, 0, b->cap, h->stream));      // the marks start out clear; every call clears the other buffer for the next
+    }
+    for (DeviceBuf* b : {&h->roi_tmp[0], &h->roi_tmp[1], &h->roi_mask}) H_TRY(b->reserve(bytes));      // (written in full by every call)
+    H_TRY(h->roi_esc.reserve(64));
+    Pose16 T;
+    for (int i = 0; i < 16; ++i) T.m[i] = (double)(float)scan.pose[i];
+    const int k = h->roi_idx;
+    H_TRY(roi_launch(h->grid, scan.d_src, scan.n_src, scan.stride_floats, T, ms, h->roi_mark[k].as<uint8_t>(), h->roi_mark[k ^ 1].as<uint8_t>(),
+                     h->roi_tmp[0].as<uint8_t>(), h->roi_tmp[1].as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream));
+    h->roi_idx ^= 1;
+    view->lat = h->grid.header.as<GridHeader>(); view->mask = h->roi_mask.as<uint8_t>(); view->escapes = h->roi_esc.as<uint32_t>();
+    view->mshift = ms; view->pad_ = 0;
+    return 0;
+}
+RoiView roi_view(const pcr_handle* h) {      // the region the handle's target was prepared for (the mask of the LAST roi_enqueue)
+    RoiView v;
+    memset(&v, 0, sizeof v);
+    if (h->roi_on) { v.lat = h->grid.header.as<GridHeader>(); v.mask = h->roi_mask.as<uint8_t>(); v.escapes = h->roi_esc.as<uint32_t>(); v.mshift = h->roi_mshift; }
+    return v;
+}
+
+int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, const RoiScan* roi_scan = nullptr) {
     h->vg_target_ready = false;
+    h->roi_on = false;
     const double res = h->prm.vgicp_resolution;
     if (!(res > 0)) return fail(h, "vgicp_resolution must be positive");
     if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
@@ -724,9 +766,17 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
         for (int d = 0; d < 3; ++d) { chk.chk_lo[d] = h->tile_lo[d] - res; chk.chk_hi[d] = h->tile_hi[d] + res; }
         chk.violations = h->cov_viol.as<uint32_t>();
     }
+    // prepared for one scan: covariances and voxels only where that scan can land (a cut index keeps the full preparation: its
+    // escape accounting is of another kind)
+    RoiView roi;
+    memset(&roi, 0, sizeof roi);
+    if (roi_scan && roi_scan->n_src > 0 && n_dst > 0 && !h->clamp.use && !check) {
+        if (roi_enqueue(h, *roi_scan, res, 1.0, &roi)) return 1;      // 1 m of translation + 0.05 rad
+        h->roi_on = true;
+    }
     H_TRY(vgicp_launch_cov(*cov_grid, cov_levels(n_dst) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_dst) > 2 ? &h->cov_l2 : nullptr, d_dst, stride_floats,
-                           n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr));
-    H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream));
+                           n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr));
+    H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream, h->roi_on ? &roi : nullptr));
     if (check) {
         uint32_t viol = 0;
         H_TRY(hipMemcpyAsync(&viol, h->cov_viol.p, sizeof viol, hipMemcpyDeviceToHost, h->stream));
@@ -757,6 +807,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     H_TRY(h->corr_slot2.reserve((n_src + 1) * sizeof(uint32_t)));
     H_TRY(h->corr_M2.reserve((n_src + 1) * 6 * sizeof(double)));
     VgicpArgs a;
+    memset(&a, 0, sizeof a);      // (roi.mask = nullptr: the whole target is prepared, unless set below)
     a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)stride_floats;
     a.src_cov6 = h->src_cov6.as<double>();
     a.hdr = h->grid.header.as<GridHeader>();
@@ -768,6 +819,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     a.use_tile = h->use_tile; a.pad_ = 0;
     for (int d = 0; d < 3; ++d) { a.tile_lo[d] = h->tile_lo[d]; a.tile_hi[d] = h->tile_hi[d]; }
     a.escapes = nullptr; a.guard_cells = 0; a.pad2_ = 0;
+    a.roi = roi_view(h);
     if (h->clamp.use) {      // the target index was cut to the bulk of the cloud (vgicp_prepare_target): watch where the scan goes
         H_TRY(h->cov_viol.reserve(16));
         H_TRY(hipMemsetAsync(h->cov_viol.p, 0, 16, h->stream));
@@ -783,6 +835,7 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     // ---- device-resident loop (vgicp_opt.h): launches are enqueued ahead of the device, the host watches a progress word.  Not for
     // sharded targets (every pass's sums cross the ranks) and not when pcr_params.host_optimiser asks for the host loop below ----
     const bool on_device = n_src > 0 && !shard && h->prm.host_optimiser == 0 && h->prm.vgicp_max_iters > 0;
+    if (h->roi_on && !on_device) return fail(h, "internal: a target prepared for one scan needs the device-resident loop");
     if (on_device) {
         if (!h->vg_out_host) {
             H_TRY(hipHostMalloc((void**)&h->vg_out_host, sizeof(VgOut), hipHostMallocMapped));
@@ -796,7 +849,8 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         VgOut* out = h->vg_out_host;
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(vgicp_launch_ctl_init(d_ctl, x0, h->prm.vgicp_max_iters, h->prm.vgicp_lm_inner, h->prm.vgicp_lm_init_scale, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps, h->stream));
+        H_TRY(vgicp_launch_ctl_init(d_ctl, x0, h->prm.vgicp_max_iters, h->prm.vgicp_lm_inner, h->prm.vgicp_lm_init_scale, h->prm.vgicp_rot_eps, h->prm.vgicp_trans_eps, h->stream,
+                                    h->roi_on ? h->roi_esc.as<uint32_t>() : nullptr));
         // every outer iteration takes at most lm_inner passes, plus the first linearisation and the launch that finishes
         const long limit = (long)h->prm.vgicp_max_iters * std::max(1, h->prm.vgicp_lm_inner) + 3;
         if ((double)limit >= kProgressWindow) return fail(h, "vgicp_max_iters * vgicp_lm_inner exceeds the device loop's pass window (2^20)");
@@ -825,6 +879,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        // some pass looked up a voxel outside the region the target was prepared for: its sums lack that correspondence.  The caller
+        // prepares the whole target and repeats the call (2).
+        if (h->roi_on && out->roi_escapes > 0) { h->roi_repeats += 1; return 2; }
         x0 = out->x0; conv = out->conv != 0;
         h->vg_outer = out->outer; h->vg_lin = out->n_lin; h->vg_err = out->n_err;
     }
@@ -897,8 +954,9 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
 // deferred: nothing is read back here -- the index is enqueued with the previous target's box as a hint and the cell table at its
 // current size; whether either was wrong (header.overflow / header.stale) comes back with the result of the alignment
 // (NdtOut), and the caller then prepares again the slow, checked way.  One host round trip less per scan.
-int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, bool deferred = false) {
+int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, bool deferred = false, const RoiScan* roi_scan = nullptr) {
     h->nd_target_ready = false;
+    h->roi_on = false;
     const double res = (double)(float)h->prm.ndt_resolution;     // resolution_ is a float (ndt_omp.h)
     if (!(res > 0)) return fail(h, "ndt_resolution must be positive");
     // the voxel lattice is VoxelGridCovariance's own (leaf index = floor(p * inverse_leaf) - min_b in float,
@@ -919,9 +977,16 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
         H_TRY(hipMemsetAsync(h->nd_count.p, 0, 256, h->stream));
     }
     h->nd_count_idx ^= 1;
+    // prepared for one scan (pcr_scan2map): voxel Gaussians only where that scan can land (RoiView)
+    RoiView roi;
+    memset(&roi, 0, sizeof roi);
+    if (roi_scan && roi_scan->n_src > 0 && n_dst > 0) {
+        if (roi_enqueue(h, *roi_scan, res, 1.0 + res, &roi)) return 1;      // 1 m of translation + the DIRECT7 face voxels, + 0.05 rad
+        h->roi_on = true;
+    }
     H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>() + 32 * h->nd_count_idx,
                             h->nd_count.as<uint32_t>() + 32 * (h->nd_count_idx ^ 1), h->nd_list.as<uint32_t>(),
-                            max_vox, min_points, 0.01, h->stream));
+                            max_vox, min_points, 0.01, h->stream, h->roi_on ? &roi : nullptr));
     h->nd_target_ready = true;
     return 0;
 }
@@ -991,12 +1056,14 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));      // (one buffer of 1024 rows, or the two of 256 of the one-launch-per-pass loop)
     H_TRY(h->nd_ctl.reserve(2 * sizeof(NdtCtl)));
     NdtRun r;
+    memset(&r.a, 0, sizeof r.a);
     r.h = h;
     r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)stride_floats;
     r.a.hdr = h->grid.header.as<GridHeader>(); r.a.vox_slot = h->nd_slot.as<uint32_t>(); r.a.vox = h->nd_vox.as<NdtVoxel>();
     r.a.partials = h->nd_partials.as<double>();
     r.a.use_tile = h->use_tile; r.a.pad_ = 0;
     for (int d = 0; d < 3; ++d) { r.a.tile_lo[d] = h->tile_lo[d]; r.a.tile_hi[d] = h->tile_hi[d]; }
+    r.a.roi_escapes = h->roi_on ? h->roi_esc.as<uint32_t>() : nullptr;
     {   // Gauss constants (ndt_omp_impl.hpp:86-93)
         const double res = (double)(float)h->prm.ndt_resolution;
         const double c1 = 10 * (1 - h->prm.ndt_outlier_ratio), c2 = h->prm.ndt_outlier_ratio / pow(res, 3);
@@ -1024,6 +1091,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     // every rank enqueues the same collectives.  (A host-supplied collective needs the host in every pass: the host loop below.)
     const bool dev_sharded = sharded(h) && h->comm && !h->host_ar && n_src > 0 && h->prm.host_optimiser == 0;
     bool on_device = n_src > 0 && !sharded(h) && h->prm.host_optimiser == 0;
+    if (h->roi_on && !on_device) return fail(h, "internal: a target prepared for one scan needs the device-resident loop");
     h->nd_grid_checked = false; h->nd_grid_bad = false;
     bool sharded_done = false;
     if (dev_sharded) {
@@ -1063,7 +1131,8 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         NdtOut* out = h->nd_out_host;
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats));
+        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats,
+                                  r.a.roi_escapes));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 5;        // an iteration takes at most 1 + 10 + 1 passes; one launch more finishes
         if ((double)limit >= kProgressWindow) return fail(h, "ndt_max_iters exceeds the device loop's pass window (2^20 passes)");
         int enq = 0;
@@ -1103,6 +1172,8 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         h->nd_grid_cells = out->grid_cells;
         h->nd_grid_checked = true;
         if (h->nd_grid_bad) return 0;           // the caller prepares the target again and repeats the call
+        // a pass looked up a voxel the target was not prepared for (RoiView), or the loop wants the host's SVD: whole target, again
+        if (h->roi_on && (out->roi_escapes > 0 || out->bail)) { h->roi_repeats += 1; return 2; }
         if (out->bail) on_device = false;       // the Newton system was (nearly) singular: the host loop below decides, with the SVD
         else {
             final_T = out->final_T; conv = out->conv; nr_it = out->nr_it; score = out->score;
@@ -1172,11 +1243,17 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         const bool try_deferred = !sharded(h) && n_src > 0 && h->prm.host_optimiser == 0;
         double pose_in[16];
         memcpy(pose_in, pose, sizeof pose_in);
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        // (unsharded, device loop: the voxel Gaussians are prepared only where this scan can land -- RoiView; a call that leaves the
+        //  region is repeated on the whole target)
+        bool use_roi = try_deferred && h->prm.full_target == 0;
+        const RoiScan rs{d_src, n_src, stride_bytes / 4, pose_in};
+        for (int attempt = 0; attempt < 3; ++attempt) {
             const bool deferred = try_deferred && attempt == 0;
-            if (agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4, deferred))) return 1;
+            if (agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4, deferred, use_roi ? &rs : nullptr))) return 1;
             if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
-            if (run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
+            const int rrc = run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged);
+            if (rrc == 2) { use_roi = false; memcpy(pose, pose_in, sizeof pose_in); if (deferred && h->nd_grid_checked && !h->nd_grid_bad && !h->nd_grid_empty) { h->grid.confirm(); h->grid.note_cells(h->nd_grid_cells); } continue; }
+            if (rrc) return 1;
             if (!deferred) break;
             if (h->nd_grid_checked && !h->nd_grid_bad) { if (!h->nd_grid_empty) { h->grid.confirm(); h->grid.note_cells(h->nd_grid_cells); } break; }
             // the hint or the table size did not hold (or the device loop handed over to the host before it could tell): checked build
@@ -1199,15 +1276,28 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         // (source side first: its ~15 launches run on the side stream while the host is still queueing the target's.  Measured the other
         //  way round -- target builds queued first, source side enqueued while the host waits for them -- 1.17 instead of 0.93 ms: the
         //  two covariance kernels then run side by side for their whole length and slow each other down)
+        // The target exists for this scan only, so only the part of it the scan can reach is prepared (RoiView): the covariances of a
+        // 1 M-point map were 0.4 of a 0.85 ms call, of which the scan looks up a tenth.  Should the optimiser carry the scan out of that
+        // region, the whole target is prepared and the call repeated from the same guess.
+        const bool use_roi = !sharded(h) && n_src > 0 && h->prm.host_optimiser == 0 && h->prm.vgicp_max_iters > 0 && h->prm.full_target == 0;
+        double pose_in[16];
+        memcpy(pose_in, pose, sizeof pose_in);
+        const RoiScan rs{d_src, n_src, stride_bytes / 4, pose_in};
         int prc = vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4);
-        if (!prc) prc = vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4);
+        if (!prc) prc = vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4, use_roi ? &rs : nullptr);
         if (prc && h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
         if (agree_prepared(h, prc)) {
             if (h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
             return 1;
         }
         if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
-        if (run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged)) return 1;
+        int rrc = run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged);
+        if (rrc == 2) {
+            memcpy(pose, pose_in, sizeof pose_in);
+            if (vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4, nullptr)) return 1;
+            rrc = run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged);
+        }
+        if (rrc) return 1;
         if (h->profile >= 1) {
             H_TRY(hipEventRecord(h->ev_end, h->stream));
             H_TRY(hipEventSynchronize(h->ev_end));
@@ -1312,6 +1402,7 @@ void pcr_destroy(pcr_handle* h) {
     if (h->result_host) (void)hipHostFree(h->result_host);
     if (h->red_host) (void)hipHostFree(h->red_host);
     h->ar_stage.release(); h->dummy_grid.release(); h->cov_viol.release();
+    h->roi_mark[0].release(); h->roi_mark[1].release(); h->roi_tmp[0].release(); h->roi_tmp[1].release(); h->roi_mask.release(); h->roi_esc.release();
     for (hipEvent_t e : h->ev_kernel) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_index) (void)hipEventDestroy(h->ev_index);
@@ -1404,6 +1495,7 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
+    if (h->roi_on) return fail(h, "no target: pcr_scan2map prepares its target for that one scan only; call pcr_set_target for a target that is kept");
     drop_fitness_state(h);
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
@@ -1415,7 +1507,7 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
 int pcr_invalidate_target(pcr_handle* h) {
     if (!h) return 1;
     h->have_target = false; h->grid.valid = false; h->vg_target_ready = false; h->nd_target_ready = false;
-    h->map_id = 0; h->map_gen = 0;
+    h->map_id = 0; h->map_gen = 0; h->roi_on = false;
     return 0;
 }
 
@@ -1566,6 +1658,7 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     h->prm.vgicp_max_iters = saved;
     if (rc) return 1;
     VgicpArgs a;
+    memset(&a, 0, sizeof a);      // (roi.mask = nullptr: the whole target is prepared, unless set below)
     a.src = d_src; a.n_src = (uint32_t)n_src; a.src_stride = (uint32_t)(stride_bytes / 4);
     a.src_cov6 = h->src_cov6.as<double>();
     a.hdr = h->grid.header.as<GridHeader>();
@@ -1608,6 +1701,7 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     }
     H_TRY(h->nd_partials.reserve((size_t)1024 * 48 * sizeof(double)));
     NdtRun r;
+    memset(&r.a, 0, sizeof r.a);
     r.h = h;
     r.a.src = d_src; r.a.n_src = (uint32_t)n_src; r.a.src_stride = (uint32_t)(stride_bytes / 4);
     r.a.hdr = h->grid.header.as<GridHeader>(); r.a.vox_slot = h->nd_slot.as<uint32_t>(); r.a.vox = h->nd_vox.as<NdtVoxel>();
@@ -1760,6 +1854,7 @@ int pcr_get_stats(pcr_handle* h, pcr_stats* out) {
     if (!h || !out) return 1;
     *out = h->stats;
     out->target_builds = (int32_t)h->target_builds;
+    out->region_repeats = (int32_t)h->roi_repeats; out->pad_ = 0;
     return 0;
 }
 

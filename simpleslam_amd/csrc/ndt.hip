@@ -76,8 +76,17 @@ static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(
 // lane utilisation.  A block owns a contiguous range of cells, counts its candidates, claims room for all of them with ONE
 // atomic on the shared counter (an atomic per 1024 cells was 1 600 same-address atomics for a 5 M-point map: they serialise at
 // the memory side, 31 us) and then writes them; the order of the list is immaterial.
+// roi (a target prepared for one scan, pcr_internal.h: RoiView): a qualifying cell OUTSIDE the region is not listed; its slot is set to
+// kNdtUnprepared, which the lookups of the optimiser count as an escape.
+static constexpr uint32_t kNdtUnprepared = 0xffffffffu;
+__device__ __forceinline__ bool ndt_cell_in_roi(const GridHeader& h, const RoiView& roi, uint64_t t) {
+    const uint32_t t32 = (uint32_t)t, d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = t32 / d0;
+    const uint32_t cz = row / d1;
+    return roi.mask[roi_macro(h, roi.mshift, (int)(t32 - row * d0), (int)(row - cz * d1), (int)cz)] != 0;
+}
 __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_t* __restrict__ vox_slot, uint32_t* __restrict__ list,
-                                                             uint32_t* __restrict__ count, uint32_t* __restrict__ count_next, int min_points, uint32_t capacity) {
+                                                             uint32_t* __restrict__ count, uint32_t* __restrict__ count_next, int min_points, uint32_t capacity,
+                                                             const RoiView roi) {
     __shared__ uint32_t sh_w[4];
     __shared__ uint32_t sh_base;
     // two counters, used alternately: this call counts in `count` (left at zero by the previous call) and clears the other for the next
@@ -98,8 +107,10 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
             if (t < h.n_cells) {
-                mine_total += (!h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points) ? 1u : 0u;
-                vox_slot[t] = 0u;
+                const bool cand = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
+                const bool in = cand && (!roi.mask || ndt_cell_in_roi(h, roi, t));
+                mine_total += in ? 1u : 0u;
+                vox_slot[t] = (cand && !in) ? kNdtUnprepared : 0u;
             }
         }
     }
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
-            if (t < h.n_cells && !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points) {
+            if (t < h.n_cells && !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points && (!roi.mask || ndt_cell_in_roi(h, roi, t))) {
                 if (pos < capacity) list[pos] = (uint32_t)t;      // (capacity = points / min_points: never short)
                 ++pos;
             }
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256) void ndt_voxel_kernel(GridView g, const uint32
 // neighbourhood: centre cell then +x -x +y -y +z -z (:419-433)
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ int ndt_neighbours(const GridHeader& h, const uint32_t* __restrict__ vox_slot, float tx, float ty, float tz,
-                                              uint32_t slots[7]) {
+                                              uint32_t slots[7], uint32_t* __restrict__ roi_escapes) {
     int n = 0;
     if (h.overflow || h.empty) return 0;
     // floor(p / leaf) evaluated in float like the reference (:380-382)
@@ -305,7 +316,8 @@ __device__ __forceinline__ int ndt_neighbours(const GridHeader& h, const uint32_
         const int x = cx + off[k][0], y = cy + off[k][1], z = cz + off[k][2];
         if (x >= 0 && x < h.dims[0] && y >= 0 && y < h.dims[1] && z >= 0 && z < h.dims[2]) {
             const uint32_t s = vox_slot[((uint64_t)z * (uint64_t)h.dims[1] + (uint64_t)y) * (uint64_t)h.dims[0] + (uint64_t)x];
-            if (s) slots[n++] = s;
+            if (s == kNdtUnprepared) { if (roi_escapes) atomicAdd(roi_escapes, 1u); }      // a voxel the target was not prepared for: the call is repeated on the whole target
+            else if (s) slots[n++] = s;
         }
     }
     return n;
@@ -427,7 +439,7 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
 #pragma unroll
             for (int r = 0; r < 3; ++r) { float s = T.R[r * 3] * x4[0]; s += T.R[r * 3 + 1] * x4[1]; s += T.R[r * 3 + 2] * x4[2]; s += T.t[r]; tp[r] = s; }
             uint32_t slots[7];
-            int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots, a.roi_escapes);
             if (a.use_tile && !ndt_in_tile(a, tp)) nn = 0;       // another rank's query
             if (nn > 0) {
                 // computePointDerivatives (float): :399-440
@@ -516,7 +528,7 @@ __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose
 #pragma unroll
             for (int r = 0; r < 3; ++r) { float s = T.R[r * 3] * xp[0]; s += T.R[r * 3 + 1] * xp[1]; s += T.R[r * 3 + 2] * xp[2]; s += T.t[r]; tp[r] = s; }
             uint32_t slots[7];
-            int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots);
+            int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots, a.roi_escapes);
             if (a.use_tile && !ndt_in_tile(a, tp)) nn = 0;
             if (nn > 0) {
                 const double x[3] = {(double)xp[0], (double)xp[1], (double)xp[2]};
@@ -606,9 +618,10 @@ __global__ __launch_bounds__(kNdtBlock, 2) void ndt_pass_kernel(const NdtArgs a,
 
 // the controller's initial state, prepared on the host (ndt_opt::ctl_init) and handed over as a kernel argument
 struct NdtCtlArg { uint32_t w[(sizeof(NdtCtl) + 3) / 4]; };
-__global__ __launch_bounds__(512) void ndt_ctl_store_kernel(NdtCtl* __restrict__ ctl, const NdtCtlArg init) {
+__global__ __launch_bounds__(512) void ndt_ctl_store_kernel(NdtCtl* __restrict__ ctl, const NdtCtlArg init, uint32_t* __restrict__ roi_escapes) {
     const int n = (int)(sizeof(NdtCtl) / 4);
     for (int t = threadIdx.x; t < n; t += 512) reinterpret_cast<uint32_t*>(ctl)[t] = init.w[t];
+    if (roi_escapes && threadIdx.x == 0) *roi_escapes = 0u;
 }
 
 static constexpr int kCtlWords = (int)((sizeof(NdtCtl) + 3) / 4);
@@ -617,7 +630,7 @@ static constexpr int kCtlWords = (int)((sizeof(NdtCtl) + 3) / 4);
 // 11 blocks) instead of eight.  Controller: thread 0 takes the decisions (ndt_opt::ctl_decide), six lanes evaluate the six
 // sine/cosine pairs of the new pose at once, thread 0 fills the tables.
 __global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restrict__ partials, uint32_t nblocks, NdtCtl* __restrict__ ctl,
-                                                           const GridHeader* __restrict__ hdr, NdtOut* __restrict__ out, double seq) {
+                                                           const GridHeader* __restrict__ hdr, NdtOut* __restrict__ out, double seq, const uint32_t* __restrict__ roi_escapes) {
     __shared__ double sh[96 * 8];                // = 16 * 48
     __shared__ double sh_sums[48];
     __shared__ double sh_sc[12];
@@ -697,7 +710,7 @@ __global__ __launch_bounds__(768) void ndt_fold_ctl_kernel(const double* __restr
             out->final_T = c->final_T; out->score = c->score;
             out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
             for (int i = 0; i < 4; ++i) out->ticks[i] = c->ticks[i];
-            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->pad0 = 0; out->grid_cells = hdr->n_cells;
+            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->roi_escapes = roi_escapes ? (int32_t)min(*roi_escapes, 0x7fffffffu) : 0; out->grid_cells = hdr->n_cells;
             __threadfence_system();
             __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArg
                     out->final_T = c->final_T; out->score = c->score;
                     out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
                     for (int i = 0; i < 4; ++i) out->ticks[i] = c->ticks[i];
-                    out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->pad0 = 0; out->grid_cells = hdr->n_cells;
+                    out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->roi_escapes = a.roi_escapes ? (int32_t)min(*a.roi_escapes, 0x7fffffffu) : 0; out->grid_cells = hdr->n_cells;
                     __threadfence_system();
                     __hip_atomic_store(&out->seq, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
@@ -899,7 +912,7 @@ __global__ __launch_bounds__(768) void ndt_fold_kernel(const double* __restrict_
 }
 
 __global__ __launch_bounds__(64) void ndt_ctl_kernel(NdtCtl* __restrict__ ctl, const double* __restrict__ sums48, const GridHeader* __restrict__ hdr,
-                                                     NdtOut* __restrict__ out, double seq, int batch_mark) {
+                                                     NdtOut* __restrict__ out, double seq, int batch_mark, const uint32_t* __restrict__ roi_escapes) {
     __shared__ double sh_sums[48];
     __shared__ double sh_sc[12];
     __shared__ int sh_need;
@@ -929,7 +942,7 @@ __global__ __launch_bounds__(64) void ndt_ctl_kernel(NdtCtl* __restrict__ ctl, c
         if (c->done && !done_in) {
             out->final_T = c->final_T; out->score = c->score;
             out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
-            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->pad0 = 0; out->grid_cells = hdr->n_cells;
+            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->roi_escapes = roi_escapes ? (int32_t)min(*roi_escapes, 0x7fffffffu) : 0; out->grid_cells = hdr->n_cells;
             __threadfence_system();
             __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -976,9 +989,12 @@ uint32_t ndt_blocks(uint32_t n_src) {
 }
 
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
-                             int min_points, double eig_mult, hipStream_t s) {
+                             int min_points, double eig_mult, hipStream_t s, const RoiView* roi) {
     const int blocks = (int)std::min<size_t>(512, grid.cell_capacity / 1024 + 1);
-    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, d_count_next, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
+    RoiView rv;
+    memset(&rv, 0, sizeof rv);
+    if (roi) rv = *roi;
+    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, d_count_next, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu), rv);
     const int vblocks = (int)std::min<size_t>(65535, list_capacity / 256 + 1);
     hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     return hipGetLastError();
@@ -992,7 +1008,8 @@ hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtA
     return hipGetLastError();
 }
 
-hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay_arg) {
+hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay_arg,
+                               uint32_t* d_roi_escapes) {
     static_assert(sizeof(NdtCtl) % 4 == 0, "NdtCtl is copied word by word");
     NdtCtl c;
     memset(&c, 0, sizeof c);
@@ -1001,13 +1018,13 @@ hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[
     c.replay_off = (no_replay || no_replay_arg) ? 1 : 0;
     NdtCtlArg a;
     memcpy(a.w, &c, sizeof c);
-    hipLaunchKernelGGL(ndt_ctl_store_kernel, dim3(1), dim3(512), 0, s, d_ctl, a);
+    hipLaunchKernelGGL(ndt_ctl_store_kernel, dim3(1), dim3(512), 0, s, d_ctl, a, d_roi_escapes);
     return hipGetLastError();
 }
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq) {
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
-    hipLaunchKernelGGL(ndt_fold_ctl_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, a.hdr, d_out, seq);
+    hipLaunchKernelGGL(ndt_fold_ctl_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, a.hdr, d_out, seq, (const uint32_t*)a.roi_escapes);
     return hipGetLastError();
 }
 // launch `index` of the one-launch-per-pass loop: d_ctl2 = two NdtCtl, d_rows2 = two buffers of kProRows * 48 doubles
@@ -1033,7 +1050,7 @@ hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums4
     return hipGetLastError();
 }
 hipError_t ndt_launch_ctl(const NdtArgs& a, NdtCtl* d_ctl, const double* d_sums48, NdtOut* d_out, hipStream_t s, double seq, int batch_mark) {
-    hipLaunchKernelGGL(ndt_ctl_kernel, dim3(1), dim3(64), 0, s, d_ctl, d_sums48, a.hdr, d_out, seq, batch_mark);
+    hipLaunchKernelGGL(ndt_ctl_kernel, dim3(1), dim3(64), 0, s, d_ctl, d_sums48, a.hdr, d_out, seq, batch_mark, (const uint32_t*)a.roi_escapes);
     return hipGetLastError();
 }
 

@@ -55,7 +55,8 @@ struct NdtCtl {
 struct NdtOut {
     NdtPose final_T;
     double score;
-    int32_t conv, nr_it, n_deriv, n_hess, bail, passes, grid_overflow, grid_empty, grid_stale, pad0;
+    int32_t conv, nr_it, n_deriv, n_hess, bail, passes, grid_overflow, grid_empty, grid_stale;
+    int32_t roi_escapes;    // lookups that hit a qualifying voxel outside the region the target was prepared for (RoiView): > 0 = repeat on the whole target
     uint64_t grid_cells;
     uint32_t ticks[4];
     double batch;           // sharded device loop: seq * 65536 + 2 * (batches finished) + done, written by the last controller step of a batch

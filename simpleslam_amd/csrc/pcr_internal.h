@@ -208,6 +208,27 @@ struct VgicpVoxel {          // fast_vgicp_voxel.hpp:59-82 (GaussianVoxel, ADDIT
     uint32_t n, pad;
 };
 
+// Region of interest of a target that is prepared for ONE scan (pcr_scan2map: the reference rebuilds its target structures for every
+// call -- fast_vgicp_impl.hpp:66-67, ndt_omp.h:276-283 -- but a scan can only ever look up the voxels near where its points land).
+// The lattice of the target index is grouped into macro cells of 2^mshift cells per axis (about 2 m); the macro cells that hold a scan
+// point at the initial pose are marked, every mark is spread over the macro cells within base + 0.05 x (distance from the sensor) metres
+// -- a translation of `base`, a rotation of 0.05 rad (grid_index.hip: roi_*) -- and only voxels inside marked macro cells are prepared (per-point covariances + voxel Gaussians for VGICP, voxel Gaussians for NDT).  Every lookup of the
+// optimiser checks the cell it hits: an occupied cell OUTSIDE the region is counted in *escapes, and the host then prepares the whole
+// target and repeats the call -- so the result is the full preparation's whenever the call succeeds (a pose that moves the scan by
+// more than the margin is rare and merely costs the repeat).
+struct RoiView {
+    const GridHeader* lat;       // the lattice (header of the target index); macro dims = ceil(dims / 2^mshift)
+    const uint8_t* mask;         // one byte per macro cell, != 0: prepared.  nullptr: no region -- everything is prepared
+    uint32_t* escapes;
+    int32_t mshift, pad_;
+};
+__host__ __device__ inline uint32_t roi_macro(const GridHeader& h, int mshift, int cx, int cy, int cz) {      // cell (cx, cy, cz) inside the lattice
+    const uint32_t m0 = ((uint32_t)h.dims[0] + (1u << mshift) - 1u) >> mshift, m1 = ((uint32_t)h.dims[1] + (1u << mshift) - 1u) >> mshift;
+    return (((uint32_t)cz >> mshift) * m1 + ((uint32_t)cy >> mshift)) * m0 + ((uint32_t)cx >> mshift);
+}
+hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
+                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp_a, uint8_t* d_tmp_b, uint8_t* d_mask, double base_m, double per_m, hipStream_t s);
+
 struct VgicpArgs {
     const float* src; uint32_t n_src, src_stride;
     const double* src_cov6;      // per source point, original order
@@ -223,20 +244,22 @@ struct VgicpArgs {
     double tile_lo[3], tile_hi[3];
     uint32_t* escapes;           // target index cut to the bulk of the cloud (header.clamped): count of source points that land within
     int32_t guard_cells, pad2_;  //   guard_cells voxels of a face with target points beyond it (their voxels' covariances may lack neighbours); else NULL
+    RoiView roi;                 // mask == nullptr: the whole target is prepared
 };
 
 // Halo check of a sharded target (pcr_set_shard): for every point inside [chk_lo, chk_hi) the 20th neighbour must be nearer
 // than the faces of [ext_lo, ext_hi) -- the region the rank's cloud is complete in; *violations counts the others.
 struct CovCheck { double chk_lo[3], chk_hi[3], ext_lo[3], ext_hi[3]; uint32_t* violations; };
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr);
-hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s);
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr, const RoiView* roi = nullptr);
+hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s, const RoiView* roi = nullptr);
 // (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
 // device-resident Levenberg-Marquardt loop (vgicp_opt.h): state in HBM, result in host-mapped memory
 struct VgCtl;
 struct VgOut;
-hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s);
+hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s,
+                                 uint32_t* d_roi_escapes = nullptr);
 hipError_t vgicp_launch_pass_pro(const VgicpArgs& a, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index);
 // out32[28] = compute_error(T); out32[0..27] = the linearisation at T (correspondences into a.corr_*_next)
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
@@ -273,15 +296,17 @@ struct NdtArgs {
     double* partials;        // [blocks][48]
     int32_t use_tile, pad_;  // sharded target: only source points whose transformed position lies in [tile_lo, tile_hi)
     double tile_lo[3], tile_hi[3];
+    uint32_t* roi_escapes;   // target prepared for one scan (RoiView): count of lookups that hit a voxel it was not prepared for; else NULL
 };
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
-                             int min_points, double eig_mult, hipStream_t s);
+                             int min_points, double eig_mult, hipStream_t s, const RoiView* roi = nullptr);
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq = 0.0);
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
 // device-resident optimiser (ndt_opt.h): controller state in HBM, result in host-mapped memory
 struct NdtCtl;
 struct NdtOut;
-hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay = 0);
+hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay = 0,
+                               uint32_t* d_roi_escapes = nullptr);
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq);
 hipError_t ndt_launch_pass_pro(const NdtArgs& a, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index);
 hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums48, hipStream_t s);

@@ -224,11 +224,20 @@ __device__ inline void sym3_eig(const double A[6] /* xx xy xz yy yz zz */, doubl
 // ------------------------------------------------------------------------------
 static constexpr int kCovK = 20;
 
+// is the voxel that the point (x, y, z) belongs to inside the prepared region?  (lat: the voxel lattice's header)
+__device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHeader& lat, double x, double y, double z) {
+    const double fx = floor(x / lat.cell - lat.shift) - lat.org[0], fy = floor(y / lat.cell - lat.shift) - lat.org[1], fz = floor(z / lat.cell - lat.shift) - lat.org[2];
+    if (!(fx >= 0.0 && fx < (double)lat.dims[0] && fy >= 0.0 && fy < (double)lat.dims[1] && fz >= 0.0 && fz < (double)lat.dims[2])) return false;
+    return roi.mask[roi_macro(lat, roi.mshift, (int)fx, (int)fy, (int)fz)] != 0;
+}
+
 __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
                                                         uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6, const int use_check,
-                                                        const CovCheck chk) {
+                                                        const CovCheck chk, const RoiView roi) {
     const GridHeader h = *g.hdr;
     if (h.empty || h.overflow) return;
+    GridHeader lat;
+    if (roi.mask) lat = *roi.lat;
     GridLevels lv;
     lv.hdr[0] = g.hdr; lv.pts[0] = g.pts; lv.cell_start[0] = g.cell_start;
     lv.hdr[1] = g1.hdr; lv.pts[1] = g1.pts; lv.cell_start[1] = g1.cell_start;
@@ -239,6 +248,8 @@ __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1,
     const uint32_t n = g.cell_start[h.n_cells];   // points actually indexed (finite ones)
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n && j < n_sorted_max; j += gridDim.x * 256) {
         const float4 q = g.pts[j];
+        // a target prepared for one scan: only the points whose voxel the scan can reach (the search itself always sees the whole cloud)
+        if (roi.mask && !roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z)) continue;
         KeyList<kCovK> L;
         ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L);
         // fast_gicp_impl.hpp:255-262: neighbours as f64, minus their mean, N N^T / k
@@ -320,7 +331,7 @@ __device__ __forceinline__ bool lattice_key(const GridHeader& h, double x, doubl
     return true;
 }
 
-__global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const double* __restrict__ cov6, VgicpVoxel* __restrict__ vox) {
+__global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const double* __restrict__ cov6, VgicpVoxel* __restrict__ vox, const RoiView roi) {
     const GridHeader h = *g.hdr;
     if (h.overflow || h.empty) return;
     const uint32_t n = g.cell_start[h.n_cells];
@@ -330,6 +341,7 @@ __global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const doub
         double c[3];
         if (!lattice_key(h, (double)q.x, (double)q.y, (double)q.z, &key, c)) continue;
         if (g.cell_start[key] != j) continue;                 // not the first point of its voxel
+        if (roi.mask && roi.mask[roi_macro(h, roi.mshift, (int)(c[0] - h.org[0]), (int)(c[1] - h.org[1]), (int)(c[2] - h.org[2]))] == 0) continue;      // out of the scan's reach
         const uint32_t e = g.cell_start[key + 1];
         const double ox = (c[0] + h.shift) * h.cell, oy = (c[1] + h.shift) * h.cell, oz = (c[2] + h.shift) * h.cell;   // lower corner
         const uint32_t cnt = e - j;
@@ -381,12 +393,17 @@ __device__ __forceinline__ void inv3_sym(const double S[6], double M[6]) {
     M[3] = (a * f - c * c) * id; M[4] = (b * c - a * e) * id; M[5] = (a * d - b * b) * id;
 }
 
-__device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint32_t* __restrict__ cell_start, const double tp[3]) {
+// roi: a voxel that exists but lies outside the prepared region is an ESCAPE (counted; the host prepares the whole target and repeats)
+__device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint32_t* __restrict__ cell_start, const double tp[3], const RoiView& roi) {
     if (h.overflow || h.empty) return 0;
     uint32_t key;
     double c[3];
     if (!lattice_key(h, tp[0], tp[1], tp[2], &key, c)) return 0;
     const uint32_t s = cell_start[key], e = cell_start[key + 1];
+    if (e > s && roi.mask && roi.mask[roi_macro(h, roi.mshift, (int)(c[0] - h.org[0]), (int)(c[1] - h.org[1]), (int)(c[2] - h.org[2]))] == 0) {
+        atomicAdd(roi.escapes, 1u);
+        return 0;
+    }
     return e > s ? s + 1 : 0;
 }
 
@@ -401,7 +418,7 @@ __device__ __forceinline__ void vgicp_lin_point(const VgicpArgs& a, const GridHe
     double tp[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) tp[r] = T.m[r] * p[0] + T.m[4 + r] * p[1] + T.m[8 + r] * p[2] + T.m[12 + r] * 1.0;
-    uint32_t slot = vgicp_lookup(h, a.cell_start, tp);
+    uint32_t slot = vgicp_lookup(h, a.cell_start, tp, a.roi);
     if (a.escapes && h.clamped) {
         // The index covers only the bulk of the target (a stray point made its box too large for dense tables).  A source point that
         // lands near -- or beyond -- a face behind which target points were left out would meet voxels whose covariances lack
@@ -607,7 +624,9 @@ __global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_i
                 VgOut* const out = pa.out;
                 if (c->done) {
                     out->x0 = c->x0;
-                    out->conv = c->conv; out->outer = c->outer; out->n_lin = c->n_lin; out->n_err = c->n_err; out->passes = c->passes; out->pad0 = 0;
+                    out->conv = c->conv; out->outer = c->outer; out->n_lin = c->n_lin; out->n_err = c->n_err; out->passes = c->passes;
+                    // (every pass ran in an earlier launch of this stream: the count is final)
+                    out->roi_escapes = a_in.roi.mask ? (int32_t)min(*a_in.roi.escapes, 0x7fffffffu) : 0;
                     __threadfence_system();
                     __hip_atomic_store(&out->seq, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
@@ -636,8 +655,9 @@ __global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_i
 }
 
 struct VgCtlArg { uint32_t w[kVgCtlWords]; };
-__global__ __launch_bounds__(256) void vgicp_ctl_store_kernel(VgCtl* __restrict__ ctl, const VgCtlArg init) {
+__global__ __launch_bounds__(256) void vgicp_ctl_store_kernel(VgCtl* __restrict__ ctl, const VgCtlArg init, uint32_t* __restrict__ roi_escapes) {
     for (int t = threadIdx.x; t < kVgCtlWords; t += 256) reinterpret_cast<uint32_t*>(ctl)[t] = init.w[t];
+    if (roi_escapes && threadIdx.x == 0) *roi_escapes = 0u;
 }
 
 // fold per-block partials (32 doubles each) into 32 doubles, fixed order
@@ -720,21 +740,27 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
 
 // ---- host launchers ---------------------------------------------------------------
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check) {
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi) {
     const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
     const int levels = coarse1 ? (coarse2 ? 3 : 2) : 1;
     CovCheck chk;
     memset(&chk, 0, sizeof chk);
     if (check) chk = *check;
+    RoiView rv;
+    memset(&rv, 0, sizeof rv);
+    if (roi) rv = *roi;
     hipLaunchKernelGGL(vgicp_cov_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
-                       coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk);
+                       coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv);
     return hipGetLastError();
 }
 
-hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s) {
+hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s, const RoiView* roi) {
     const size_t n = grid.n_points;
     const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
-    hipLaunchKernelGGL(vgicp_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_cov6, d_vox);
+    RoiView rv;
+    memset(&rv, 0, sizeof rv);
+    if (roi) rv = *roi;
+    hipLaunchKernelGGL(vgicp_voxel_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_cov6, d_vox, rv);
     return hipGetLastError();
 }
 
@@ -750,13 +776,14 @@ hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d
     return hipGetLastError();
 }
 
-hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s) {
+hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s,
+                                 uint32_t* d_roi_escapes) {
     VgCtl c;
     memset(&c, 0, sizeof c);
     vg_opt::ctl_init(&c, guess, max_iters, lm_inner, lm_init_scale, rot_eps, trans_eps);
     VgCtlArg arg;
     memcpy(arg.w, &c, sizeof c);
-    hipLaunchKernelGGL(vgicp_ctl_store_kernel, dim3(1), dim3(256), 0, s, d_ctl2, arg);
+    hipLaunchKernelGGL(vgicp_ctl_store_kernel, dim3(1), dim3(256), 0, s, d_ctl2, arg, d_roi_escapes);
     return hipGetLastError();
 }
 // launch `index` of the device-resident loop: d_ctl2 = two VgCtl, d_rows2 = two buffers of 512 * 32 doubles

@@ -43,8 +43,9 @@ struct VgCtl {
 // what the device-resident loop reports (host-mapped memory; `seq` is written last)
 struct VgOut {
     Pose16 x0;
-    int32_t conv, outer, n_lin, n_err, passes, pad0;
-    double progress;         // seq * 4096 + passes consumed so far
+    int32_t conv, outer, n_lin, n_err, passes;
+    int32_t roi_escapes;     // lookups that hit an occupied voxel outside the region the target was prepared for (RoiView): > 0 = repeat on the whole target
+    double progress;         // seq * kProgressWindow + passes consumed so far
     double seq;
 };
 

@@ -245,3 +245,22 @@ def test_replayed_line_search_evaluations_change_nothing_but_the_number_of_passe
         assert sf["attempts"] <= ss["attempts"] and ss["attempts"] == ss["kernel_launches"], (seed, sf, ss)
         saved += ss["attempts"] - sf["attempts"]
     assert saved > 0
+
+
+@pytest.mark.parametrize("off", [0.1, 5.0])
+def test_target_prepared_for_the_scans_region_only(gpu, nd_world, off):
+    """as tests/test_vgicp_gpu.py::test_target_prepared_for_the_scans_region_only: voxel Gaussians only where the scan can land, the whole
+    target when the pose leaves that region -- the pose of the full preparation either way, bit for bit"""
+    w = nd_world
+    T0 = w["truth"].copy()
+    T0[:3, 3] += np.array([off, -0.5 * off, 0.0])
+    full = NdtRegister(full_target=1)
+    pf = T0.copy(); cf = full.scan2Map(w["scan"], w["map"], pf)
+    reg = NdtRegister()
+    p = T0.copy(); c = reg.scan2Map(w["scan"], w["map"], p)
+    assert c == cf
+    np.testing.assert_array_equal(p, pf)
+    assert reg.stats()["iterations"] == full.stats()["iterations"]
+    assert full.stats()["region_repeats"] == 0
+    if off < 1.0:
+        assert reg.stats()["region_repeats"] == 0

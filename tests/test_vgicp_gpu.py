@@ -259,3 +259,27 @@ def test_one_handle_through_a_sequence_of_unrelated_targets(gpu, vg_world):
         c_used = reg.scan2Map(scan, m, p_used)
         assert c_used == c_fresh, (case, kind)
         np.testing.assert_array_equal(p_used, p_fresh, err_msg=f"case {case} kind {kind}")
+
+
+@pytest.mark.parametrize("off", [0.25, 4.0])
+def test_target_prepared_for_the_scans_region_only(gpu, vg_world, off):
+    """pcr_scan2map prepares covariances and voxels only where the scan can land (a 2 m margin around its points at the initial pose); a
+    pose that carries the scan out of that region makes the call repeat on the whole target.  Either way: the pose of the full
+    preparation (pcr_params.full_target = 1, what the reference computes), bit for bit."""
+    w = vg_world
+    T0 = w["truth"].copy()
+    T0[:3, 3] += np.array([off, -0.6 * off, 0.05 * off])
+    full = VgicpRegister(full_target=1)
+    pf = T0.copy(); cf = full.scan2Map(w["scan"], w["map"], pf)
+    reg = VgicpRegister()
+    p = T0.copy(); c = reg.scan2Map(w["scan"], w["map"], p)
+    assert c == cf
+    np.testing.assert_array_equal(p, pf)
+    assert reg.stats()["iterations"] == full.stats()["iterations"]
+    rep = reg.stats()["region_repeats"]
+    assert full.stats()["region_repeats"] == 0
+    assert rep == 0 if off < 1.0 else rep in (0, 1), rep      # 0.25 m stays inside the margin; a start 4 m off may end (or wander) outside it
+    # the handle must not pass a partially prepared target on to pcr_align
+    if rep == 0:
+        with pytest.raises(Exception, match="prepares its target for that one scan only"):
+            reg.align(w["scan"], T0.copy())
