@@ -559,6 +559,7 @@ int settle_grid(pcr_handle* h, GridIndex& g, const float* d_pts, size_t n, size_
 // whole scan2map on one box: 3 x 4: 0.906 ms, 2 x 4: 0.917, 2 x 5: 0.890, 2 x 6: 0.875, 2 x 7: 0.900, 2 x 8: 0.880, 3 x 6: 0.975, 2 x 12: 1.25.
 // (PCR_COV_LEVELS / PCR_COV_RATIO override for such runs.)
 static int cov_levels_small() { static const int v = dev_env("PCR_COV_LEVELS") ? atoi(dev_env("PCR_COV_LEVELS")) : 2; return v < 1 ? 1 : (v > 3 ? 3 : v); }
+static double src_cell0() { static const double v = dev_env("PCR_COV_CELL0") ? atof(dev_env("PCR_COV_CELL0")) : 1.0; return v > 0 ? v : 1.0; }      // (development: cell of a scan's own search levels, in voxels)
 static double cov_ratio() { static const double v = dev_env("PCR_COV_RATIO") ? atof(dev_env("PCR_COV_RATIO")) : 6.0; return v; }
 int cov_levels(size_t n) { return n <= 300000 ? cov_levels_small() : 1; }
 
@@ -584,7 +585,10 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
         GridHeader hdr[3];
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
-            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr) != hipSuccess) return 1;
+            // (the box and the tile layout of this index's previous build serve as hints -- GridIndex::hint_ok: a sub-map changes by a key frame
+            //  at a time, a scan's box in the sensor frame hardly at all; a cloud that does not fit raises header.stale and is built afresh)
+            lv[l]->no_hints = h->prm.index_no_hints != 0;
+            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, true) != hipSuccess) return 1;
             if (l == 0 && hdr0_out) H_TRY(lv[l]->enqueue_density(h->stream));
             H_TRY(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
@@ -593,15 +597,22 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
         GridHeader hdr_ahead;
         const bool ahead = ahead_cell > 0.0 && levels == 1 && attempt == 0 && !(h->clamp.use && may_cut);
         if (ahead) {
-            if (l1.build(d_pts, n, stride_floats, ahead_cell, h->stream, &h->err, 0.0, 0, nullptr) != hipSuccess) return 1;
+            l1.no_hints = h->prm.index_no_hints != 0;
+            if (l1.build(d_pts, n, stride_floats, ahead_cell, h->stream, &h->err, 0.0, 0, nullptr, true) != hipSuccess) return 1;
             H_TRY(hipMemcpyAsync(&hdr_ahead, l1.header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
         H_TRY(hipStreamSynchronize(h->stream));
         if (ahead_ok) *ahead_ok = false;
-        if (ahead && !hdr_ahead.overflow) { l1.note_cells(hdr_ahead.n_cells); if (ahead_ok) *ahead_ok = true; }
+        if (ahead && hdr_ahead.stale) { l1.hint_margin = 8; l1.cells_hint = 0; }      // (built afresh by the caller: it checks ahead_ok)
+        else if (ahead && !hdr_ahead.overflow) { l1.note_cells(hdr_ahead.n_cells); if (!hdr_ahead.empty) l1.confirm(); if (ahead_ok) *ahead_ok = true; }
         bool again = false;
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
+            if (hdr[l].stale) {      // the box (or a tile's room) taken over from the previous build does not hold this cloud: fresh box, padded from now on
+                lv[l]->hint_margin = 8; lv[l]->cells_hint = 0;
+                again = true;
+                continue;
+            }
             if (hdr[l].overflow) {
                 if (hdr[l].n_cells > 4000000000ull && may_cut && !h->clamp.use) {
                     // a box no dense table can hold (a stray point far from the map): index the bulk of the cloud instead, all levels alike
@@ -613,7 +624,7 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
                 if (lv[l]->grow_cells(hdr[l].n_cells, &h->err) != hipSuccess) return 1;
                 again = true;
             }
-            else { todo[l] = false; lv[l]->note_cells(hdr[l].n_cells); if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
+            else { todo[l] = false; lv[l]->note_cells(hdr[l].n_cells); if (!hdr[l].empty && !h->clamp.use) lv[l]->confirm(); if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
         }
         if (!again) return 0;
     }
@@ -638,7 +649,9 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
     // have drained (the caller is free to release d_src as soon as the call has failed)
     hipError_t e = hipSuccess;
     for (int l = 0; l < levels && e == hipSuccess; ++l) {
-        e = lv[l]->build(d_src, n_src, stride_floats, cells[l], h->side_stream, &h->err, 0.0);
+        // (no hints here: the box and the tile layout of one scan do not hold the next -- walls at other distances, other tiles crowded;
+        //  measured: every call's hint failed and the redo cost 0.9 ms)
+        e = lv[l]->build(d_src, n_src, stride_floats, src_cell0() * cells[l], h->side_stream, &h->err, 0.0);
         if (e == hipSuccess && (e = hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream)) != hipSuccess)
             h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
     }
@@ -665,10 +678,13 @@ int vgicp_source_settle(pcr_handle* h, const float* d_src, size_t n_src, size_t 
         h->side_pending = false;
         H_TRY(hipEventSynchronize(h->ev_side_done));
         bool overflow = false;
-        for (int l = 0; l < levels; ++l) overflow = overflow || h->side_hdr[l].overflow != 0;
+        GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
+        for (int l = 0; l < levels; ++l) {
+            overflow = overflow || h->side_hdr[l].overflow != 0 || h->side_hdr[l].stale != 0;
+            if (h->side_hdr[l].stale) { lv[l]->hint_margin = 8; lv[l]->cells_hint = 0; }      // (redone below, with a fresh box)
+        }
         if (!overflow) {
-            GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
-            for (int l = 0; l < levels; ++l) lv[l]->note_cells(h->side_hdr[l].n_cells);
+            for (int l = 0; l < levels; ++l) { lv[l]->note_cells(h->side_hdr[l].n_cells); if (!h->side_hdr[l].empty) lv[l]->confirm(); }
             H_TRY(hipStreamWaitEvent(h->stream, h->ev_side_done, 0));
             return 0;
         }

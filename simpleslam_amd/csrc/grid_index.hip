@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
                 continue;
             }
             double clo = floor((double)lo / cell - shift), chi = floor((double)hi / cell - shift);
-            if (d < 2 && !h.empty) { clo -= margin_xy; chi += margin_xy; }      // room for the next cloud (see GridIndex::hint_ok)
+            if (!h.empty) {      // room for the next cloud (see GridIndex::hint_ok): a sub-map grows sideways, a scan's box breathes on every axis
+                const int mg = d < 2 ? margin_xy : (margin_xy < 2 ? margin_xy : 2);
+                clo -= mg; chi += mg;
+            }
             h.org[d] = clo - kPad;
             h.origin[d] = (clo - kPad + shift) * cell;
             double dim = chi - clo + 1.0 + 2.0 * kPad;

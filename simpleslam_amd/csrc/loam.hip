@@ -591,7 +591,7 @@ template <int kGroup>
 __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h, const double* __restrict__ pose,
                                           float sx, float sy, float sz, bool valid, const NnCacheEntry& ce_in, bool have_entry,
                                           KnnRuns& sh, MissExchange& ex, double row[7], uint32_t nn_idx[5], uint32_t qi, int* how,
-                                          bool* escaped, unsigned long long* tl) {
+                                          bool* escaped, unsigned long long* tl, const bool all_search = false) {
     const double ox = (double)sx, oy = (double)sy, oz = (double)sz;
     // LoamRegister.cpp:126-130: Isometry3d * Vector4d in f64, then cast to f32
     const float px = (float)(pose[0] * ox + pose[4] * oy + pose[8] * oz + pose[12] * 1.0);
@@ -630,6 +630,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
 #pragma unroll
     for (int r = 0; r < 9; ++r) { own_ranges.ra[r] = 0u; own_ranges.rb[r] = 0u; }
     if (__any(miss)) knn_ranges_issue(h, a.grid.cell_start, px, py, pz, miss, own_ranges);      // (wave-uniform: nothing is loaded in an all-hit wave)
+    if (!all_search) {      // (block-uniform)
     if (tid == 0) ex.count = 0;
     __syncthreads();
     if (miss) {
@@ -647,6 +648,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         ex.seed[tid] = sb;
     }
     __syncthreads();
+    }
     if (tl) tl[2] = wall_clock64();
     // ---- the posted queries are searched: a few -> one wave per query (lanes = candidates); many -> thread m
     //      serves the m-th posted query (lanes = queries) ----
@@ -654,7 +656,7 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
     uint32_t self_pos[kNb], self_state = 0u;
     double self_bound = 0.0;
     {
-        const uint32_t n_miss = ex.count;           // block-uniform
+        const uint32_t n_miss = all_search ? 256u : ex.count;           // block-uniform
         bool dense = n_miss > (uint32_t)kSparseMisses;
         if (n_miss && !dense) {
             if (tid == 0) ex.fallback = 0;
@@ -848,9 +850,11 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
 // Every block runs it and obtains bit-identical results.  Returns true when this
 // launch must not linearise (loop finished).
 // ------------------------------------------------------------------------------
+static constexpr double kBigStep = 0.12;      // metres at 10 m from the sensor: |rho| + 10 |omega| of the Gauss-Newton step
 struct Prologue {
     double pose[16];
     int done;
+    int big_step;      // the step just applied moves the scan by more than a neighbour cache entry survives: this launch searches every query afresh
 };
 
 // 16 bytes per lane from global memory straight into LDS (lane i lands at lds_wave_base + 16 i); completion is
@@ -868,7 +872,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     const int t = threadIdx.x;
     if (k == 0) {
         if (t < 16) sh->pose[t] = a.init_pose[t];
-        if (t == 0) sh->done = 0;
+        if (t == 0) { sh->done = 0; sh->big_step = 0; }
         if (blockIdx.x == 0 && t == 0) {
             for (int i = 0; i < 16; ++i) cur->pose[i] = a.init_pose[i];
             cur->done = 0; cur->converged = 0; cur->iters_run = 0; cur->fail = 0;
@@ -931,7 +935,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         return true;
     }
     if (kAblation && (a.ablate & 4)) {
-        if (t == 0) sh->done = k >= a.c.iters;
+        if (t == 0) { sh->done = k >= a.c.iters; sh->big_step = 0; }
         if (blockIdx.x == 0 && t == 0) { *cur = *prev; cur->done = k >= a.c.iters; cur->iters_run = k; }
         __syncthreads();
         return k >= a.c.iters;
@@ -1010,6 +1014,13 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         if (k >= a.c.iters) done = 1;
         for (int i = 0; i < 16; ++i) sh->pose[i] = pose[i];
         sh->done = done;
+        // A cache entry proves its five neighbours while the query has moved by less than the gap between the 5th and the 9th neighbour
+        // distance -- centimetres on a 0.5 m map.  A step that moves a point 10 m from the sensor by more than kBigStep makes four
+        // entries in five fail (launch 1 after a 0.3 m / 2 degree guess: 52 682 of 65 536): then nobody reads or tests an entry and
+        // every lane searches its own query, without the exchange.  A performance decision only -- a search is exact whatever the cache
+        // would have said.  Measured (A/B on one box, profiles/r03_notes.md): launch 1 30.5 -> 28.6 us, and launch 2 searches 7 140
+        // instead of 11 682 queries because every entry is now anchored at the pose after the big step; 3 803 -> 3 894 scans/s.
+        sh->big_step = (!done && sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) + 10.0 * sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]) > kBigStep) ? 1 : 0;
         if (blockIdx.x == 0) {
             for (int i = 0; i < 16; ++i) cur->pose[i] = pose[i];
             cur->done = done; cur->converged = conv; cur->fail = fail; cur->iters_run = k;
@@ -1107,7 +1118,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
             // the staging area is reused right after the barrier, and a transfer still in flight would land in the search
             // scratch of the other waves.
             if (use_cache) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (use_cache && valid) {
+            if (use_cache && valid && !sh_pro.big_step) {
 #pragma unroll
                 for (int f = 0; f < kEntryVec; ++f) ce.v[f] = sh_pre[f * 256 + tid];
             }
@@ -1120,7 +1131,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
                 if (use_cache) ce.e = a.nn_cache[q];
             }
         }
-        const int st = loam_point<kGroup>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid, sh_knn, sh_ex, row, nn, q, &how, &esc, base == blk * 256 ? tl : nullptr);
+        const bool all_search = sh_pro.big_step != 0 && base == blk * 256;      // (later rounds of a grid-stride launch go the ordinary way)
+        const int st = loam_point<kGroup>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid && !all_search, sh_knn, sh_ex, row, nn, q, &how, &esc,
+                                          base == blk * 256 ? tl : nullptr, all_search);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const size_t oi = (size_t)q;
             if (a.dbg_status) a.dbg_status[oi] = (int8_t)st;
