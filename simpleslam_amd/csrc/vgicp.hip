@@ -74,9 +74,11 @@ struct GridLevels {
 };
 
 // Rings first..last of one level.  Returns true when the K-th distance is final (or nothing can lie beyond).
+static constexpr bool kBatchRing1 = true;      // (taken only where the caller hands an LDS table over)
+// rows: 9 x 256 uint2 of LDS (this block's), or nullptr (callers outside a 256-thread block layout)
 template <int K, bool DEDUPE>
 __device__ __forceinline__ bool ring_level(const GridHeader& h, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                           float qx, float qy, float qz, float max_sq, int last_ring, KeyList<K>& L) {
+                                           float qx, float qy, float qz, float max_sq, int last_ring, KeyList<K>& L, uint2* rows = nullptr) {
     const int d0 = h.dims[0], d1 = h.dims[1], d2 = h.dims[2];
     double fx = floor((double)qx / h.cell - h.shift) - h.org[0], fy = floor((double)qy / h.cell - h.shift) - h.org[1],
            fz = floor((double)qz / h.cell - h.shift) - h.org[2];
@@ -90,6 +92,31 @@ __device__ __forceinline__ bool ring_level(const GridHeader& h, const float4* __
         const int z0 = max(cz - r, 0), z1 = min(cz + r, d2 - 1), y0 = max(cy - r, 0), y1 = min(cy + r, d1 - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, d0 - 1);
         const float worst = __uint_as_float((uint32_t)(L.k[K - 1] >> 32));
+        if (kBatchRing1 && r == 1 && rows) {
+            // Ring 1 -- the nine rows of the 3 x 3 x 3 block, for most points the whole search of a level -- with ALL its row ranges
+            // requested at once (18 independent loads) instead of row by row: a scan point's search is a chain of dependent round
+            // trips at one wave per SIMD, and the nine pairs were nine of them.  The ranges wait in this lane's slots of the block's
+            // LDS table; rows are then walked in the same order, each tested against the K-th distance as it stands.
+            uint32_t ra[9], rb[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
+                const bool in = z >= 0 && z < d2 && y >= 0 && y < d1;
+                const uint32_t row = in ? ((uint32_t)z * (uint32_t)d1 + (uint32_t)y) * (uint32_t)d0 : 0u;
+                ra[i] = cell_start[in ? row + (uint32_t)x0 : 0u]; rb[i] = cell_start[in ? row + (uint32_t)x1 + 1u : 0u];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rows[i * 256 + threadIdx.x] = make_uint2(ra[i], rb[i]);
+            for (int i = 0; i < 9; ++i) {
+                const uint2 rg = rows[i * 256 + threadIdx.x];      // (each lane reads back what it wrote: no barrier)
+                if (rg.y <= rg.x) continue;
+                const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
+                const float zlo = (float)((o2 + z) * h.cell), gz = fmaxf(fmaxf(zlo - qz, qz - (zlo + cellf)), 0.f) * 0.99999f;
+                const float ylo = (float)((o1 + y) * h.cell), gy = fmaxf(fmaxf(ylo - qy, qy - (ylo + cellf)), 0.f) * 0.99999f;
+                if (gy * gy + gz * gz > __uint_as_float((uint32_t)(L.k[K - 1] >> 32))) continue;
+                ring_scan_run<K, DEDUPE>(pts, rg.x, rg.y, qx, qy, qz, L);
+            }
+        } else
         for (int z = z0; z <= z1; ++z) {
             // distance from the query to the slab of cells z (0 inside it); float, shaved so that it never exceeds the true gap
             const float zlo = (float)((o2 + z) * h.cell), gz = fmaxf(fmaxf(zlo - qz, qz - (zlo + cellf)), 0.f) * 0.99999f;
@@ -134,19 +161,19 @@ __device__ __forceinline__ bool ring_level(const GridHeader& h, const float4* __
 // sentinels at that radius so that, in a crowded cell, the thousands of farther candidates are rejected by one
 // compare instead of being inserted and displaced again.
 template <int K>
-__device__ __forceinline__ void ring_knn_pass(const GridLevels& lv, float qx, float qy, float qz, float max_sq, float seed_sq, KeyList<K>& L) {
+__device__ __forceinline__ void ring_knn_pass(const GridLevels& lv, float qx, float qy, float qz, float max_sq, float seed_sq, KeyList<K>& L, uint2* rows) {
     const unsigned long long sentinel = ((unsigned long long)__float_as_uint(seed_sq) << 32) | 0xffffffffull;
 #pragma unroll
     for (int i = 0; i < K; ++i) L.k[i] = sentinel;
-    bool done = ring_level<K, false>(*lv.hdr[0], lv.pts[0], lv.cell_start[0], qx, qy, qz, max_sq, lv.n > 1 ? 2 : 0x7fffffff, L);
+    bool done = ring_level<K, false>(*lv.hdr[0], lv.pts[0], lv.cell_start[0], qx, qy, qz, max_sq, lv.n > 1 ? 2 : 0x7fffffff, L, rows);
     for (int l = 1; l < lv.n; ++l) {
         if (done) break;
-        done = ring_level<K, true>(*lv.hdr[l], lv.pts[l], lv.cell_start[l], qx, qy, qz, max_sq, l + 1 < lv.n ? 2 : 0x7fffffff, L);
+        done = ring_level<K, true>(*lv.hdr[l], lv.pts[l], lv.cell_start[l], qx, qy, qz, max_sq, l + 1 < lv.n ? 2 : 0x7fffffff, L, rows);
     }
 }
 
 template <int K>
-__device__ __forceinline__ void ring_knn(const GridLevels& lv, float qx, float qy, float qz, float max_sq, KeyList<K>& L) {
+__device__ __forceinline__ void ring_knn(const GridLevels& lv, float qx, float qy, float qz, float max_sq, KeyList<K>& L, uint2* rows = nullptr) {
     const GridHeader& h = *lv.hdr[0];
     if (h.empty || h.overflow) {
 #pragma unroll
@@ -164,9 +191,9 @@ __device__ __forceinline__ void ring_knn(const GridLevels& lv, float qx, float q
             if (nc >= 4u * (uint32_t)K) seed = (float)(h.cell * h.cell) * (2.0f * (float)K / (3.14159265f * (float)nc));
         }
     }
-    ring_knn_pass<K>(lv, qx, qy, qz, max_sq, seed, L);
+    ring_knn_pass<K>(lv, qx, qy, qz, max_sq, seed, L, rows);
     if (seed < 3.0e38f && (uint32_t)L.k[K - 1] == 0xffffffffu)      // the seed radius held fewer than K points: exact redo
-        ring_knn_pass<K>(lv, qx, qy, qz, max_sq, 3.0e38f, L);
+        ring_knn_pass<K>(lv, qx, qy, qz, max_sq, 3.0e38f, L, rows);
 #pragma unroll
     for (int i = 0; i < K; ++i) if ((uint32_t)L.k[i] == 0xffffffffu) L.k[i] = ~0ull;   // unfilled slots
 }
@@ -231,9 +258,15 @@ __device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHe
     return roi.mask[roi_macro(lat, roi.mshift, (int)fx, (int)fy, (int)fz)] != 0;
 }
 
+// kBatch: ring 1 of every level with its nine row ranges requested at once (ring_level).  For a SCAN-sized cloud, whose search is a chain
+// of dependent round trips at one wave per SIMD: A/B on one box, the scan's 65 k covariances no longer hold the optimiser up (align 0.19 ->
+// 0.11 ms).  A map-sized cloud runs the same kernel at four waves per SIMD and is bound by instruction issue: there the batched form
+// costs 0.83 -> 1.28 ms per million points, so it keeps the row-by-row walk.
+template <bool kBatch>
 __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
                                                         uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6, const int use_check,
                                                         const CovCheck chk, const RoiView roi) {
+    __shared__ uint2 sh_rows[kBatch ? 9 * 256 : 1];      // row ranges of ring 1 (ring_level)
     const GridHeader h = *g.hdr;
     if (h.empty || h.overflow) return;
     GridHeader lat;
@@ -251,7 +284,7 @@ __global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1,
         // a target prepared for one scan: only the points whose voxel the scan can reach (the search itself always sees the whole cloud)
         if (roi.mask && !roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z)) continue;
         KeyList<kCovK> L;
-        ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L);
+        ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L, kBatch ? sh_rows : nullptr);
         // fast_gicp_impl.hpp:255-262: neighbours as f64, minus their mean, N N^T / k
         double mx = 0, my = 0, mz = 0;
         int found = 0;
@@ -749,8 +782,12 @@ hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, con
     RoiView rv;
     memset(&rv, 0, sizeof rv);
     if (roi) rv = *roi;
-    hipLaunchKernelGGL(vgicp_cov_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
-                       coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv);
+    if (n <= 300000)      // scan-sized (the same threshold as the choice of search levels, capi.hip: cov_levels)
+        hipLaunchKernelGGL(vgicp_cov_kernel<true>, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
+                           coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv);
+    else
+        hipLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
+                           coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv);
     return hipGetLastError();
 }
 
