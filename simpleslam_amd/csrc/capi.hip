@@ -735,13 +735,14 @@ RoiView roi_view(const pcr_handle* h) {      // the region the handle's target w
     return v;
 }
 
-int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, const RoiScan* roi_scan = nullptr) {
+// keep_clamp: the caller has set h->clamp (a region cut around a scan, vgicp_align_recut): index that region instead of deciding here
+int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, const RoiScan* roi_scan = nullptr, bool keep_clamp = false) {
     h->vg_target_ready = false;
     h->roi_on = false;
     const double res = h->prm.vgicp_resolution;
     if (!(res > 0)) return fail(h, "vgicp_resolution must be positive");
     if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
-    h->clamp.use = 0;
+    if (!keep_clamp) h->clamp.use = 0;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats;
     // (unsharded: a cloud too spread out for dense tables is cut to its bulk, settle_cov_levels; a rank of a sharded call refuses it)
     static const bool no_ahead = dev_env("PCR_COV_NO_AHEAD") != nullptr;      // (A/B runs)
@@ -928,8 +929,10 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         uint32_t esc = 0;
         H_TRY(hipMemcpyAsync(&esc, a.escapes, sizeof esc, hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
-        if (esc) return fail(h, "the target is too spread out for the dense voxel tables (a stray point far from the map?) and was cut to its bulk, but the scan reaches "
-                                "the part that was left out: range-filter the target");
+        // the scan reaches (the reach of a covariance of) a face the index was cut at: 3 -- the caller cuts the target around THIS scan
+        // and repeats (vgicp_align_recut); a rank of a sharded call cannot (its peers would be left in their collectives)
+        if (esc) { h->err = "the target is too spread out for the dense voxel tables (a stray point far from the map?) and was cut to its bulk, but the scan reaches "
+                            "the part that was left out"; return 3; }
     }
     for (int i = 0; i < 16; ++i) pose[i] = (double)(float)x0.m[i];     // final_transformation_ is a Matrix4f
     if (converged) *converged = conv ? 1 : 0;
@@ -961,6 +964,30 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     h->stats.iterations = h->vg_outer; h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
     h->stats.kernel_launches = h->vg_lin + h->vg_err;
     return 0;
+}
+
+// run_vgicp, and when the scan reached a cut face of an index that could not hold the whole target (a stray point kilometres away,
+// a second cluster far off): the target cut around the scan itself -- its box at the initial pose plus the reach of a covariance plus
+// room to move, doubled for as long as the scan still reaches a cut face -- and the alignment again from the same guess.  The
+// reference's hash map and kd-tree serve any extent (fast_vgicp_voxel.hpp:129-156); with this a dense table does too, wherever the
+// scan is.  d_dst: the target's points (the caller's buffer of a scan2map call, the staged copy of pcr_set_target, a sub-map).
+int vgicp_align_recut(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged) {
+    double pose_in[16];
+    memcpy(pose_in, pose, sizeof pose_in);
+    int rc = run_vgicp(h, d_src, n_src, stride_floats, pose, converged);
+    if (rc != 3) return rc;
+    if (sharded(h)) return 1;      // (h->err says what happened)
+    const double reach = std::max(4.0, 8.0 * h->prm.vgicp_resolution);
+    h->clamp_margin = reach + kClampMargin;
+    for (int attempt = 0; attempt < kClampRetries && rc == 3; ++attempt) {
+        memcpy(pose, pose_in, sizeof pose_in);
+        if (set_clamp_from_scan(h, d_src, n_src, stride_floats, pose_in)) return 1;
+        if (vgicp_prepare_target(h, h->tgt_ptr, h->tgt_n, h->tgt_stride, nullptr, true)) return 1;
+        rc = run_vgicp(h, d_src, n_src, stride_floats, pose, converged);
+        h->clamp_margin *= 2.0;
+    }
+    if (rc == 3) return fail(h, "the pose left every region the target could be indexed over (a target too sparse for dense voxel tables and an optimiser that wanders)");
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1307,11 +1334,11 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
             return 1;
         }
         if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
-        int rrc = run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged);
+        int rrc = vgicp_align_recut(h, d_src, n_src, stride_bytes / 4, pose, converged);
         if (rrc == 2) {
             memcpy(pose, pose_in, sizeof pose_in);
             if (vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4, nullptr)) return 1;
-            rrc = run_vgicp(h, d_src, n_src, stride_bytes / 4, pose, converged);
+            rrc = vgicp_align_recut(h, d_src, n_src, stride_bytes / 4, pose, converged);
         }
         if (rrc) return 1;
         if (h->profile >= 1) {
@@ -1516,7 +1543,7 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (h->method == kNdt) return run_ndt(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);
-    if (h->method == kVgicp) return run_vgicp(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);
+    if (h->method == kVgicp) return vgicp_align_recut(h, d_src, n_src, stride_bytes / 4, pose_inout, converged) ? 1 : 0;
     return run_loam(h, d_src, n_src, stride_bytes / 4, pose_inout, converged, false);
 }
 
