@@ -29,7 +29,7 @@ namespace pcr {
 #endif
 
 enum : int { kNdtPassDerivH = 0, kNdtPassDeriv = 1, kNdtPassHessian = 2, kNdtPassNone = 3 };
-enum : int { kNdtPhaseInit = 0, kNdtPhaseLsFirst = 1, kNdtPhaseLsLoop = 2, kNdtPhaseLsHess = 3 };
+enum : int { kNdtPhaseInit = 0, kNdtPhaseLsFirst = 1, kNdtPhaseLsLoop = 2, kNdtPhaseLsHess = 3, kNdtPhaseLsFirstH = 4 };
 
 struct NdtCtl {
     // ---- what the next pass evaluates (read by the pass kernel) ----
@@ -38,7 +38,7 @@ struct NdtCtl {
     int32_t kind, phase;
     // ---- parameters ----
     double step_size, trans_eps;
-    int32_t max_iters, pad0;
+    int32_t max_iters, late_h;      // late_h: float Hessians evaluated at a first trial point AFTER the search had ended there (see ctl_advance)
     // ---- optimiser state ----
     double p[6], dir[6], x_t[6], grad[6], hess[36], score;
     double phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_t, step_min, step_max;
@@ -48,7 +48,7 @@ struct NdtCtl {
     uint32_t ticks[4];      // profiling: 100 MHz ticks spent in fold / controller step / write-back, summed over the passes
     // ---- the point (score, grad) were last evaluated at: a request for the same sums at the same point is answered from here ----
     double x_eval[6];
-    int32_t eval_valid, replayed, replay_off, pad1;      // replay_off: PCR_NDT_NO_REPLAY (A/B runs): every request becomes a pass
+    int32_t eval_valid, replayed, replay_off, need_h;      // need_h: see ctl_advance; replay_off: PCR_NDT_NO_REPLAY (A/B runs): every request becomes a pass
 };
 
 // what the device-resident loop reports to the host (host-mapped memory; `seq` is written last)
@@ -322,14 +322,14 @@ NDT_HD inline void ctl_init(NdtCtl* c, const NdtPose& T0, const double p0[6], do
     for (int i = 0; i < 36; ++i) c->hess[i] = 0;
     angle_derivatives(p0, &c->ang);
     c->kind = kNdtPassDerivH; c->phase = kNdtPhaseInit;
-    c->step_size = step_size; c->trans_eps = trans_eps; c->max_iters = max_iters; c->pad0 = 0;
+    c->step_size = step_size; c->trans_eps = trans_eps; c->max_iters = max_iters; c->late_h = 0;
     c->score = 0; c->phi_0 = c->d_phi_0 = c->a_l = c->f_l = c->g_l = c->a_u = c->f_u = c->g_u = c->a_t = 0;
     c->step_min = trans_eps / 2; c->step_max = step_size;
     c->open_interval = 1; c->interval_converged = 0; c->it = 0; c->nr_it = 0; c->conv = 0; c->n_deriv = c->n_hess = 0; c->bail = 0;
     c->done = 0; c->passes = 0;
     for (int i = 0; i < 4; ++i) c->ticks[i] = 0;
     for (int i = 0; i < 6; ++i) c->x_eval[i] = 0;
-    c->eval_valid = 0; c->replayed = 0; c->replay_off = 0; c->pad1 = 0;
+    c->eval_valid = 0; c->replayed = 0; c->replay_off = 0; c->need_h = 0;
 }
 
 // the pose and the angle tables of the next pass from the six sine/cosine pairs of x_t (trig_pair)
@@ -374,10 +374,14 @@ NDT_HD_FLAT bool ctl_advance(NdtCtl* c) {
             c->kind = kNdtPassHessian; c->phase = kNdtPhaseLsHess;
             return false;
         }
+        // The search ended at its first trial point: the float Hessian computeDerivatives(.., true) left there (:832) is the one the
+        // next Newton step uses.  That first evaluation was asked for WITHOUT the Hessian (below): ask for it now, at the same point.
+        // -- but only if another Newton step follows: first the convergence test of the loop below (need_h).
+        if (c->kind == kNdtPassDeriv) c->need_h = 1;
         line_search_over = true;
     } else if (c->phase == kNdtPhaseLsHess) {
         line_search_over = true;
-    }
+    }      // (kNdtPhaseLsFirstH: the late Hessian has arrived; the step it follows was applied before it was asked for)
     // ---- computeTransformation's loop (:120-160); passes that need no evaluation are walked through right here ----
     for (;;) {
         if (line_search_over) {
@@ -387,6 +391,11 @@ NDT_HD_FLAT bool ctl_advance(NdtCtl* c) {
             if (c->nr_it > c->max_iters || (c->nr_it && fabs(nrm) < c->trans_eps)) c->conv = 1;
             c->nr_it += 1;
             if (c->conv) { c->done = 1; c->kind = kNdtPassNone; return false; }
+            if (c->need_h) {      // the float Hessian at the point the search ended at (= p now; pose and tables are still the ones of that pass)
+                c->need_h = 0;
+                c->kind = kNdtPassDerivH; c->phase = kNdtPhaseLsFirstH;
+                return false;
+            }
         }
         // Newton direction (:124-135)
         double rhs[6], dp[6];
@@ -422,7 +431,13 @@ NDT_HD_FLAT bool ctl_advance(NdtCtl* c) {
         c->a_t = min_std(nrm, c->step_max);
         c->a_t = max_std(c->a_t, c->step_min);
         for (int i = 0; i < 6; ++i) c->x_t[i] = c->p[i] + c->dir[i] * c->a_t;
-        c->kind = kNdtPassDerivH; c->phase = kNdtPhaseLsFirst;
+        // The reference evaluates the first trial point WITH the float Hessian (computeDerivatives(.., true), :832) -- and throws that
+        // Hessian away whenever the search goes on to a second point: every further computeDerivatives zeroes it (:183) and
+        // computeHessian replaces it (:928).  A pass with the Hessian costs twice a pass without (ndt.hip: 35 vs 18 us at 131 072
+        // points), and on the reference's constants nearly every search goes on.  So the first trial is asked for without it, and the
+        // rare search that ends right there gets its Hessian by a pass of its own (kNdtPhaseLsFirstH): same numbers either way -- score
+        // and gradient do not depend on whether the Hessian is accumulated beside them.  (replay_off = the reference's schedule.)
+        c->kind = c->replay_off ? kNdtPassDerivH : kNdtPassDeriv; c->phase = kNdtPhaseLsFirst;
         return true;
     }
 }
@@ -443,6 +458,9 @@ NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
     // ---- take the sums in ----
     if (c->kind == kNdtPassHessian) {
         c->n_hess += 1;
+        for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
+    } else if (c->phase == kNdtPhaseLsFirstH) {
+        c->late_h += 1;      // (not an evaluation of the reference's: it computed this Hessian with the first trial)
         for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
     } else {
         c->n_deriv += 1;

@@ -317,7 +317,8 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
         o = L.pcr_ndt_opt_create(guess.ctypes.data_as(dp), float(prm.step_size), float(prm.trans_eps), int(prm.max_iters))
         assert o
         try:
-            n_deriv = n_hess = 0
+            n_deriv = n_hess = n_req = with_h = 0
+            last = None
             for _ in range(600):
                 kind, p6 = C.c_int(-1), np.zeros(6)
                 assert L.pcr_ndt_opt_request(o, C.byref(kind), p6.ctypes.data_as(dp), None) == 0
@@ -328,7 +329,16 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
                 sums[0] = d["score"]; sums[1:7] = d["grad"]
                 sums[7:] = (d["hess_d"] if kind.value == 2 else d["hess"]).reshape(36)
                 n_hess += kind.value == 2
-                n_deriv += kind.value != 2
+                # The first trial point of a line search is asked for WITHOUT its float Hessian (the reference computes it there and drops
+                # it as soon as the search goes on); a search that ends at that point asks for the Hessian afterwards, at the SAME point:
+                # that request is not one of the reference's evaluations.
+                late = kind.value == 0 and n_req > 0
+                if late:
+                    assert last is not None and last[0] == 1 and np.array_equal(last[1], p6)
+                n_deriv += kind.value != 2 and not late
+                with_h += kind.value == 0
+                n_req += 1
+                last = (kind.value, p6.copy())
                 assert L.pcr_ndt_opt_feed(o, sums.ctypes.data_as(dp)) == 0
             else:
                 raise AssertionError("the optimiser did not finish")
@@ -338,6 +348,7 @@ def test_ndt_optimiser_driven_by_the_oracles_derivatives_arrives_where_the_oracl
             assert L.pcr_ndt_opt_counts(o, C.byref(ev), C.byref(hs), C.byref(rep)) == 0
             # what the reference evaluates = what was asked for + what the state machine answered itself (a clamped trial step repeated)
             assert ev.value == n_deriv + rep.value and hs.value == n_hess
+            assert with_h < info["iterations"] + 1      # fewer passes carry a float Hessian than the reference's one per Newton iteration + 1
             n_deriv, replayed_total = ev.value, replayed_total + rep.value
         finally:
             L.pcr_ndt_opt_destroy(o)

@@ -242,7 +242,9 @@ def test_replayed_line_search_evaluations_change_nothing_but_the_number_of_passe
         sf, ss = fast.stats(), slow.stats()
         assert (sf["iterations"], sf["kernel_launches"]) == (ss["iterations"], ss["kernel_launches"]), (seed, sf, ss)
         np.testing.assert_array_equal(pf, ps)
-        assert sf["attempts"] <= ss["attempts"] and ss["attempts"] == ss["kernel_launches"], (seed, sf, ss)
+        # (a search that ends at its first trial point and is followed by another Newton step costs the fast schedule one pass more: the
+        #  float Hessian it had not asked for with that trial -- csrc/ndt_opt.h, need_h)
+        assert sf["attempts"] <= ss["attempts"] + sf["iterations"] and ss["attempts"] == ss["kernel_launches"], (seed, sf, ss)
         saved += ss["attempts"] - sf["attempts"]
     assert saved > 0
 
