@@ -328,7 +328,15 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         step(i); st = reg.stats(); idx_ms += st["index_ms"] / 8; sol_ms += st["solve_ms"] / 8
     reg.set_profile(0)
     ach = alg(scans[0].shape[0], n_map) / (idx_ms * 1e-3) / 1e9
-    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+    traffic = None      # HBM bytes per scan of the preparation kernels, from the committed --pmc passes (scripts/profile_round.sh)
+    for tag in ("r03",):
+        pj = os.path.join(ROOT, "profiles", f"{tag}_{method}_pmc.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_scan_preparation")
+            except Exception:
+                traffic = None
+    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                        "kernel": what, "target_prep_ms": idx_ms, "align_ms": sol_ms}
     out["roofline"]["note"] = "target_prep_ms / align_ms come from a separate 8-scan pass with phase events (pcr_set_profile 1)"
     if not args.no_cpu_baseline and world_size == 1:      # the CPU leg is timed at N = 1 only

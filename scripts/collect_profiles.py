@@ -1,12 +1,12 @@
-"""Condense gpurun_out/prof_r02 (scripts/profile_round.sh) into profiles/: the kernel statistics table, the
+"""Condense gpurun_out/prof_<tag> (scripts/profile_round.sh <tag>) into profiles/: the kernel statistics table, the
 per-kernel PMC means, and profiles/loam_iterate_pmc.json (HBM bytes per launch of the dominant kernel,
 corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KiB... see below)."""
 import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r02")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs(dst, exist_ok=True)
 
 
@@ -70,6 +70,26 @@ if "FETCH_SIZE" in it and "WRITE_SIZE" in it:
     }
     json.dump(out, open(os.path.join(dst, "loam_iterate_pmc.json"), "w"), indent=1)
     print(out)
+# configs[2] / configs[4]: HBM bytes per scan of everything but the optimiser's passes (= target preparation, plus the scan's own two index
+# levels and covariances for VGICP), from the per-dispatch counters: sum over the kernels of (mean bytes per dispatch x dispatches per scan)
+for m in ("vgicp", "ndt"):
+    fm, wm = means(f"pmc_fetch_{m}/**/*counter_collection.csv"), means(f"pmc_write_{m}/**/*counter_collection.csv")
+    if not fm or not wm:
+        continue
+    scans = next((v["FETCH_SIZE"][1] for k, v in fm.items() if "ctl_store" in k), 0)
+    rows, prep, total = [], 0.0, 0.0
+    for k in sorted(set(fm) | set(wm)):
+        f_kib, n = fm.get(k, {}).get("FETCH_SIZE", (0.0, 0))
+        w_kib, n2 = wm.get(k, {}).get("WRITE_SIZE", (0.0, 0))
+        per_scan = (2 * f_kib * n + w_kib * n2) * 1024 / max(1, scans)      # FETCH_SIZE doubled: the gfx950 correction of the guide
+        is_pass = "pass_pro" in k or "ctl_store" in k or "copyBuffer" in k
+        rows.append({"kernel": k, "dispatches_per_scan": n / max(1, scans), "fetch_kib": f_kib, "write_kib": w_kib, "hbm_bytes_per_scan": per_scan, "target_preparation": not is_pass})
+        total += per_scan
+        prep += 0.0 if is_pass else per_scan
+    json.dump({"method": m, "scans": scans, "hbm_bytes_per_scan_preparation": prep, "hbm_bytes_per_scan_total": total, "kernels": rows,
+               "note": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, one counter per pass), FETCH doubled per the gfx950 correction; "
+                       "preparation = every kernel but the optimiser's passes"}, open(os.path.join(dst, f"{tag}_{m}_pmc.json"), "w"), indent=1)
+    print(m, "HBM bytes per scan: preparation", prep, "total", total)
 b = os.path.join(src, "bench_under_profiler.json")
 if os.path.exists(b):
     open(os.path.join(dst, f"{tag}_bench_under_profiler.json"), "w").write(open(b).read())

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace statistics of the bench command and the HBM traffic
 # counters of the dominant kernel, each PMC group in its own pass (MI355X_MICROARCH.md, "HBM" / "rocprofv3 PMC").
-# Output under gpurun_out/prof_r02; the summaries are then copied into profiles/ by scripts/collect_profiles.py.
+# Output under gpurun_out/prof_<tag>; the summaries are then copied into profiles/ by scripts/collect_profiles.py.
 set -e
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_r02
+OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra --windows 1"
@@ -14,8 +15,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARG
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $ARGS > $OUT/pmc_l2.log 2>&1
 grep -h '"metric"' $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json || true
-# the two secondary configurations (BASELINE configs[2] and configs[4]): kernel statistics only
+# the two secondary configurations (BASELINE configs[2] and configs[4]): kernel statistics and the HBM traffic counters (own passes)
 for m in vgicp ndt; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -- python3 $R/bench.py --method $m --steps 40 --warmup 5 --no-cpu-baseline --windows 1 > $OUT/stats_$m.log 2>&1
+  MARGS="$R/bench.py --method $m --steps 40 --warmup 5 --no-cpu-baseline --windows 1"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -- python3 $MARGS > $OUT/stats_$m.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$m -- python3 $MARGS > $OUT/pmc_fetch_$m.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$m -- python3 $MARGS > $OUT/pmc_write_$m.log 2>&1
 done
 echo done
