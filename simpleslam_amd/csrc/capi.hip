@@ -651,6 +651,9 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
     for (int l = 0; l < levels && e == hipSuccess; ++l) {
         // (no hints here: the box and the tile layout of one scan do not hold the next -- walls at other distances, other tiles crowded;
         //  measured: every call's hint failed and the redo cost 0.9 ms)
+        // (the coarse level of a scan: a few thousand cells, the ones around the sensor holding thousands of points each -- the tiled
+        //  build leaves a third of the scan to one block, 94-146 us in the trace; the one-level build has no such tile)
+        lv[l]->prefer_one_level = l > 0 && dev_env("PCR_COV_COARSE_TILED") == nullptr;
         e = lv[l]->build(d_src, n_src, stride_floats, src_cell0() * cells[l], h->side_stream, &h->err, 0.0);
         if (e == hipSuccess && (e = hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream)) != hipSuccess)
             h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);

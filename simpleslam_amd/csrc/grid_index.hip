@@ -833,7 +833,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     else { tshift = 8; while (((uint64_t)cap_eff >> tshift) + 2 > 2048 && tshift < 11) ++tshift; }
     if (const char* e = dev_env("PCR_TILE_SHIFT")) tshift = std::max(2, atoi(e));      // (development: tile size sweep)
     while (((uint64_t)cap_eff >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
-    const bool tiled_path = tshift <= kMaxTileShift && !force_atomic_path;
+    const bool tiled_path = tshift <= kMaxTileShift && !force_atomic_path && !prefer_one_level;
     if (dev_env("PCR_INDEX_DEBUG")) fprintf(stderr, "index build: n %zu cell %.3g capacity %zu cells_hint %llu cap_eff %zu tshift %d hint_ok %d lay_ok %d\n", n, cell, cell_capacity, (unsigned long long)cells_hint, cap_eff, tshift, (int)hint_ok, (int)lay_ok);
     const bool reuse_header = allow_hint && !no_hints && hint_ok && tiled_path && hint_pcl == pcl_mode && hint_shift == shift && !cb.use && hint_cell == cell && tiled_shift == tshift;
     hint_ok = false;      // until the host has seen this build's header (confirm())
