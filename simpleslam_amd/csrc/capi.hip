@@ -1692,6 +1692,7 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     if (h->method != kVgicp) return fail(h, "pcr_vgicp_linearize needs a vgicp handle");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->vg_target_ready) return fail(h, "no target: call pcr_set_target first");
+    if (h->roi_on) return fail(h, "no target: pcr_scan2map prepares its target for that one scan only; call pcr_set_target for a target that is kept");
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     // run the driver's set-up with zero iterations, then one linearisation at the given pose
@@ -1738,6 +1739,7 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     if (h->method != kNdt) return fail(h, "pcr_ndt_derivatives needs an ndt handle");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->nd_target_ready) return fail(h, "no target: call pcr_set_target first");
+    if (h->roi_on) return fail(h, "no target: pcr_scan2map prepares its target for that one scan only; call pcr_set_target for a target that is kept");
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (!h->out48_host) {

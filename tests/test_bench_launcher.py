@@ -74,3 +74,29 @@ def test_a_failing_rank_fails_the_launch():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stderr)
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_ranks_rehearsed_on_one_card(shard):
+    """The rank path behind the launcher, on the one GPU a test box has: PCR_BENCH_REHEARSE=1 lets the two ranks share the card and
+    exchange over gloo (RCCL refuses one device twice).  Not a measurement -- the line says so -- but everything else is what an
+    8-GPU node would run: fresh rank processes, tiles + halo per rank, the all-reduce per linearisation, the per-rank report, the
+    N = 1 origin of the sharded curve."""
+    env = _clean_env()
+    env["PCR_BENCH_REHEARSE"] = "1"
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--steps", "6", "--warmup", "2", "--windows", "1", "--map-points", "200000", "--scans", "2",
+           "--no-cpu-baseline", "--no-extra"] + (["--shard-map"] if shard else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["gpus_arg"] == 2 and d["launcher"] == "bench.py" and d["rccl_ranks"] == 0      # gloo in a rehearsal
+    assert "REHEARSAL" in d["data"] and d["value"] > 0
+    assert [x["rank"] for x in d["ranks"]] == [0, 1]
+    if shard:
+        assert d["scaling"] == "strong" and d["n1"]["value"] > 0
+        assert sum(x["tile_core_points"] for x in d["ranks"]) == 200000          # every map point belongs to exactly one tile
+        assert all(x["tile_points"] >= x["tile_core_points"] and x["transport"] == "host" for x in d["ranks"])
+        assert d["ranks"][0]["tile_hi"] == d["ranks"][1]["tile_lo"]
+    else:
+        assert d["scaling"] == "weak" and "n1" not in d
