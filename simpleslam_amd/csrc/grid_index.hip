@@ -523,8 +523,12 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
 // One block per tile.  Dynamic LDS: the tile's cell histogram (2^shift counters).  A tile of up to 256 * kTilePer points
 // is held in registers between the two passes (all its loads in flight at once); a larger one goes through the generic loop
 // (ranks parked in global scratch).
-static constexpr int kTilePer = 16;
-
+// kTilePer = 16 (64 VGPRs of points; the kernel then needs 223 VGPRs: TWO waves per SIMD, 512 blocks in flight).  That is right for a
+// grid whose tiles all hold several hundred points (LOAM's 1 m cells over a 0.5 m map), and wrong for a fine lattice over the same map:
+// the 0.5 m voxel lattice makes 3 350 tiles of which most hold nothing or a handful of points, they go through the kernel in 6.5 rounds of
+// 512 blocks -- 123 us.  A sparse grid is therefore served by TWO instantiations over the same tiles: kMode 1 takes the tiles of up to 256
+// points with one point per thread (few VGPRs, many blocks in flight), kMode 2 the others with sixteen; kMode 0 = every tile (dense grids).
+template <int kTilePer, int kMode>
 // src_start: where tile t's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
 __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
@@ -548,6 +552,8 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
         const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
         const uint32_t q0 = src_start[tile];      // first point of the tile in `tiled`
         const uint64_t cell0 = (uint64_t)tile << shift;
+        if (kMode == 1 && np > 256u) continue;          // (block-uniform: the other instantiation's tile)
+        if (kMode == 2 && np <= 256u) continue;
         const bool small = np <= 256u * kTilePer;      // block-uniform
         float4 p[kTilePer];
         uint32_t cr[kTilePer];
@@ -896,9 +902,14 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
                 hipLaunchKernelGGL(grid_place_kernel<false>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
                                    ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
         }
-        hipLaunchKernelGGL(grid_tile_kernel, dim3(tile_blocks), dim3(256), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), bin_start.as<uint32_t>(),
-                           bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift,
-                           use_layout ? lay_cur : bin_start.as<uint32_t>());
+        // (a grid with many more cells than points: light tiles and heavy tiles by an instantiation each, see grid_tile_kernel)
+        const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
+#define PCR_LAUNCH_TILE(PER, MODE) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE>), dim3(tile_blocks), dim3(256), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
+                           bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
+                           use_layout ? lay_cur : bin_start.as<uint32_t>())
+        if (sparse) { PCR_LAUNCH_TILE(1, 1); PCR_LAUNCH_TILE(16, 2); }
+        else PCR_LAUNCH_TILE(16, 0);
+#undef PCR_LAUNCH_TILE
         lay_idx ^= 1; lay_ok = true; lay_n = n; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
         PCR_TRY(hipGetLastError());
         n_points = n;

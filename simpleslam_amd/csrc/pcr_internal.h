@@ -172,6 +172,7 @@ struct GridIndex {
     int hint_margin = 0;                        // cells added around a fresh box in x and y (0 until a hint has failed once)
     bool used_hint = false;                     // the last build() reused the header
     bool no_hints = false;                      // pcr_params.index_no_hints: never reuse a header or a tile layout
+    bool split_sparse_tiles = true;             // sparse grids: light and heavy tiles by an instantiation of the tile kernel each (grid_index.hip)
     bool prefer_one_level = false;              // build by the one-level path (histogram with ranks -> scan -> scatter): a small cloud on a COARSE grid puts
                                                 // a third of its points into one tile, which one block of the tiled path then sorts alone
     // Layout hint: where each tile's points may go in `tiled` (an eighth more room than the tile held + 32), written by the last block
