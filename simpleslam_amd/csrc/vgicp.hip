@@ -263,7 +263,7 @@ __device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHe
 // 0.11 ms).  A map-sized cloud runs the same kernel at four waves per SIMD and is bound by instruction issue: there the batched form
 // costs 0.83 -> 1.28 ms per million points, so it keeps the row-by-row walk.
 template <bool kBatch>
-__global__ __launch_bounds__(256) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
+__global__ __launch_bounds__(256, kBatch ? 1 : 4) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
                                                         uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6, const int use_check,
                                                         const CovCheck chk, const RoiView roi) {
     __shared__ uint2 sh_rows[kBatch ? 9 * 256 : 1];      // row ranges of ring 1 (ring_level)
