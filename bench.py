@@ -327,6 +327,9 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
     for i in range(8):
         step(i); st = reg.stats(); idx_ms += st["index_ms"] / 8; sol_ms += st["solve_ms"] / 8
     reg.set_profile(0)
+    # calls so far whose pose left the region the target had been prepared for and were repeated on the whole target (pcr_stats.region_repeats)
+    out["region_repeats"] = int(reg.stats().get("region_repeats", 0))
+    out["region_index"] = int(reg.stats().get("region_index", 0))      # NDT: the last call indexed only the target points of the scan's region
     ach = alg(scans[0].shape[0], n_map) / (idx_ms * 1e-3) / 1e9
     traffic = None      # HBM bytes per scan of the preparation kernels, from the committed --pmc passes (scripts/profile_round.sh)
     for tag in ("r03",):

@@ -106,7 +106,8 @@ typedef struct pcr_stats {
     int32_t target_builds;  /* pcr_scan2map_submap: times this handle has (re)built its target structures (one per sub-map generation) */
     int32_t region_repeats; /* NDT, VGICP pcr_scan2map: calls of this handle so far whose pose left the region the target had been prepared for and
                              * that were therefore repeated on the whole target (pcr_params.full_target) */
-    int32_t pad_;
+    int32_t region_index;   /* NDT pcr_scan2map: 1 when the last call's target index itself held only the points of the scan's region (possible once
+                             * an earlier call of the handle has left its lattice and tile layout as hints), 0 when it held the whole cloud */
 } pcr_stats;
 
 void pcr_default_params(pcr_params* p);

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -92,8 +93,9 @@ struct pcr_handle {
     GridIndex cov_l1, cov_l2;        // the TARGET cloud while its covariances are computed, indexed at 4x and 16x the cell
     GridIndex src_l1, src_l2;        // the same for the source (own buffers: its side runs on side_stream next to the target's)
     hipStream_t side_stream = nullptr;     // source index + covariances of a scan2map call, concurrent with the target preparation
-    hipEvent_t ev_side_in = nullptr, ev_side_done = nullptr;
-    GridHeader* side_hdr = nullptr;  // pinned: headers of the three source levels, read back without blocking the host
+    hipEvent_t ev_side_in = nullptr, ev_side_done = nullptr, ev_hdr = nullptr, ev_aux_in = nullptr, ev_aux_done = nullptr;
+    hipStream_t aux_stream = nullptr; // the target's covariance grid, built beside its voxel lattice (settle_cov_levels)
+    GridHeader* side_hdr = nullptr;  // pinned: headers of the three source levels [0..2] and of the target's grids [3..6], read back without blocking the host
     bool side_pending = false;       // source work of (side_src, side_n, side_stride) is in flight on side_stream
     const float* side_src = nullptr; size_t side_n = 0, side_stride = 0;
     GridHeader cov_hdr0;             // header of the fine level of the last settle_cov_levels (density estimate)
@@ -569,39 +571,71 @@ int vgicp_side_init(pcr_handle* h) {
         H_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         H_TRY(hipEventCreateWithFlags(&h->ev_side_in, hipEventDisableTiming));
         H_TRY(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
-        H_TRY(hipHostMalloc((void**)&h->side_hdr, 3 * sizeof(GridHeader), hipHostMallocDefault));
+        H_TRY(hipEventCreateWithFlags(&h->ev_hdr, hipEventDisableTiming));
+        H_TRY(hipEventCreateWithFlags(&h->ev_aux_in, hipEventDisableTiming));
+        H_TRY(hipEventCreateWithFlags(&h->ev_aux_done, hipEventDisableTiming));
+        H_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        H_TRY(hipHostMalloc((void**)&h->side_hdr, 7 * sizeof(GridHeader), hipHostMallocDefault));
     }
     return 0;
 }
 
+// (inside settle_cov_levels: work may be in flight on the auxiliary stream -- never return before it has drained)
+#define H_TRY_AUX(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (aux) (void)hipStreamSynchronize(h->aux_stream); return fail(h, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
 // the fine index plus the coarse ones of the covariance search, settled with one round trip
+// after_ahead (with a grid built ahead only): what the caller would enqueue once the headers have been read, enqueued BEFORE they are -- the
+// host waits for the headers alone (an event behind their copies) while the device goes on; *after_clean tells whether what was enqueued
+// stands (first attempt, nothing stale or overflowing, the grid built ahead usable).  Kernels queued that way see the flags in the headers
+// and leave early; whatever they wrote is written again by the caller.
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
-                      double shift0, GridHeader* hdr0_out, bool may_cut = false, double ahead_cell = 0.0, bool* ahead_ok = nullptr) {
+                      double shift0, GridHeader* hdr0_out, bool may_cut = false, double ahead_cell = 0.0, bool* ahead_ok = nullptr,
+                      const std::function<int()>* after_ahead = nullptr, bool* after_clean = nullptr) {
     GridIndex* lv[3] = {&g, &l1, &l2};
     const double cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n);
     bool todo[3] = {true, levels > 1, levels > 2};
+    if (after_clean) *after_clean = false;
+    if (after_ahead && vgicp_side_init(h)) return 1;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        GridHeader hdr[3];
+        GridHeader hdr_stack[4];
+        GridHeader* hdr = after_ahead ? h->side_hdr + 3 : hdr_stack;      // (page-locked when the host is not to block in the copies)
+        // (a one-level target's covariance grid at last call's cell size, enqueued with the fine level so that one round trip
+        //  settles both; whether that size still suits the density is the caller's check)
+        GridHeader& hdr_ahead = hdr[3];
+        const bool ahead = ahead_cell > 0.0 && levels == 1 && attempt == 0 && !(h->clamp.use && may_cut);
+        // ... on a stream of its own when the caller queues its work behind both (after_ahead): the two builds read the same cloud and
+        // depend on nothing of each other, and neither fills the device (a chain of two or three launches of a few hundred blocks)
+        static const bool no_aux = dev_env("PCR_COV_NO_AUX") != nullptr;      // (A/B runs)
+        const bool aux = ahead && after_ahead != nullptr && h->aux_stream != nullptr && !no_aux;
+        auto build_ahead = [&](hipStream_t s) -> int {
+            l1.no_hints = h->prm.index_no_hints != 0;
+            if (l1.build(d_pts, n, stride_floats, ahead_cell, s, &h->err, 0.0, 0, nullptr, true) != hipSuccess) return 1;
+            H_TRY(hipMemcpyAsync(&hdr_ahead, l1.header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, s));
+            return 0;
+        };
+        if (aux) {
+            H_TRY(hipEventRecord(h->ev_aux_in, h->stream));      // (whatever brought the cloud here is on the main stream)
+            H_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_aux_in, 0));
+            const int rc = build_ahead(h->aux_stream);
+            if (hipEventRecord(h->ev_aux_done, h->aux_stream) != hipSuccess || rc) { (void)hipStreamSynchronize(h->aux_stream); return rc ? 1 : fail(h, "hipEventRecord failed"); }
+        }
         for (int l = 0; l < 3; ++l) {
             if (!todo[l]) continue;
             // (the box and the tile layout of this index's previous build serve as hints -- GridIndex::hint_ok: a sub-map changes by a key frame
             //  at a time, a scan's box in the sensor frame hardly at all; a cloud that does not fit raises header.stale and is built afresh)
             lv[l]->no_hints = h->prm.index_no_hints != 0;
-            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, true) != hipSuccess) return 1;
-            if (l == 0 && hdr0_out) H_TRY(lv[l]->enqueue_density(h->stream));
-            H_TRY(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
+            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, true) != hipSuccess) { if (aux) (void)hipStreamSynchronize(h->aux_stream); return 1; }
+            if (l == 0 && hdr0_out) H_TRY_AUX(lv[l]->enqueue_density(h->stream));
+            H_TRY_AUX(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
-        // (a one-level target's covariance grid at last call's cell size, enqueued behind the fine level so that one round trip
-        //  settles both; whether that size still suits the density is the caller's check)
-        GridHeader hdr_ahead;
-        const bool ahead = ahead_cell > 0.0 && levels == 1 && attempt == 0 && !(h->clamp.use && may_cut);
-        if (ahead) {
-            l1.no_hints = h->prm.index_no_hints != 0;
-            if (l1.build(d_pts, n, stride_floats, ahead_cell, h->stream, &h->err, 0.0, 0, nullptr, true) != hipSuccess) return 1;
-            H_TRY(hipMemcpyAsync(&hdr_ahead, l1.header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
-        }
-        H_TRY(hipStreamSynchronize(h->stream));
+        if (aux) H_TRY_AUX(hipStreamWaitEvent(h->stream, h->ev_aux_done, 0));
+        else if (ahead && build_ahead(h->stream)) return 1;
+        const bool early = ahead && after_ahead != nullptr;
+        if (early) {
+            H_TRY(hipEventRecord(h->ev_hdr, h->stream));
+            if ((*after_ahead)()) { (void)hipStreamSynchronize(h->stream); return 1; }
+            H_TRY(hipEventSynchronize(h->ev_hdr));
+        } else H_TRY(hipStreamSynchronize(h->stream));
         if (ahead_ok) *ahead_ok = false;
         if (ahead && hdr_ahead.stale) { l1.hint_margin = 8; l1.cells_hint = 0; }      // (built afresh by the caller: it checks ahead_ok)
         else if (ahead && !hdr_ahead.overflow) { l1.note_cells(hdr_ahead.n_cells); if (!hdr_ahead.empty) l1.confirm(); if (ahead_ok) *ahead_ok = true; }
@@ -626,7 +660,7 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
             }
             else { todo[l] = false; lv[l]->note_cells(hdr[l].n_cells); if (!hdr[l].empty && !h->clamp.use) lv[l]->confirm(); if (l == 0 && hdr0_out) *hdr0_out = hdr[0]; }
         }
-        if (!again) return 0;
+        if (!again) { if (after_clean) *after_clean = early && !hdr_ahead.stale && !hdr_ahead.overflow; return 0; }
     }
     return fail(h, "index could not be sized");
 }
@@ -651,11 +685,18 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
     for (int l = 0; l < levels && e == hipSuccess; ++l) {
         // (no hints here: the box and the tile layout of one scan do not hold the next -- walls at other distances, other tiles crowded;
         //  measured: every call's hint failed and the redo cost 0.9 ms)
-        // (the coarse level of a scan: a few thousand cells, the ones around the sensor holding thousands of points each -- the tiled
-        //  build leaves a third of the scan to one block, 94-146 us in the trace; the one-level build has no such tile)
-        lv[l]->prefer_one_level = l > 0 && dev_env("PCR_COV_COARSE_TILED") == nullptr;
+        // (a scan's points crowd around the sensor: on the coarse level a few cells hold a third of the scan, and the tiled build leaves
+        //  them to ONE block, 94-146 us in the trace; on the fine level the crowded tiles still cost 34 us where the one-level build
+        //  -- histogram with ranks, scan of the table, scatter -- takes ~30 us for the whole level.  A/B: 0.571 -> 0.54 ms per scan)
+        lv[l]->prefer_one_level = dev_env("PCR_COV_SCAN_TILED") == nullptr;
+        // (one pass over the scan finds the box of both levels, and the headers go to the host from the kernel that makes them: a build
+        //  without hints changes nothing in its header afterwards)
+        lv[l]->header_mirror = &h->side_hdr[l];
+        lv[l]->twin = (l == 0 && levels > 1) ? lv[1] : nullptr;
+        lv[l]->twin_cell = src_cell0() * cells[1];
         e = lv[l]->build(d_src, n_src, stride_floats, src_cell0() * cells[l], h->side_stream, &h->err, 0.0);
-        if (e == hipSuccess && (e = hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream)) != hipSuccess)
+        lv[l]->twin = nullptr;
+        if (e == hipSuccess && !lv[l]->mirrored && (e = hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream)) != hipSuccess)
             h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
     }
     if (e == hipSuccess && (e = vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
@@ -728,7 +769,7 @@ int roi_enqueue(pcr_handle* h, const RoiScan& scan, double cell, double base_m, 
                      h->roi_tmp[0].as<uint8_t>(), h->roi_tmp[1].as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream));
     h->roi_idx ^= 1;
     view->lat = h->grid.header.as<GridHeader>(); view->mask = h->roi_mask.as<uint8_t>(); view->escapes = h->roi_esc.as<uint32_t>();
-    view->mshift = ms; view->pad_ = 0;
+    view->mshift = ms; view->filtered = 0;
     return 0;
 }
 RoiView roi_view(const pcr_handle* h) {      // the region the handle's target was prepared for (the mask of the LAST roi_enqueue)
@@ -749,18 +790,44 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats;
     // (unsharded: a cloud too spread out for dense tables is cut to its bulk, settle_cov_levels; a rank of a sharded call refuses it)
     static const bool no_ahead = dev_env("PCR_COV_NO_AHEAD") != nullptr;      // (A/B runs)
+    static const bool no_early = dev_env("PCR_COV_NO_EARLY") != nullptr;
     bool ahead_ok = false;
     const double ahead_cell = (!no_ahead && cov_levels(n_dst) == 1 && h->cov_scale_hint >= 1.3) ? res * h->cov_scale_hint : 0.0;
-    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h), ahead_cell, &ahead_ok)) return 1;
-    if (h->clamp.use) ahead_ok = false;      // (the target was cut to its bulk in there: the grid built ahead covers the uncut cloud)
-    h->have_target = true;
+    CovCheck chk;
+    const bool check = h->use_tile && h->have_halo;
+    // prepared for one scan: covariances and voxels only where that scan can land (a cut index keeps the full preparation: its
+    // escape accounting is of another kind)
+    RoiView roi;
+    memset(&roi, 0, sizeof roi);
+    const bool want_roi = roi_scan && roi_scan->n_src > 0 && n_dst > 0 && !check;
+    // region, covariances and voxels over (lattice, search grid): enqueued by settle_cov_levels behind the grid it builds ahead, before the
+    // host has seen a header (the device used to idle ~45 us between the header read-back and the first of these launches), or below
+    auto enqueue_rest = [&](const GridIndex* cov_grid) -> int {
+        h->roi_on = false;
+        if (want_roi && !h->clamp.use) {
+            if (roi_enqueue(h, *roi_scan, res, 1.0, &roi)) return 1;      // 1 m of translation + 0.05 rad
+            h->roi_on = true;
+        }
+        H_TRY(vgicp_launch_cov(*cov_grid, cov_levels(n_dst) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_dst) > 2 ? &h->cov_l2 : nullptr, d_dst, stride_floats,
+                               n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr));
+        H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream, h->roi_on ? &roi : nullptr));
+        return 0;
+    };
     H_TRY(h->tgt_cov6.reserve((n_dst + 1) * 6 * sizeof(double)));
     H_TRY(h->vox.reserve((n_dst + 1) * sizeof(VgicpVoxel)));
+    const std::function<int()> early = [&]() -> int { return enqueue_rest(&h->cov_l1); };
+    bool early_clean = false;
+    const bool try_early = want_roi && !no_early && ahead_cell > 0.0 && !h->clamp.use;
+    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h), ahead_cell, &ahead_ok,
+                          try_early ? &early : nullptr, &early_clean)) return 1;
+    if (h->clamp.use) { ahead_ok = false; early_clean = false; }      // (the target was cut to its bulk in there: the grid built ahead covers the uncut cloud)
+    h->have_target = true;
     // A map-sized cloud is searched on ONE level whose cell is sized for the 20-neighbour radius, not for the voxel
     // lattice: sum_sq / n is the occupancy of the cell a point lives in (averaged over the points); on a surface it grows
     // with cell^2, and ~10 points per cell put ~4 K candidates into the 27-cell block (measured optimum).  (0.5 m voxels over a 0.5 m-spaced
     // map: cell 1.25 m, 0.74 -> 0.50 ms for 1 M points, the extra index build included.)
     const GridIndex* cov_grid = &h->grid;
+    bool kept_ahead = false;
     if (cov_levels(n_dst) == 1 && n_dst > 0 && grid_sum_sq(h->cov_hdr0) > 0.0) {
         const double occ = grid_sum_sq(h->cov_hdr0) / (double)n_dst;
         const double scale = std::min(8.0, sqrt(10.0 / std::max(occ, 1e-3)));
@@ -772,11 +839,10 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
                 if (settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * scale, 0, h->clamp.use ? &h->clamp : nullptr)) return 1;
                 h->cov_scale_hint = scale;
             }
+            kept_ahead = keep;
             cov_grid = &h->cov_l1;
         } else h->cov_scale_hint = 0.0;
     } else h->cov_scale_hint = 0.0;
-    CovCheck chk;
-    const bool check = h->use_tile && h->have_halo;
     if (check) {
         // sharded target (pcr_set_shard): the covariances of the points that can enter a voxel of the tile must be the whole
         // map's -- every neighbourhood of a point within one voxel of the tile has to end inside the halo
@@ -786,17 +852,7 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
         for (int d = 0; d < 3; ++d) { chk.chk_lo[d] = h->tile_lo[d] - res; chk.chk_hi[d] = h->tile_hi[d] + res; }
         chk.violations = h->cov_viol.as<uint32_t>();
     }
-    // prepared for one scan: covariances and voxels only where that scan can land (a cut index keeps the full preparation: its
-    // escape accounting is of another kind)
-    RoiView roi;
-    memset(&roi, 0, sizeof roi);
-    if (roi_scan && roi_scan->n_src > 0 && n_dst > 0 && !h->clamp.use && !check) {
-        if (roi_enqueue(h, *roi_scan, res, 1.0, &roi)) return 1;      // 1 m of translation + 0.05 rad
-        h->roi_on = true;
-    }
-    H_TRY(vgicp_launch_cov(*cov_grid, cov_levels(n_dst) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_dst) > 2 ? &h->cov_l2 : nullptr, d_dst, stride_floats,
-                           n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr));
-    H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream, h->roi_on ? &roi : nullptr));
+    if (!(early_clean && kept_ahead) && enqueue_rest(cov_grid)) return 1;
     if (check) {
         uint32_t viol = 0;
         H_TRY(hipMemcpyAsync(&viol, h->cov_viol.p, sizeof viol, hipMemcpyDeviceToHost, h->stream));
@@ -1008,8 +1064,20 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
     // the voxel lattice is VoxelGridCovariance's own (leaf index = floor(p * inverse_leaf) - min_b in float,
     // voxel_grid_covariance_omp_impl.hpp:218-220): GridHeader.pcl_mode, no pad cells
     h->grid.no_hints = h->prm.index_no_hints != 0;
+    // prepared for one scan (pcr_scan2map): voxel Gaussians only where that scan can land (RoiView) -- and, when this build can take the
+    // lattice and the tile layout of an earlier full build as they are, an index of the region's points only (BuildFilter)
+    RoiView roi;
+    memset(&roi, 0, sizeof roi);
+    const bool want_roi = roi_scan && roi_scan->n_src > 0 && n_dst > 0;
+    static const bool no_filter = dev_env("PCR_NDT_NO_FILTER") != nullptr;      // (A/B runs)
+    BuildFilter bf;
+    bf.enqueue_mask = [&]() -> hipError_t {
+        if (roi_enqueue(h, *roi_scan, res, 1.0 + res, &roi)) return hipErrorUnknown;      // 1 m of translation + the DIRECT7 face voxels, + 0.05 rad
+        bf.mask = roi.mask; bf.mshift = roi.mshift;
+        return hipSuccess;
+    };
     if (deferred) {
-        if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true) != hipSuccess) return 1;
+        if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true, want_roi && !no_filter ? &bf : nullptr) != hipSuccess) return 1;
     } else if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
@@ -1023,11 +1091,9 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
         H_TRY(hipMemsetAsync(h->nd_count.p, 0, 256, h->stream));
     }
     h->nd_count_idx ^= 1;
-    // prepared for one scan (pcr_scan2map): voxel Gaussians only where that scan can land (RoiView)
-    RoiView roi;
-    memset(&roi, 0, sizeof roi);
-    if (roi_scan && roi_scan->n_src > 0 && n_dst > 0) {
-        if (roi_enqueue(h, *roi_scan, res, 1.0 + res, &roi)) return 1;      // 1 m of translation + the DIRECT7 face voxels, + 0.05 rad
+    if (bf.applied) { roi.filtered = 1; h->roi_on = true; }
+    else if (want_roi) {
+        if (roi_enqueue(h, *roi_scan, res, 1.0 + res, &roi)) return 1;
         h->roi_on = true;
     }
     H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>() + 32 * h->nd_count_idx,
@@ -1455,6 +1521,10 @@ void pcr_destroy(pcr_handle* h) {
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->side_hdr) (void)hipHostFree(h->side_hdr);
     if (h->ev_side_in) (void)hipEventDestroy(h->ev_side_in);
+    if (h->ev_hdr) (void)hipEventDestroy(h->ev_hdr);
+    if (h->ev_aux_in) (void)hipEventDestroy(h->ev_aux_in);
+    if (h->ev_aux_done) (void)hipEventDestroy(h->ev_aux_done);
+    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1902,7 +1972,7 @@ int pcr_get_stats(pcr_handle* h, pcr_stats* out) {
     if (!h || !out) return 1;
     *out = h->stats;
     out->target_builds = (int32_t)h->target_builds;
-    out->region_repeats = (int32_t)h->roi_repeats; out->pad_ = 0;
+    out->region_repeats = (int32_t)h->roi_repeats; out->region_index = (h->roi_on && h->grid.filtered) ? 1 : 0;
     return 0;
 }
 

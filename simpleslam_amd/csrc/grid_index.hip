@@ -37,7 +37,10 @@ __device__ inline float wave_max(float v) {
 __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
                                                                float* __restrict__ partials, uint32_t* __restrict__ ticket,
                                                                GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode,
-                                                               const ClampBox clamp, int margin_xy) {
+                                                               const ClampBox clamp, int margin_xy, GridHeader* __restrict__ mirror, const HeaderTwin twin) {
+    // mirror: a host-mapped copy of the header (or nullptr), written here so that no copy has to be queued behind the build when nothing
+    // later in it can change the header (a build without hints).  twin: a second index over the SAME cloud at another cell size gets its
+    // header from the same box (the coarse level of a scan's covariance search: one pass over the cloud instead of two).
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     // eight independent loads in flight per lane (a 1 M-point cloud is 16-32 MB: this pass should run at HBM speed)
     constexpr int kU = 8;
@@ -99,8 +102,10 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         if (lane == 0) { sh[wave][d] = a; sh[wave][3 + d] = b; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        *ticket = 0;                                           // ready for the next build
+    if (threadIdx.x == 0) *ticket = 0;                         // ready for the next build
+    if (threadIdx.x < 2 && (threadIdx.x == 0 || twin.hdr)) {  // (lane 0: this index's header, lane 1: the twin's)
+        const bool second = threadIdx.x == 1;
+        if (second) { cell = twin.cell; capacity = twin.capacity; hdr = twin.hdr; mirror = twin.mirror; }
         GridHeader h;
         h.cell = cell; h.inv_cell = 1.0 / cell; h.n_points = n; h.shift = shift;
         h.empty = 0; h.overflow = 0;
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         else if (nc + 1.0 > (double)capacity || nc > 4.0e9) { h.overflow = 1; h.n_cells = nc < 1.8e19 ? (uint64_t)nc : ~0ull; }
         else h.n_cells = (uint64_t)h.dims[0] * (uint64_t)h.dims[1] * (uint64_t)h.dims[2];
         *hdr = h;
+        if (mirror) *mirror = h;
     }
 }
 
@@ -361,7 +367,10 @@ template <bool kVec, int kBinPer, bool kPlace>
 __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start, uint32_t* __restrict__ lay_next,
-                                                       const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap) {
+                                                       const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
+                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift) {
+    // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
+    // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;
     uint32_t* const sh_lay = dyn_lds + max_bins;      // kPlace: max_bins + 1 entries
@@ -388,7 +397,8 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
             uint32_t key;
             bin[u] = 0xffffffffu; loc[u] = 0u;
             bool outside = false;
-            if (i < n && point_key(h, px[u], py[u], pz[u], &key, &outside)) bin[u] = key >> shift;
+            if (i < n && point_key(h, px[u], py[u], pz[u], &key, &outside) && (!kPlace || !keep_mask || roi_mask_holds_cell(h, keep_mask, keep_mshift, key)))
+                bin[u] = key >> shift;
             if (outside && !h.clamped) hdr->stale = 1;      // (only a box reused from the previous build can be too small)
             // one LDS atomic per RUN of equal tiles in consecutive lanes (a cloud stored in a spatially coherent order puts
             // whole waves into one tile: 64 same-address atomics would serialise)
@@ -466,6 +476,11 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         if (j < per && b0 + j < nbins) { bin_start[b0 + j] = off; off += c[j]; }
     if (threadIdx.x == 255) bin_start[nbins] = total;
     // ... and into the layout the NEXT build may place its points by: every tile gets an eighth more room than it holds now
+    if (kPlace && keep_mask) {      // (a build of a region: the counts are not the cloud's; the layout it came with stays)
+        for (uint32_t b = threadIdx.x; b <= nbins; b += 256) lay_next[b] = lay_cur[b];
+        if (threadIdx.x == 0) *ticket = 0u;
+        return;
+    }
     __syncthreads();      // sh4 is reused
     uint32_t room = 0;
 #pragma unroll
@@ -673,7 +688,7 @@ __global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restric
 __global__ __launch_bounds__(256) void roi_mark_kernel(const float* __restrict__ src, uint32_t n, uint32_t stride, const Pose16 T, const GridHeader* __restrict__ lat,
                                                        uint8_t* __restrict__ mark, int mshift) {
     const GridHeader h = *lat;
-    if (h.overflow || h.empty) return;
+    if (h.overflow || h.empty || h.stale) return;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float* sp = src + (size_t)i * stride;
         const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
@@ -795,20 +810,9 @@ hipError_t GridIndex::grow_cells(uint64_t need_cells, std::string* err) {
 
 #define PCR_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { if (err) *err = std::string(#x) + ": " + hipGetErrorString(_e); return _e; } } while (0)
 
-hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift,
-                            int pcl_mode, const ClampBox* clamp, bool allow_hint) {
-    valid = false;
-    const bool force_atomic_path = dev_env("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
-    if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
-    PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
-    PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
+// header and cell table exist (first call: a table of 2^20 cells)
+hipError_t GridIndex::ensure_tables(hipStream_t s, std::string* err) {
     PCR_TRY(header.reserve(sizeof(GridHeader)));
-    PCR_TRY(keys.reserve((n + 1) * sizeof(uint32_t)));
-    PCR_TRY(ranks.reserve((n + 1) * sizeof(uint32_t)));
-    if (!ticket.p) {
-        PCR_TRY(ticket.reserve(256));
-        PCR_TRY(hipMemsetAsync(ticket.p, 0, 256, s));
-    }
     if (cell_capacity == 0) {
         // first guess; a too-small table is detected on the device (header.overflow)
         // and the caller grows it with grow_cells() and retries
@@ -819,6 +823,31 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         cell_capacity = guess;
         PCR_TRY(block_sums.reserve(2 * (guess / kScanTile + 2) * sizeof(uint32_t)));
     }
+    return hipSuccess;
+}
+// The cell count a build may use: the table's capacity, or -- once a header of this index has been seen (note_cells) -- twice that header's count.
+size_t GridIndex::effective_capacity() const {
+    size_t cap_eff = cell_capacity;
+    if (cells_hint) cap_eff = std::min<size_t>(cell_capacity, std::max<size_t>(2 * (size_t)cells_hint + 64, 1024));
+    return cap_eff;
+}
+
+hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s, std::string* err, double shift,
+                            int pcl_mode, const ClampBox* clamp, bool allow_hint, BuildFilter* filter) {
+    valid = false;
+    filtered = false;
+    if (filter) filter->applied = false;
+    const bool force_atomic_path = dev_env("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
+    if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
+    PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
+    PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
+    PCR_TRY(keys.reserve((n + 1) * sizeof(uint32_t)));
+    PCR_TRY(ranks.reserve((n + 1) * sizeof(uint32_t)));
+    if (!ticket.p) {
+        PCR_TRY(ticket.reserve(256));
+        PCR_TRY(hipMemsetAsync(ticket.p, 0, 256, s));
+    }
+    PCR_TRY(ensure_tables(s, err));
     ClampBox cb;
     memset(&cb, 0, sizeof cb);
     if (clamp) cb = *clamp;
@@ -828,8 +857,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     // header's count.  The tile size follows from it, and a grid of a few hundred cells (the coarse levels of the covariance search)
     // must not be cut into 256-cell tiles: two blocks then sorted a whole scan between them (158 us).  A cloud that needs more cells
     // than the bound raises header.overflow like a table that is too small, and grow_cells() lifts the bound.
-    size_t cap_eff = cell_capacity;
-    if (cells_hint) cap_eff = std::min<size_t>(cell_capacity, std::max<size_t>(2 * (size_t)cells_hint + 64, 1024));
+    const size_t cap_eff = effective_capacity();
     // tile size: ~512 points per tile on average, at most 2048 tiles, at least 4 cells per tile (16-byte accesses of the tile kernel)
     const size_t tiles_target = std::min<size_t>(2048, std::max<size_t>(64, n / 512));
     // (never more than 2^11 cells per tile unless the counter array forces it: a tile's block zeroes, scans and writes every cell of it,
@@ -845,10 +873,23 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     hint_ok = false;      // until the host has seen this build's header (confirm())
     used_hint = reuse_header;
     hint_cell = cell; hint_shift = shift; hint_pcl = pcl_mode;
-    if (!reuse_header)
+    // (a header written by the twin's build -- see below -- serves if it was made for this very cloud and cell)
+    const bool preset = header_preset && preset_pts == d_pts && preset_n == n && preset_cell == cell && !reuse_header && !cb.use && pcl_mode == 0 && shift == 0.0;
+    header_preset = false;
+    mirrored = false;
+    if (!reuse_header && !preset) {
+        HeaderTwin tw;
+        memset(&tw, 0, sizeof tw);
+        if (twin && twin != this && !cb.use && pcl_mode == 0 && shift == 0.0 && !allow_hint) {
+            PCR_TRY(twin->ensure_tables(s, err));
+            tw.hdr = twin->header.as<GridHeader>(); tw.mirror = twin->header_mirror; tw.capacity = (uint64_t)twin->effective_capacity(); tw.cell = twin_cell;
+            twin->header_preset = true; twin->preset_pts = d_pts; twin->preset_n = n; twin->preset_cell = twin_cell; twin->mirrored = twin->header_mirror != nullptr;
+        }
         hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
                            ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cap_eff, cell, shift, pcl_mode, cb,
-                           (allow_hint && !cb.use) ? hint_margin : 0);
+                           (allow_hint && !cb.use) ? hint_margin : 0, header_mirror, tw);
+        mirrored = header_mirror != nullptr;
+    } else if (preset) mirrored = header_mirror != nullptr;
     // Tile size from the CAPACITY of the cell table (the device-side cell count never exceeds it: a larger box is an overflow):
     // ~2048 tiles when the table allows it -- 8 KB of LDS counters per block in the bin kernel, tiles of a few hundred to a few
     // thousand points -- never more than kMaxBins.
@@ -882,10 +923,17 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         uint32_t* const lay_cur = layout[lay_idx].as<uint32_t>();
         uint32_t* const lay_next = layout[lay_idx ^ 1].as<uint32_t>();
         used_layout = use_layout;
+        const uint8_t* keep_mask = nullptr;
+        int keep_mshift = 0;
+        if (filter && use_layout && filter->enqueue_mask) {      // the lattice is the reused header's, the rooms are the full cloud's: this build may leave points out
+            PCR_TRY(filter->enqueue_mask());
+            keep_mask = filter->mask; keep_mshift = filter->mshift;
+            filter->applied = filtered = keep_mask != nullptr;
+        }
         const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
 #define PCR_LAUNCH_BIN(VEC, PER, PLACE) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
                                                     bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
-                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap)
+                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
         if (use_layout) {
             if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, true); else PCR_LAUNCH_BIN(true, 16, true); }
             else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, true); else PCR_LAUNCH_BIN(false, 16, true); }
@@ -914,7 +962,8 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         else if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE(8, 0);
         else PCR_LAUNCH_TILE(16, 0);
 #undef PCR_LAUNCH_TILE
-        lay_idx ^= 1; lay_ok = true; lay_n = n; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
+        lay_idx ^= 1; lay_ok = true; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
+        if (!filtered) lay_n = n;
         PCR_TRY(hipGetLastError());
         n_points = n;
         valid = true;

@@ -80,9 +80,7 @@ static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(
 // kNdtUnprepared, which the lookups of the optimiser count as an escape.
 static constexpr uint32_t kNdtUnprepared = 0xffffffffu;
 __device__ __forceinline__ bool ndt_cell_in_roi(const GridHeader& h, const RoiView& roi, uint64_t t) {
-    const uint32_t t32 = (uint32_t)t, d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = t32 / d0;
-    const uint32_t cz = row / d1;
-    return roi.mask[roi_macro(h, roi.mshift, (int)(t32 - row * d0), (int)(row - cz * d1), (int)cz)] != 0;
+    return roi_mask_holds_cell(h, roi.mask, roi.mshift, (uint32_t)t);
 }
 __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_t* __restrict__ vox_slot, uint32_t* __restrict__ list,
                                                              uint32_t* __restrict__ count, uint32_t* __restrict__ count_next, int min_points, uint32_t capacity,
@@ -103,14 +101,25 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
     uint32_t mine_total = 0;
     for (uint64_t st = s_lo; st < s_hi; ++st) {
         const uint64_t t0 = st * 1024 + (uint64_t)threadIdx.x * 4;
+        // (an index of the region's points only holds nothing outside the mask: EVERY cell there counts as unprepared -- the four cells
+        //  of a thread are neighbours along x: one decode serves them unless the row ends in between)
+        const bool every = roi.mask && roi.filtered;
+        uint32_t cx0 = 0, mrow = 0;
+        if (every && t0 < h.n_cells) {
+            const uint32_t d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = (uint32_t)t0 / d0, cz = row / d1;
+            cx0 = (uint32_t)t0 - row * d0;
+            mrow = roi_macro(h, roi.mshift, 0, (int)(row - cz * d1), (int)cz);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
             if (t < h.n_cells) {
-                const bool cand = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
-                const bool in = cand && (!roi.mask || ndt_cell_in_roi(h, roi, t));
-                mine_total += in ? 1u : 0u;
-                vox_slot[t] = (cand && !in) ? kNdtUnprepared : 0u;
+                const bool full = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
+                bool in = true;
+                if (every) in = cx0 + u < (uint32_t)h.dims[0] ? roi.mask[mrow + ((cx0 + u) >> roi.mshift)] != 0 : ndt_cell_in_roi(h, roi, t);
+                else if (full && roi.mask) in = ndt_cell_in_roi(h, roi, t);
+                mine_total += (full && in) ? 1u : 0u;
+                vox_slot[t] = ((full || every) && !in && !h.empty) ? kNdtUnprepared : 0u;
             }
         }
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,8 @@ __host__ __device__ inline double grid_sum_sq(const GridHeader& h) { return h.su
 
 // Region of interest for an index whose full bounding box cannot be tabulated (a far outlier in the cloud): see capi.hip
 struct ClampBox { double lo[3], hi[3]; int32_t use, pad_; };
+
+struct HeaderTwin { GridHeader* hdr; GridHeader* mirror; uint64_t capacity; double cell; };      // grid_bbox_header_kernel: a second header from the same box
 
 struct GridView {            // what kernels need to query the index
     const GridHeader* hdr;
@@ -159,6 +162,18 @@ struct DeviceBuf {
 static constexpr int kMaxBins = 8192;    // tiles of the tiled build path (grid_index.hip): one 32 KB LDS histogram
 static constexpr int kMaxTileShift = 13; // a tile's cells are histogrammed in LDS too
 
+// A build that indexes only the points inside a region (pcr_scan2map of NDT: voxel Gaussians depend on a voxel's own points alone, so
+// a lattice that holds nothing outside the region the scan can reach serves that scan as the full one would).  Possible only when the
+// build reuses the header and the tile layout of a previous FULL build (the lattice the mask is laid over must be known before the
+// points are binned, and the room of every tile is the full cloud's): build() then calls enqueue_mask -- which queues the marking of the
+// region on the build's stream and fills mask / mshift -- and sets `applied`; otherwise it builds in full and leaves `applied` false.
+struct BuildFilter {
+    std::function<hipError_t()> enqueue_mask;
+    const uint8_t* mask = nullptr;      // one byte per macro cell of the lattice (RoiView::mask)
+    int mshift = 0;
+    bool applied = false;
+};
+
 struct GridIndex {
     DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header, keys, ranks, ticket;
     DeviceBuf tiled, bin_count, bin_start, tile_sq;      // tiled build path: points grouped by tile, points per tile, first point of every tile, sum of count^2 per tile
@@ -181,6 +196,16 @@ struct GridIndex {
     int lay_idx = 0, lay_shift = -1;
     size_t lay_n = 0;
     bool lay_ok = false, used_layout = false;
+    bool filtered = false;                      // the last build() indexed the points of a region only (BuildFilter)
+    // A build WITHOUT hints computes the bounding box itself; then (grid_bbox_header_kernel)
+    GridHeader* header_mirror = nullptr;        //   the header is also written to this host-mapped address (no copy queued behind the build): `mirrored` says so
+    bool mirrored = false;
+    GridIndex* twin = nullptr;                  //   and `twin`, an index the caller builds NEXT over the same cloud with cell twin_cell, gets its header from the
+    double twin_cell = 0.0;                     //   same pass (its build() then launches no box kernel)
+    bool header_preset = false;
+    const float* preset_pts = nullptr; size_t preset_n = 0; double preset_cell = 0.0;
+    hipError_t ensure_tables(hipStream_t s, std::string* err);
+    size_t effective_capacity() const;
     void confirm() { hint_ok = valid && tiled_shift >= 0; }
     size_t cell_capacity = 0;   // entries available in cell_count / cell_start
     uint64_t cells_hint = 0;    // cells of the last header of this index the host has seen (0: none): bounds the next build's cell count and sets its tile size
@@ -193,7 +218,8 @@ struct GridIndex {
     // Enqueue the build of the index over n points (device pointer, stride in floats).
     // No host synchronisation unless the cell table must grow.  cell = grid edge.
     hipError_t build(const float* d_pts, size_t n, size_t stride_floats, double cell, hipStream_t s,
-                     std::string* err, double shift = 0.0, int pcl_mode = 0, const ClampBox* clamp = nullptr, bool allow_hint = false);
+                     std::string* err, double shift = 0.0, int pcl_mode = 0, const ClampBox* clamp = nullptr, bool allow_hint = false,
+                     BuildFilter* filter = nullptr);
     // Make room for `need_cells` cells (+1 start) after the device reported overflow.
     hipError_t grow_cells(uint64_t need_cells, std::string* err);
     // header.sum_sq_u <- sum over the cells of count^2 (enqueued; VGICP reads it back with the header)
@@ -223,11 +249,16 @@ struct RoiView {
     const GridHeader* lat;       // the lattice (header of the target index); macro dims = ceil(dims / 2^mshift)
     const uint8_t* mask;         // one byte per macro cell, != 0: prepared.  nullptr: no region -- everything is prepared
     uint32_t* escapes;
-    int32_t mshift, pad_;
+    int32_t mshift;
+    int32_t filtered;            // the index itself holds the region's points only (BuildFilter): NDT then treats EVERY cell outside the mask as unprepared
 };
 __host__ __device__ inline uint32_t roi_macro(const GridHeader& h, int mshift, int cx, int cy, int cz) {      // cell (cx, cy, cz) inside the lattice
     const uint32_t m0 = ((uint32_t)h.dims[0] + (1u << mshift) - 1u) >> mshift, m1 = ((uint32_t)h.dims[1] + (1u << mshift) - 1u) >> mshift;
     return (((uint32_t)cz >> mshift) * m1 + ((uint32_t)cy >> mshift)) * m0 + ((uint32_t)cx >> mshift);
+}
+__host__ __device__ inline bool roi_mask_holds_cell(const GridHeader& h, const uint8_t* mask, int mshift, uint32_t key) {      // linear cell key
+    const uint32_t d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = key / d0, cz = row / d1;
+    return mask[roi_macro(h, mshift, (int)(key - row * d0), (int)(row - cz * d1), (int)cz)] != 0;
 }
 hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
                       uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp_a, uint8_t* d_tmp_b, uint8_t* d_mask, double base_m, double per_m, hipStream_t s);

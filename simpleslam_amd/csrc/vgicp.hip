@@ -268,9 +268,10 @@ __global__ __launch_bounds__(256, kBatch ? 1 : 4) void vgicp_cov_kernel(GridView
                                                         const CovCheck chk, const RoiView roi) {
     __shared__ uint2 sh_rows[kBatch ? 9 * 256 : 1];      // row ranges of ring 1 (ring_level)
     const GridHeader h = *g.hdr;
-    if (h.empty || h.overflow) return;
+    if (h.empty || h.overflow || h.stale) return;      // (stale: queued ahead of the host's look at the header, capi.hip: settle_cov_levels; the caller builds afresh)
     GridHeader lat;
     if (roi.mask) lat = *roi.lat;
+    if (roi.mask && (lat.stale || lat.overflow)) return;
     GridLevels lv;
     lv.hdr[0] = g.hdr; lv.pts[0] = g.pts; lv.cell_start[0] = g.cell_start;
     lv.hdr[1] = g1.hdr; lv.pts[1] = g1.pts; lv.cell_start[1] = g1.cell_start;
@@ -366,7 +367,7 @@ __device__ __forceinline__ bool lattice_key(const GridHeader& h, double x, doubl
 
 __global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const double* __restrict__ cov6, VgicpVoxel* __restrict__ vox, const RoiView roi) {
     const GridHeader h = *g.hdr;
-    if (h.overflow || h.empty) return;
+    if (h.overflow || h.empty || h.stale) return;
     const uint32_t n = g.cell_start[h.n_cells];
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
         const float4 q = g.pts[j];

@@ -43,7 +43,7 @@ class PcrStats(C.Structure):
     _fields_ = [
         ("total_ms", C.c_double), ("index_ms", C.c_double), ("solve_ms", C.c_double), ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_int32), ("iterations", C.c_int32), ("n_src", C.c_int64), ("n_dst", C.c_int64),
-        ("attempts", C.c_int32), ("target_builds", C.c_int32), ("region_repeats", C.c_int32), ("pad_", C.c_int32),
+        ("attempts", C.c_int32), ("target_builds", C.c_int32), ("region_repeats", C.c_int32), ("region_index", C.c_int32),
     ]
 
 

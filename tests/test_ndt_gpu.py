@@ -266,3 +266,28 @@ def test_target_prepared_for_the_scans_region_only(gpu, nd_world, off):
     assert full.stats()["region_repeats"] == 0
     if off < 1.0:
         assert reg.stats()["region_repeats"] == 0
+
+
+def test_region_index_of_later_calls_matches_the_whole_target(gpu, nd_world):
+    """From its second pcr_scan2map on, a handle indexes only the target points inside the scan's region (BuildFilter: the lattice and the
+    tile layout of the first, full build are the hints that make it possible).  Voxel Gaussians depend on a voxel's own points alone, so
+    poses, verdicts and iteration counts are those of a handle that always prepares the whole target, bit for bit -- also when the pose
+    leaves the region (every cell outside it counts as unprepared) and the call is repeated on the whole target."""
+    w = nd_world
+    full = NdtRegister(full_target=1)
+    reg = NdtRegister()
+    seen_region_index = 0
+    for k, off in enumerate([0.1, -0.2, 0.15, 6.0, 0.05]):
+        T0 = w["truth"].copy()
+        T0[:3, 3] += np.array([off, -0.5 * off, 0.02 * off])
+        pf = T0.copy(); cf = full.scan2Map(w["scan"], w["map"], pf)
+        p = T0.copy(); c = reg.scan2Map(w["scan"], w["map"], p)
+        assert c == cf, (k, off)
+        np.testing.assert_array_equal(p, pf)
+        assert reg.stats()["iterations"] == full.stats()["iterations"]
+        seen_region_index += reg.stats()["region_index"]
+        if k == 0:
+            assert reg.stats()["region_index"] == 0      # nothing to go by yet: the whole cloud is indexed
+    assert seen_region_index >= 2
+    assert reg.stats()["region_repeats"] >= 1            # the 6 m guess
+    assert full.stats()["region_repeats"] == 0 and full.stats()["region_index"] == 0
