@@ -114,10 +114,14 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
             if (t < h.n_cells) {
-                const bool full = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
-                bool in = true;
-                if (every) in = cx0 + u < (uint32_t)h.dims[0] ? roi.mask[mrow + ((cx0 + u) >> roi.mshift)] != 0 : ndt_cell_in_roi(h, roi, t);
-                else if (full && roi.mask) in = ndt_cell_in_roi(h, roi, t);
+                bool in = true, full;
+                if (every) {      // (the mask first: two cells in three lie outside it and their counts need not be read)
+                    in = cx0 + u < (uint32_t)h.dims[0] ? roi.mask[mrow + ((cx0 + u) >> roi.mshift)] != 0 : ndt_cell_in_roi(h, roi, t);
+                    full = in && !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
+                } else {
+                    full = !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points;
+                    if (full && roi.mask) in = ndt_cell_in_roi(h, roi, t);
+                }
                 mine_total += (full && in) ? 1u : 0u;
                 vox_slot[t] = ((full || every) && !in && !h.empty) ? kNdtUnprepared : 0u;
             }
@@ -141,7 +145,10 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
-            if (t < h.n_cells && !h.empty && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points && (!roi.mask || ndt_cell_in_roi(h, roi, t))) {
+            // (same cells as round 1; with an index of the region only the mask is asked first, as there)
+            const bool every = roi.mask && roi.filtered;
+            if (t < h.n_cells && !h.empty && (!every || ndt_cell_in_roi(h, roi, t)) && (int)(g.cell_start[t + 1] - g.cell_start[t]) >= min_points &&
+                (every || !roi.mask || ndt_cell_in_roi(h, roi, t))) {
                 if (pos < capacity) list[pos] = (uint32_t)t;      // (capacity = points / min_points: never short)
                 ++pos;
             }
