@@ -2078,6 +2078,16 @@ int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t strid
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->have_target || !h->grid.valid) return fail(h, "no target: register a scan or call pcr_set_target first");
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
+    if (h->grid.filtered) {
+        // The last pcr_scan2map (NDT) indexed only the target points of its scan's region; a nearest-neighbour search needs them all.
+        // A target that came in as a HOST buffer still lies in this handle's staging copy and is indexed again, in full; a device buffer
+        // is the caller's and may be gone.
+        if (h->method != kNdt || h->tgt_ptr != h->tgt_stage.as<float>() || !h->tgt_n)
+            return fail(h, "the target index of the last pcr_scan2map holds the scan's region only (pcr_stats.region_index) and the target was a device buffer: "
+                           "call pcr_set_target, or set pcr_params.full_target, before asking for a fitness score against it");
+        h->nd_target_ready = false;
+        if (settle_grid(h, h->grid, h->tgt_ptr, h->tgt_n, h->tgt_stride, (double)(float)h->prm.ndt_resolution, 1)) return 1;
+    }
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (ensure_out32(h)) return 1;

@@ -193,6 +193,8 @@ def test_gated_fitness_of_align_cpp(gpu, vg_world):
         reg = make()
         pose = w["init"].copy()
         reg.scan2Map(w["scan"], w["map"], pose)                  # align.cpp:144 ... then :150 scores against the same target
+        pose = w["init"].copy()
+        reg.scan2Map(w["scan"], w["map"], pose)                  # (a handle's later calls may index the scan's region only: the score must not care)
         got, n_in = reg.fitnessGated(w["scan"], T, gate)
         assert n_in == n_want
         np.testing.assert_allclose(got, want, rtol=1e-6)
@@ -295,3 +297,27 @@ def test_target_prepared_for_the_scans_region_only(gpu, vg_world, off):
     if rep == 0:
         with pytest.raises(Exception, match="prepares its target for that one scan only"):
             reg.align(w["scan"], T0.copy())
+
+
+def test_gated_fitness_against_a_region_only_index_of_a_device_target_is_refused(gpu, vg_world):
+    """NDT, from the second pcr_scan2map of a handle on, indexes only the target points of the scan's region (pcr_stats.region_index).  A host
+    target still lies in the handle's staging copy and is indexed again for the score (the test above); a DEVICE target is the caller's and
+    may be gone: the call says so instead of searching an incomplete index."""
+    import torch
+    from simpleslam_amd import NdtRegister
+    from simpleslam_amd.pcr import PcrError
+    w = vg_world
+    d_scan, d_map = torch.from_numpy(w["scan"]).cuda(), torch.from_numpy(w["map"]).cuda()
+    reg = NdtRegister()
+    for _ in range(2):
+        pose = w["init"].copy()
+        reg.scan2Map(d_scan, d_map, pose)
+    if reg.stats()["region_index"]:
+        with pytest.raises(PcrError, match="region only"):
+            reg.fitnessGated(d_scan, w["init"], 1.0)
+    full = NdtRegister(full_target=1)
+    for _ in range(2):
+        pose = w["init"].copy()
+        full.scan2Map(d_scan, d_map, pose)
+    assert full.stats()["region_index"] == 0
+    full.fitnessGated(d_scan, w["init"], 1.0)
