@@ -347,7 +347,10 @@ int pcr_get_params(const pcr_handle* h, pcr_params* out);
 
 /* The fitness score of the reference's test/align.cpp:29-61: the source transformed by `pose` (float, as
  * pcl::transformPointCloud), 1-NN in the handle's current target, mean of the squared distances that are <= max_sq
- * (align.cpp uses 1.0); *n_in = points counted.  score = -1 when none is (align.cpp:56-59).  Any method's handle with a target. */
+ * (align.cpp uses 1.0); *n_in = points counted.  score = -1 when none is (align.cpp:56-59).  Any method's handle with a target.
+ * An NDT handle whose last pcr_scan2map indexed the scan's region only (pcr_stats.region_index) indexes the target again, in full, when
+ * that target came in as a HOST buffer (it still lies in the handle's staging copy); a DEVICE target is the caller's and may be gone: the
+ * call fails and says so (pcr_set_target, or pcr_params.full_target = 1, avoid it). */
 int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes, int on_device, const double pose[16],
                       double max_sq, double* score, int64_t* n_in);
 
