@@ -568,13 +568,20 @@ int cov_levels(size_t n) { return n <= 300000 ? cov_levels_small() : 1; }
 int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats);
 int vgicp_side_init(pcr_handle* h) {
     if (!h->side_stream) {
-        H_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        // The three streams of a VGICP call must be three HARDWARE queues.  The runtime spreads the streams of a process over a small pool
+        // of queues per priority level (four by default), in the order they were created: in a process that had made a few streams
+        // before -- bench.py's LOAM handles, any host application -- this handle's main and side stream came to share a queue, the scan's
+        // side ran behind the target's kernels instead of beside them, and a call took 0.76 ms instead of 0.53.  Each priority level
+        // has a pool of its own: the side stream asks for the highest, the auxiliary one for the lowest, the main one keeps the default.
+        int prio_least = 0, prio_greatest = 0;
+        H_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        H_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_greatest));
         H_TRY(hipEventCreateWithFlags(&h->ev_side_in, hipEventDisableTiming));
         H_TRY(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
         H_TRY(hipEventCreateWithFlags(&h->ev_hdr, hipEventDisableTiming));
         H_TRY(hipEventCreateWithFlags(&h->ev_aux_in, hipEventDisableTiming));
         H_TRY(hipEventCreateWithFlags(&h->ev_aux_done, hipEventDisableTiming));
-        H_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        H_TRY(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_least));
         H_TRY(hipHostMalloc((void**)&h->side_hdr, 7 * sizeof(GridHeader), hipHostMallocDefault));
     }
     return 0;
