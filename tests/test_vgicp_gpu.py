@@ -321,3 +321,28 @@ def test_gated_fitness_against_a_region_only_index_of_a_device_target_is_refused
         full.scan2Map(d_scan, d_map, pose)
     assert full.stats()["region_index"] == 0
     full.fitnessGated(d_scan, w["init"], 1.0)
+
+
+@pytest.mark.parametrize("method", ["vgicp", "ndt"])
+def test_hints_of_an_earlier_target_that_do_not_hold_the_next_one(gpu, vg_world, method):
+    """From its second pcr_scan2map on a handle builds its target grids by the previous call's box and tile layout, queues the region,
+    the covariances and the voxels before it has seen a header (VGICP) and indexes only the region's points (NDT).  When the next target
+    does not fit those hints -- the sub-map grew beyond the box, a tile outgrew its room, or it shrank -- the kernels queued ahead leave
+    on the header's flag and the target is prepared again without hints: the result is a fresh handle's, bit for bit, for every call."""
+    from simpleslam_amd import make_register
+    w = vg_world
+    m = w["map"]
+    x = m[:, 0]
+    lo, hi = np.percentile(x, 30), np.percentile(x, 70)
+    targets = [m[(x > lo) & (x < hi)], m, m[x < hi], m[::3], m]      # grows past the box, shrinks, thins out, grows again
+    reg = make_register(method)
+    for k, tgt in enumerate(targets):
+        tgt = np.ascontiguousarray(tgt)
+        pose = w["init"].copy()
+        conv = reg.scan2Map(w["scan"], tgt, pose)
+        fresh = make_register(method)
+        pf = w["init"].copy()
+        cf = fresh.scan2Map(w["scan"], tgt, pf)
+        assert conv == cf, (method, k)
+        np.testing.assert_array_equal(pose, pf, err_msg=f"{method} call {k}")
+        assert reg.stats()["iterations"] == fresh.stats()["iterations"]
