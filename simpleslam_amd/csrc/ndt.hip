@@ -492,11 +492,18 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
                     e = gauss_d2 * e;
                     if (e > 1 || e < 0 || e != e) continue;                      // :504-505
                     e = (float)((double)e * a.d1);
+                    // c_inv * point_gradient.  The first three columns of the point gradient are the identity and pg[0][3] is zero by
+                    // construction (:399-440).  Written out, ci * 1 + cj * 0 + ck * 0 is ci to the bit for finite entries (a product with
+                    // 0 is +-0, and adding +-0 changes nothing but the sign of a zero), but a compiler that may not assume finite values
+                    // has to keep every one of those multiplies and adds: a fifth of a pass's arithmetic.  They are left out here.
                     float cpg[3][6];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < 3; ++r) {
+                        cpg[r][0] = ci[r][0]; cpg[r][1] = ci[r][1]; cpg[r][2] = ci[r][2];
+                        { float s = ci[r][1] * pg[1][3]; s += ci[r][2] * pg[2][3]; cpg[r][3] = s; }
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) { float s = ci[r][0] * pg[0][c]; s += ci[r][1] * pg[1][c]; s += ci[r][2] * pg[2][c]; cpg[r][c] = s; }
+                        for (int c = 4; c < 6; ++c) { float s = ci[r][0] * pg[0][c]; s += ci[r][1] * pg[1][c]; s += ci[r][2] * pg[2][c]; cpg[r][c] = s; }
+                    }
                     float xcpg[6];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) { float s = x4t[0] * cpg[0][c]; s += x4t[1] * cpg[1][c]; s += x4t[2] * cpg[2][c]; xcpg[c] = s; }
@@ -507,13 +514,23 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
                         for (int i = 0; i < 6; ++i) {
 #pragma unroll
                             for (int j = 0; j < 6; ++j) {
-                                float xph = 0.0f;
+                                // (PG^T C PG)(j,i) and x^T C (second derivative), with the structural zeros and ones left out as above:
+                                // column j < 3 of the point gradient is a unit vector, pg[0][3] and the first component of five of the
+                                // nine second derivatives are zero
+                                float pgc;
+                                if (j < 3) pgc = cpg[j][i];
+                                else if (j == 3) { pgc = pg[1][3] * cpg[1][i]; pgc += pg[2][3] * cpg[2][i]; }
+                                else { pgc = pg[0][j] * cpg[0][i]; pgc += pg[1][j] * cpg[1][i]; pgc += pg[2][j] * cpg[2][i]; }
+                                float t = -gauss_d2 * xcpg[i] * xcpg[j];
                                 if (i >= 3 && j >= 3) {
-                                    const float* q = ph[(i - 3) * 3 + (j - 3)];
-                                    xph = xc[0] * q[0]; xph += xc[1] * q[1]; xph += xc[2] * q[2];
+                                    const int qi = (i - 3) * 3 + (j - 3);
+                                    const float* q = ph[qi];
+                                    float xph;
+                                    if (qi == 0 || qi == 1 || qi == 2 || qi == 3 || qi == 6) { xph = xc[1] * q[1]; xph += xc[2] * q[2]; }
+                                    else { xph = xc[0] * q[0]; xph += xc[1] * q[1]; xph += xc[2] * q[2]; }
+                                    t += xph;
                                 }
-                                float pgc = pg[0][j] * cpg[0][i]; pgc += pg[1][j] * cpg[1][i]; pgc += pg[2][j] * cpg[2][i];   // (PG^T C PG)(j,i)
-                                v[7 + i * 6 + j] += (double)(e * (-gauss_d2 * xcpg[i] * xcpg[j] + xph + pgc));
+                                v[7 + i * 6 + j] += (double)(e * (t + pgc));
                             }
                         }
                     }
@@ -572,27 +589,37 @@ __device__ __forceinline__ void ndt_hessian_body(const NdtArgs& a, const NdtPose
                     double e = a.d2 * exp(-a.d2 * (xt[0] * cx[0] + xt[1] * cx[1] + xt[2] * cx[2]) / 2);     // :623
                     if (e > 1 || e < 0 || e != e) continue;
                     e *= a.d1;
+                    // (structural zeros and ones of the point gradient and of the second derivatives left out, as in the float pass above)
                     double cpg[6][3], xd[6];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) cpg[i][r] = ci[r * 3] * pg[0][i] + ci[r * 3 + 1] * pg[1][i] + ci[r * 3 + 2] * pg[2][i];
+                        for (int r = 0; r < 3; ++r) {
+                            if (i < 3) cpg[i][r] = ci[r * 3 + i];
+                            else if (i == 3) cpg[i][r] = ci[r * 3 + 1] * pg[1][3] + ci[r * 3 + 2] * pg[2][3];
+                            else cpg[i][r] = ci[r * 3] * pg[0][i] + ci[r * 3 + 1] * pg[1][i] + ci[r * 3 + 2] * pg[2][i];
+                        }
                         xd[i] = xt[0] * cpg[i][0] + xt[1] * cpg[i][1] + xt[2] * cpg[i][2];
                     }
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
-                            double t2 = 0.0;
+                            double t = -a.d2 * xd[i] * xd[j];
                             if (i >= 3 && j >= 3) {
-                                const double* q = ph[(i - 3) * 3 + (j - 3)];
+                                const int qi = (i - 3) * 3 + (j - 3);
+                                const double* q = ph[qi];
                                 double cph[3];
+                                const bool q0_zero = qi == 0 || qi == 1 || qi == 2 || qi == 3 || qi == 6;
 #pragma unroll
-                                for (int r = 0; r < 3; ++r) cph[r] = ci[r * 3] * q[0] + ci[r * 3 + 1] * q[1] + ci[r * 3 + 2] * q[2];
-                                t2 = xt[0] * cph[0] + xt[1] * cph[1] + xt[2] * cph[2];
+                                for (int r = 0; r < 3; ++r) cph[r] = q0_zero ? ci[r * 3 + 1] * q[1] + ci[r * 3 + 2] * q[2] : ci[r * 3] * q[0] + ci[r * 3 + 1] * q[1] + ci[r * 3 + 2] * q[2];
+                                t += xt[0] * cph[0] + xt[1] * cph[1] + xt[2] * cph[2];
                             }
-                            const double t3 = pg[0][j] * cpg[i][0] + pg[1][j] * cpg[i][1] + pg[2][j] * cpg[i][2];
-                            v[7 + i * 6 + j] += e * (-a.d2 * xd[i] * xd[j] + t2 + t3);
+                            double t3;
+                            if (j < 3) t3 = cpg[i][j];
+                            else if (j == 3) t3 = pg[1][3] * cpg[i][1] + pg[2][3] * cpg[i][2];
+                            else t3 = pg[0][j] * cpg[i][0] + pg[1][j] * cpg[i][1] + pg[2][j] * cpg[i][2];
+                            v[7 + i * 6 + j] += e * (t + t3);
                         }
                     }
                 }
