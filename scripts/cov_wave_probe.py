@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-wave record of vgicp_cov_kernel<true> on the bench's VGICP scan (development; needs a library built with EXTRA=-DPCR_COV_DEBUG in
-place of simpleslam_amd/lib/libpcr_hip.so): duration of every wave against the work of its lanes' searches."""
+"""Per-wave record of vgicp_cov_kernel<true> on the bench's VGICP scan: duration of every wave against the work of its lanes' searches.
+Development aid, kept for the record of profiles/r03_notes.md: it reads a table that an INSTRUMENTED build of vgicp.hip fills (s_memrealtime
+at the wave's begin and end, per-lane counters of runs / steps / insertions folded over the wave, exported as pcr_cov_debug_dump) -- that
+instrumentation is not in the tree; the notes describe it and what it found."""
 import ctypes as C, os, re, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +22,8 @@ for _ in range(3):
     pose = init.copy()
     reg.scan2Map(d_scan, d_map, pose)
 lib = reg._lib
+if not hasattr(lib, "pcr_cov_debug_dump"):
+    raise SystemExit("this library has no pcr_cov_debug_dump: see the docstring")
 buf = (C.c_ulonglong * (4096 * 10))()
 lib.pcr_cov_debug_dump.argtypes = [C.POINTER(C.c_ulonglong)]
 assert lib.pcr_cov_debug_dump(buf) == 0
