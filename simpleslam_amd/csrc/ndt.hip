@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
             cx0 = (uint32_t)t0 - row * d0;
             mrow = roi_macro(h, roi.mshift, 0, (int)(row - cz * d1), (int)cz);
         }
+        uint32_t sl[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + u;
@@ -123,8 +124,15 @@ __global__ __launch_bounds__(256) void ndt_candidates_kernel(GridView g, uint32_
                     if (full && roi.mask) in = ndt_cell_in_roi(h, roi, t);
                 }
                 mine_total += (full && in) ? 1u : 0u;
-                vox_slot[t] = ((full || every) && !in && !h.empty) ? kNdtUnprepared : 0u;
+                sl[u] = ((full || every) && !in && !h.empty) ? kNdtUnprepared : 0u;
             }
+        }
+        // (the table is written in full by every target: one 16-byte store per thread -- the slot table's allocation is 256-byte aligned
+        //  and t0 a multiple of four)
+        if (t0 + 3 < h.n_cells) *reinterpret_cast<uint4*>(vox_slot + t0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+        else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (t0 + u < h.n_cells) vox_slot[t0 + u] = sl[u];
         }
     }
     uint32_t inc = mine_total;                     // inclusive prefix over the block
