@@ -177,6 +177,11 @@ int pcr_get_trace_counts(pcr_handle* h, int64_t* cache_hits, int64_t* searches);
 /* VGICP introspection.  Per-point covariances as fast_gicp::FastGICP::calculate_covariances forms
  * them (fast_gicp_impl.hpp:241-297; 20-NN, PLANE regularisation): cov_out[n*6] = xx xy xz yy yz zz. */
 int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double* cov_out);
+/* The neighbour lists behind the covariances of the LAST pcr_vgicp_covariances call on a scan-sized cloud (n <= 300 000):
+ * nbr_out[n*20] = original indices of each point's 20 nearest neighbours (FLANN's float distances, ties on the lower index; the
+ * point itself first), 0xffffffff where the cloud holds fewer; *queued_out = the queries the lane-per-query search handed to the
+ * wave-per-query one (csrc/cov_search.hip).  fast_gicp_impl.hpp:250-253 (kdtree.nearestKSearch). */
+int pcr_vgicp_neighbours(pcr_handle* h, size_t n, uint32_t* nbr_out, uint32_t* queued_out);
 /* One FastVGICP::linearize (fast_vgicp_impl.hpp:119-180) at `pose` against the current target
  * (pcr_set_target): H (36, row-major, twist = [rotation; translation]), b (6), sum of errors,
  * number of source points with a voxel correspondence. */

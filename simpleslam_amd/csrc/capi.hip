@@ -102,6 +102,7 @@ struct pcr_handle {
     double cov_scale_hint = 0.0;     // cell scale of the last map-sized target's covariance grid: built ahead of the density it is derived from
     bool cov_l1_ahead = false;       // ... and whether that build is the one in h->cov_l1 now
     DeviceBuf tgt_cov6, src_cov6, vox, corr_slot, corr_M, corr_slot2, corr_M2, vg_partials;
+    CovScratch src_scratch, tgt_scratch;   // neighbour lists + queue of the covariance search of a scan-sized cloud: the source's runs on the side stream beside the target's
     double seq = 0.0;                    // completion numbers of the host-mapped result blocks below
     double* out32_host = nullptr;        // host-mapped: 32 doubles written by sum_partials_kernel
     double* out32_dev = nullptr;
@@ -707,7 +708,7 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
             h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
     }
     if (e == hipSuccess && (e = vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
-                                                 h->src_cov6.as<double>(), h->side_stream)) != hipSuccess)
+                                                 h->src_cov6.as<double>(), h->side_stream, nullptr, nullptr, &h->src_scratch)) != hipSuccess)
         h->err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
     h->fit_copied_from = nullptr;
     if (e == hipSuccess && !sharded(h) && n_src > 0) {      // the scan, kept for a later pcr_fitness() (off the critical path here)
@@ -746,7 +747,7 @@ int vgicp_source_settle(pcr_handle* h, const float* d_src, size_t n_src, size_t 
     if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_src, n_src, stride_floats, h->prm.vgicp_resolution, 0.0, nullptr)) return 1;
     H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
-                           h->src_cov6.as<double>(), h->stream));
+                           h->src_cov6.as<double>(), h->stream, nullptr, nullptr, &h->src_scratch));
     return 0;
 }
 
@@ -816,7 +817,7 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
             h->roi_on = true;
         }
         H_TRY(vgicp_launch_cov(*cov_grid, cov_levels(n_dst) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_dst) > 2 ? &h->cov_l2 : nullptr, d_dst, stride_floats,
-                               n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr));
+                               n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr, &h->tgt_scratch));
         H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream, h->roi_on ? &roi : nullptr));
         return 0;
     };
@@ -1508,7 +1509,7 @@ void pcr_destroy(pcr_handle* h) {
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
-    h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release();
+    h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release(); h->src_scratch.release(); h->tgt_scratch.release();
     h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release(); h->vg_ctl.release(); h->fit_src.release();
     if (h->vg_out_host) (void)hipHostFree(h->vg_out_host);
     if (h->out32_host) (void)hipHostFree(h->out32_host);
@@ -1756,9 +1757,35 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
     H_TRY(h->src_cov6.reserve((n + 1) * 6 * sizeof(double)));
     H_TRY(hipMemsetAsync(h->src_cov6.p, 0, (n + 1) * 6 * sizeof(double), h->stream));
     H_TRY(vgicp_launch_cov(h->src_grid, cov_levels(n) > 1 ? &h->src_l1 : nullptr, cov_levels(n) > 2 ? &h->src_l2 : nullptr, d_pts, stride_bytes / 4, n,
-                           h->src_cov6.as<double>(), h->stream));
+                           h->src_cov6.as<double>(), h->stream, nullptr, nullptr, &h->src_scratch));
     H_TRY(hipMemcpyAsync(cov_out, h->src_cov6.p, n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pcr_vgicp_neighbours(pcr_handle* h, size_t n, uint32_t* nbr_out, uint32_t* queued_out) {
+    if (!h) return 1;
+    h->err.clear();
+    if (h->method != kVgicp) return fail(h, "pcr_vgicp_neighbours needs a vgicp handle");
+    if (set_device(h)) return 1;
+    const CovScratch& sc = h->src_scratch;
+    if (!sc.nbr.p || !h->src_grid.valid || h->src_grid.n_points > n || n > 300000) return fail(h, "no neighbour lists of a cloud of that size: call pcr_vgicp_covariances on a scan-sized cloud first");
+    const size_t n_cap = std::min(sc.queue.cap / sizeof(uint32_t), sc.nbr.cap / (20 * sizeof(uint32_t))), ns = h->src_grid.n_points;
+    std::vector<uint32_t> lists(n_cap * 20);
+    std::vector<float> sorted(ns * 4);
+    uint32_t queued = 0;
+    H_TRY(hipStreamSynchronize(h->stream));
+    H_TRY(hipMemcpy(lists.data(), sc.nbr.p, lists.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    H_TRY(hipMemcpy(sorted.data(), h->src_grid.sorted.p, sorted.size() * sizeof(float), hipMemcpyDeviceToHost));
+    H_TRY(hipMemcpy(&queued, sc.count.p, sizeof queued, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n * 20; ++i) nbr_out[i] = 0xffffffffu;
+    for (size_t j = 0; j < ns; ++j) {
+        uint32_t orig;
+        memcpy(&orig, &sorted[j * 4 + 3], 4);
+        if (orig >= n) return fail(h, "the scan index does not belong to a cloud of that size");
+        for (int k = 0; k < 20; ++k) nbr_out[(size_t)orig * 20 + k] = lists[(size_t)k * n_cap + j];
+    }
+    if (queued_out) *queued_out = queued;
     return 0;
 }
 

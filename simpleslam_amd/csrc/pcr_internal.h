@@ -260,6 +260,14 @@ __host__ __device__ inline bool roi_mask_holds_cell(const GridHeader& h, const u
     const uint32_t d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = key / d0, cz = row / d1;
     return mask[roi_macro(h, mshift, (int)(key - row * d0), (int)(row - cz * d1), (int)cz)] != 0;
 }
+#ifdef __HIPCC__
+// is the voxel that the point (x, y, z) belongs to inside the prepared region?  (lat: the voxel lattice's header)
+__device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHeader& lat, double x, double y, double z) {
+    const double fx = floor(x / lat.cell - lat.shift) - lat.org[0], fy = floor(y / lat.cell - lat.shift) - lat.org[1], fz = floor(z / lat.cell - lat.shift) - lat.org[2];
+    if (!(fx >= 0.0 && fx < (double)lat.dims[0] && fy >= 0.0 && fy < (double)lat.dims[1] && fz >= 0.0 && fz < (double)lat.dims[2])) return false;
+    return roi.mask[roi_macro(lat, roi.mshift, (int)fx, (int)fy, (int)fz)] != 0;
+}
+#endif
 hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
                       uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp_a, uint8_t* d_tmp_b, uint8_t* d_mask, double base_m, double per_m, hipStream_t s);
 
@@ -284,8 +292,18 @@ struct VgicpArgs {
 // Halo check of a sharded target (pcr_set_shard): for every point inside [chk_lo, chk_hi) the 20th neighbour must be nearer
 // than the faces of [ext_lo, ext_hi) -- the region the rank's cloud is complete in; *violations counts the others.
 struct CovCheck { double chk_lo[3], chk_hi[3], ext_lo[3], ext_hi[3]; uint32_t* violations; };
+// Work memory of the two-class covariance search of a scan-sized cloud (cov_search.hip): neighbour lists [20][n], the queue of the queries
+// the lane-per-query kernel hands to the wave-per-query one (+ the bound each brings along), its counter.  One per stream that runs it.
+struct CovScratch {
+    DeviceBuf nbr, queue, seed, count;
+    hipError_t reserve(size_t n);
+    void release();
+};
+hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
+                             size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch& sc);
+// scratch: scan-sized clouds (n <= 300 000) go through cov_search.hip when given one
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr, const RoiView* roi = nullptr);
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr, const RoiView* roi = nullptr, CovScratch* scratch = nullptr);
 hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s, const RoiView* roi = nullptr);
 // (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);

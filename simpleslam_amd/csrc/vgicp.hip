@@ -17,6 +17,7 @@
 #include "pcr_internal.h"
 #include "small_math.h"
 #include "vgicp_opt.h"
+#include "cov_math.h"
 
 namespace pcr {
 
@@ -205,59 +206,6 @@ __device__ __forceinline__ GridLevels one_level(const GridView& g) {
     return lv;
 }
 
-// ------------------------------------------------------------------------------
-// symmetric 3x3 eigen-decomposition by cyclic Jacobi; eigenvalues descending, V columns
-// ------------------------------------------------------------------------------
-__device__ inline void sym3_eig(const double A[6] /* xx xy xz yy yz zz */, double w[3], double V[3][3]) {
-    double a[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
-    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 32; ++sweep) {
-        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
-        if (off <= 1e-300 || off <= 1e-22 * diag) break;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int q = p + 1; q < 3; ++q) {
-                if (a[p][q] != 0.0) {
-                    const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
-                }
-            }
-        }
-    }
-    // sort descending with static indexing
-    double e0 = a[0][0], e1 = a[1][1], e2 = a[2][2];
-    double c0[3] = {v[0][0], v[1][0], v[2][0]}, c1[3] = {v[0][1], v[1][1], v[2][1]}, c2[3] = {v[0][2], v[1][2], v[2][2]};
-#define SWAPCOL(ea, ca, eb, cb) if (eb > ea) { double t_ = ea; ea = eb; eb = t_; for (int k_ = 0; k_ < 3; ++k_) { double u_ = ca[k_]; ca[k_] = cb[k_]; cb[k_] = u_; } }
-    // same selection order as the oracle: position 0 vs 1, 0 vs 2, then 1 vs 2
-    SWAPCOL(e0, c0, e1, c1) SWAPCOL(e0, c0, e2, c2) SWAPCOL(e1, c1, e2, c2)
-#undef SWAPCOL
-    w[0] = e0; w[1] = e1; w[2] = e2;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { V[k][0] = c0[k]; V[k][1] = c1[k]; V[k][2] = c2[k]; }
-}
-
-// ------------------------------------------------------------------------------
-// V2: covariance of every point of an indexed cloud (thread per cell-sorted point)
-// cov6 is indexed by the ORIGINAL point index: xx xy xz yy yz zz
-// ------------------------------------------------------------------------------
-static constexpr int kCovK = 20;
-
-// is the voxel that the point (x, y, z) belongs to inside the prepared region?  (lat: the voxel lattice's header)
-__device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHeader& lat, double x, double y, double z) {
-    const double fx = floor(x / lat.cell - lat.shift) - lat.org[0], fy = floor(y / lat.cell - lat.shift) - lat.org[1], fz = floor(z / lat.cell - lat.shift) - lat.org[2];
-    if (!(fx >= 0.0 && fx < (double)lat.dims[0] && fy >= 0.0 && fy < (double)lat.dims[1] && fz >= 0.0 && fz < (double)lat.dims[2])) return false;
-    return roi.mask[roi_macro(lat, roi.mshift, (int)fx, (int)fy, (int)fz)] != 0;
-}
-
 // kBatch: ring 1 of every level with its nine row ranges requested at once (ring_level).  For a SCAN-sized cloud, whose search is a chain
 // of dependent round trips at one wave per SIMD: A/B on one box, the scan's 65 k covariances no longer hold the optimiser up (align 0.19 ->
 // 0.11 ms).  A map-sized cloud runs the same kernel at four waves per SIMD and is bound by instruction issue: there the batched form
@@ -286,48 +234,10 @@ __global__ __launch_bounds__(256, kBatch ? 1 : 4) void vgicp_cov_kernel(GridView
         if (roi.mask && !roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z)) continue;
         KeyList<kCovK> L;
         ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L, kBatch ? sh_rows : nullptr);
-        // fast_gicp_impl.hpp:255-262: neighbours as f64, minus their mean, N N^T / k
-        double mx = 0, my = 0, mz = 0;
-        int found = 0;
+        uint32_t nb_idx[kCovK];
 #pragma unroll
-        for (int i = 0; i < kCovK; ++i) {
-            if (L.k[i] != ~0ull) {
-                const float* p = orig + (size_t)(uint32_t)L.k[i] * stride;
-                mx += (double)p[0]; my += (double)p[1]; mz += (double)p[2];
-                ++found;
-            }
-        }
-        mx /= (double)kCovK; my /= (double)kCovK; mz /= (double)kCovK;
-        double C[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < kCovK; ++i) {
-            if (L.k[i] != ~0ull) {
-                const float* p = orig + (size_t)(uint32_t)L.k[i] * stride;
-                const double c0 = (double)p[0] - mx, c1 = (double)p[1] - my, c2 = (double)p[2] - mz;
-                C[0] += c0 * c0; C[1] += c0 * c1; C[2] += c0 * c2; C[3] += c1 * c1; C[4] += c1 * c2; C[5] += c2 * c2;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 6; ++e) C[e] /= (double)kCovK;
-        double w[3], V[3][3];
-        sym3_eig(C, w, V);
-        // PLANE: singular values replaced by (1, 1, 1e-3)   fast_gicp_impl.hpp:279-281,292
-        const double val[3] = {1.0, 1.0, 1e-3};
-        double out[6];
-        int o = 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = r; c < 3; ++c) {
-                double s = 0;
-#pragma unroll
-                for (int e = 0; e < 3; ++e) s += V[r][e] * val[e] * V[c][e];
-                out[o++] = s;
-            }
-        }
-        double* dst = cov6 + (size_t)__float_as_uint(q.w) * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) dst[e] = out[e];
+        for (int i = 0; i < kCovK; ++i) nb_idx[i] = L.k[i] != ~0ull ? (uint32_t)L.k[i] : 0xffffffffu;
+        const int found = cov_from_neighbours(nb_idx, orig, stride, cov6 + (size_t)__float_as_uint(q.w) * 6);
         if (use_check) {
             // sharded target: this rank holds every map point inside [ext_lo, ext_hi) only.  The neighbourhood of a point that
             // can enter a voxel of the tile is the map's own iff its 20th neighbour is nearer than every face of that region.
@@ -774,7 +684,12 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
 
 // ---- host launchers ---------------------------------------------------------------
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi) {
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch* scratch) {
+    static const bool old_kernel = dev_env("PCR_COV_OLD") != nullptr;      // (development builds: A/B against the lane-per-query kernel)
+    if (scratch && n <= 300000 && n > 0 && !old_kernel) {      // scan-sized: two classes of queries (cov_search.hip)
+        const hipError_t e = scratch->reserve(n);
+        return e != hipSuccess ? e : cov_search_launch(grid, coarse1, coarse2, d_orig, stride_floats, n, d_cov6, s, check, roi, *scratch);
+    }
     const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
     const int levels = coarse1 ? (coarse2 ? 3 : 2) : 1;
     CovCheck chk;

@@ -51,7 +51,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device", "pcr_host_pin", "pcr_host_unpin",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
-    "pcr_vgicp_covariances", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info",
+    "pcr_vgicp_covariances", "pcr_vgicp_neighbours", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info",
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices", "pcr_map_generation", "pcr_scan2map_submap",
@@ -113,6 +113,7 @@ def load_library():
     L.pcr_get_trace.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, vp, vp]
     L.pcr_get_trace_counts.argtypes = [vp, vp, vp]
     L.pcr_vgicp_covariances.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
+    L.pcr_vgicp_neighbours.argtypes = [vp, C.c_size_t, vp, vp]
     L.pcr_vgicp_linearize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.pcr_ndt_derivatives.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, dp]
     L.pcr_get_timeline.argtypes = [vp, vp, C.c_size_t, ip, ip]
@@ -500,6 +501,14 @@ class VgicpRegister(PointCloudRegister):
         out[:, 0, 0], out[:, 0, 1], out[:, 0, 2], out[:, 1, 1], out[:, 1, 2], out[:, 2, 2] = c6.T
         out[:, 1, 0], out[:, 2, 0], out[:, 2, 1] = out[:, 0, 1], out[:, 0, 2], out[:, 1, 2]
         return out
+
+    def neighbours(self, n):
+        """(n,20) original indices of every point's 20 nearest neighbours as the last covariances() call on a scan-sized cloud found them
+        (0xffffffff: none), and the number of queries that went to the wave-per-query search."""
+        out = np.zeros((n, 20), np.uint32)
+        q = C.c_uint32(0)
+        self._check(self._lib.pcr_vgicp_neighbours(self._h, n, out.ctypes.data_as(C.c_void_p), C.byref(q)))
+        return out, int(q.value)
 
     def linearize(self, src, pose):
         p, n, s, dev, _k = _cloud(src)

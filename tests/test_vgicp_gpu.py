@@ -28,6 +28,50 @@ def test_covariances_match_oracle(gpu, vg_world):
     np.testing.assert_allclose(ev, np.tile([1e-3, 1.0, 1.0], (ev.shape[0], 1)), atol=1e-9)
 
 
+def _check_neighbours(scan):
+    """neighbour lists of covariances(scan) == the oracle's float k-NN, index for index (ties on the lower index)"""
+    reg = VgicpRegister()
+    reg.covariances(scan)
+    nb, queued = reg.neighbours(len(scan))
+    k = min(20, len(scan))
+    ref, _ = oracle.knn_f32(scan, scan[:, :3], 20)
+    want = np.where(ref < 0, 0xFFFFFFFF, ref).astype(np.uint32)
+    assert (nb[:, :k] == want[:, :k]).all(), int((nb[:, :k] != want[:, :k]).any(axis=1).sum())
+    assert (nb[:, k:] == 0xFFFFFFFF).all()
+    return queued
+
+
+def test_neighbour_lists_match_oracle_index_for_index(gpu, vg_world):
+    """fast_gicp_impl.hpp:250-253: the 20 nearest neighbours of every scan point.  Both classes of queries of csrc/cov_search.hip
+    (lane-per-query ring 1, wave-per-query rings beyond) must be exercised by a lidar scan."""
+    scan = vg_world["scan"]
+    queued = _check_neighbours(scan)
+    assert 0 < queued < len(scan)
+
+
+def test_neighbour_lists_on_a_lattice_with_exact_ties(gpu):
+    """Coordinates on a 1/8 m lattice: many exactly equal distances at the edge of a list -- the screening keys of the lane-per-query
+    kernel cannot prove those lists and hands them to the exact wave-per-query search; duplicated points tie on everything but the index."""
+    rng = np.random.default_rng(5)
+    pts = np.zeros((6000, 4), np.float32)
+    pts[:, :3] = rng.integers(-40, 40, (6000, 3)) / 8.0
+    pts[:, 2] = rng.integers(0, 3, 6000) / 8.0
+    pts[100:140] = pts[200:240]
+    queued = _check_neighbours(pts)
+    assert queued > 0
+
+
+def test_neighbour_lists_of_tiny_and_sparse_clouds(gpu):
+    """fewer points than neighbours (unfilled slots), one far straggler (rings of the coarse level), a dense clump (thousands of candidates)"""
+    rng = np.random.default_rng(6)
+    tiny = np.zeros((7, 4), np.float32); tiny[:, :3] = rng.normal(0, 1, (7, 3))
+    _check_neighbours(tiny)
+    sparse = np.zeros((400, 4), np.float32); sparse[:, :3] = rng.uniform(-60, 60, (400, 3)); sparse[0, :3] = (400.0, 300.0, 20.0)
+    _check_neighbours(sparse)
+    clump = np.zeros((12000, 4), np.float32); clump[:, :3] = rng.normal(0, 0.15, (12000, 3)); clump[:2000, :3] = rng.uniform(-30, 30, (2000, 3))
+    _check_neighbours(clump)
+
+
 def test_linearize_matches_oracle(gpu, vg_world):
     w = vg_world
     reg = VgicpRegister()
