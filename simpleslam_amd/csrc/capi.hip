@@ -566,7 +566,7 @@ static double src_cell0() { static const double v = dev_env("PCR_COV_CELL0") ? a
 static double cov_ratio() { static const double v = dev_env("PCR_COV_RATIO") ? atof(dev_env("PCR_COV_RATIO")) : 6.0; return v; }
 int cov_levels(size_t n) { return n <= 300000 ? cov_levels_small() : 1; }
 
-int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats);
+int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, bool marked = false);
 int vgicp_side_init(pcr_handle* h) {
     if (!h->side_stream) {
         // The three streams of a VGICP call must be three HARDWARE queues.  The runtime spreads the streams of a process over a small pool
@@ -597,7 +597,7 @@ int vgicp_side_init(pcr_handle* h) {
 // and leave early; whatever they wrote is written again by the caller.
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
                       double shift0, GridHeader* hdr0_out, bool may_cut = false, double ahead_cell = 0.0, bool* ahead_ok = nullptr,
-                      const std::function<int()>* after_ahead = nullptr, bool* after_clean = nullptr) {
+                      const std::function<int()>* after_ahead = nullptr, bool* after_clean = nullptr, const std::function<int()>* before_wait = nullptr) {
     GridIndex* lv[3] = {&g, &l1, &l2};
     const double cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n);
@@ -642,8 +642,11 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
         if (early) {
             H_TRY(hipEventRecord(h->ev_hdr, h->stream));
             if ((*after_ahead)()) { (void)hipStreamSynchronize(h->stream); return 1; }
-            H_TRY(hipEventSynchronize(h->ev_hdr));
-        } else H_TRY(hipStreamSynchronize(h->stream));
+        }
+        // (what the caller wants queued on OTHER streams while the host waits here: the scan's side of a scan2map call)
+        if (before_wait && attempt == 0 && (*before_wait)()) { (void)hipStreamSynchronize(h->stream); return 1; }
+        if (early) H_TRY(hipEventSynchronize(h->ev_hdr));
+        else H_TRY(hipStreamSynchronize(h->stream));
         if (ahead_ok) *ahead_ok = false;
         if (ahead && hdr_ahead.stale) { l1.hint_margin = 8; l1.cells_hint = 0; }      // (built afresh by the caller: it checks ahead_ok)
         else if (ahead && !hdr_ahead.overflow) { l1.note_cells(hdr_ahead.n_cells); if (!hdr_ahead.empty) l1.confirm(); if (ahead_ok) *ahead_ok = true; }
@@ -677,12 +680,19 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
 // stream BEFORE the target is prepared on the main one: the 65 k-point covariance search is latency-bound and hides under
 // the target's kernels.  Speculative about the cell tables: an overflowing level makes its kernels return early, which
 // vgicp_source_settle() detects from the headers and redoes in order.
-int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats) {
+// The point of the main stream the scan's side may start behind (its staging copy, if any, is on the main stream): recorded BEFORE the
+// target's work is queued there, so that a source side enqueued later (vgicp_source_enqueue(.., marked)) does not wait for that work.
+int vgicp_source_mark(pcr_handle* h) {
+    if (vgicp_side_init(h)) return 1;
+    H_TRY(hipEventRecord(h->ev_side_in, h->stream));
+    return 0;
+}
+int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, bool marked) {
     h->side_pending = false;
     if (vgicp_side_init(h)) return 1;
     if (n_src > 0xfffffff0ull) return 0;                         // run_vgicp reports it
     H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
-    H_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
+    if (!marked) H_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
     H_TRY(hipStreamWaitEvent(h->side_stream, h->ev_side_in, 0));
     GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
     const double cell = h->prm.vgicp_resolution, cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
@@ -788,7 +798,8 @@ RoiView roi_view(const pcr_handle* h) {      // the region the handle's target w
 }
 
 // keep_clamp: the caller has set h->clamp (a region cut around a scan, vgicp_align_recut): index that region instead of deciding here
-int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, const RoiScan* roi_scan = nullptr, bool keep_clamp = false) {
+int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t stride_floats, const RoiScan* roi_scan = nullptr, bool keep_clamp = false,
+                         const std::function<int()>* before_wait = nullptr) {
     h->vg_target_ready = false;
     h->roi_on = false;
     const double res = h->prm.vgicp_resolution;
@@ -827,7 +838,7 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     bool early_clean = false;
     const bool try_early = want_roi && !no_early && ahead_cell > 0.0 && !h->clamp.use;
     if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h), ahead_cell, &ahead_ok,
-                          try_early ? &early : nullptr, &early_clean)) return 1;
+                          try_early ? &early : nullptr, &early_clean, before_wait)) return 1;
     if (h->clamp.use) { ahead_ok = false; early_clean = false; }      // (the target was cut to its bulk in there: the grid built ahead covers the uncut cloud)
     h->have_target = true;
     // A map-sized cloud is searched on ONE level whose cell is sized for the 20-neighbour radius, not for the voxel
@@ -1403,8 +1414,18 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         double pose_in[16];
         memcpy(pose_in, pose, sizeof pose_in);
         const RoiScan rs{d_src, n_src, stride_bytes / 4, pose_in};
-        int prc = vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4);
-        if (!prc) prc = vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4, use_roi ? &rs : nullptr);
+        // Order of the two sides.  The scan's own covariances used to be the longest thing in a call (344 us) and were queued first; since
+        // they are searched in two classes (cov_search.hip: ~190 us with the scan's index levels) the target is the long pole, and the
+        // dozen launches of the scan's side cost the host ~100 us during which the main stream sat empty.  Now the target's builds are
+        // queued first and the scan's side while the host waits for their headers (settle_cov_levels: before_wait).
+        static const bool src_first = dev_env("PCR_VG_SRC_FIRST") != nullptr;      // (development builds: the old order, for A/B runs)
+        int prc = 0;
+        bool src_queued = false;
+        const std::function<int()> queue_src = [&]() -> int { src_queued = true; return vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4, true); };
+        if (src_first) { prc = vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4); src_queued = true; }
+        else prc = vgicp_source_mark(h);
+        if (!prc) prc = vgicp_prepare_target(h, d_dst, n_dst, stride_bytes / 4, use_roi ? &rs : nullptr, false, src_first ? nullptr : &queue_src);
+        if (!prc && !src_queued) prc = queue_src();
         if (prc && h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }
         if (agree_prepared(h, prc)) {
             if (h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }

@@ -41,7 +41,7 @@ __device__ __forceinline__ constexpr int row_dy(int r) { return (int)((kRowOrder
 __device__ __forceinline__ constexpr int row_dz(int r) { return (int)((kRowOrder >> (4 * r + 2)) & 3) - 1; }
 
 constexpr int kRuns = 11;                       // the query's own cell, its two x-neighbours, the eight other rows of the block
-struct CovRuns { uint2 run[kRuns + 1][256]; };      // the non-empty runs {first, end} of every lane's block, compacted; entries past the last are {0, 0}
+struct CovRuns { uint2 run[kRuns][256]; };      // {first position, length} of every lane's runs, in the order they are streamed
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -76,27 +76,15 @@ __device__ __forceinline__ double block_bound_sq(const GridHeader& h, float qx, 
     return bound > 0 ? bound * bound * (1.0 - 1e-5) : 0.0;
 }
 
-struct RunCursor { uint32_t j, e, k; uint2 nx; };
-__device__ __forceinline__ uint32_t cursor_step(RunCursor& c, const CovRuns& sh, int tid) {
-    const uint32_t pos = c.j;
-    const uint32_t j1 = c.j + 1u;
-    const bool adv = j1 >= c.e;
-    c.k += adv ? 1u : 0u;
-    c.j = adv ? c.nx.x : j1;
-    c.e = adv ? c.nx.y : c.e;
-    c.nx = sh.run[min(c.k + 1u, (uint32_t)kRuns)][tid];
-    return pos;
+template <int kCtrl> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kCtrl, 0xf, 0xf, false); }
+template <int kCtrl> __device__ __forceinline__ unsigned long long quad_dpp64(unsigned long long v) {
+    return ((unsigned long long)quad_dpp<kCtrl>((uint32_t)(v >> 32)) << 32) | (unsigned long long)quad_dpp<kCtrl>((uint32_t)v);
 }
-// skip n positions of the stream (runs are tens to hundreds of points long: the loop rarely turns more than once)
-__device__ __forceinline__ void cursor_skip(RunCursor& c, const CovRuns& sh, int tid, uint32_t n) {
-    uint32_t left = c.e - c.j;
-    while (n >= left && c.k < (uint32_t)kRuns) {
-        n -= left;
-        c.k += 1u; c.j = c.nx.x; c.e = c.nx.y;
-        c.nx = sh.run[min(c.k + 1u, (uint32_t)kRuns)][tid];
-        left = c.e - c.j;
-    }
-    c.j += n;
+// maximum over the wave as a scalar: quads, halves of rows and rows by DPP (quad_perm, row_half_mirror, row_mirror), the four rows by readlane
+__device__ __forceinline__ uint32_t wave_max_uniform(uint32_t v) {
+    v = max(v, quad_dpp<0xB1>(v)); v = max(v, quad_dpp<0x4E>(v)); v = max(v, quad_dpp<0x141>(v)); v = max(v, quad_dpp<0x140>(v));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
 
 #define COV_CSWAP(a, b) { const bool sw_ = (b) < (a); const unsigned long long lo_ = sw_ ? (b) : (a), hi_ = sw_ ? (a) : (b); (a) = lo_; (b) = hi_; any_sw |= sw_; }
@@ -120,10 +108,6 @@ struct BitonicDesc {      // sorts a[kLo .. kLo + kN), a sequence that rises and
         }
     }
 };
-template <int kCtrl> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kCtrl, 0xf, 0xf, false); }
-template <int kCtrl> __device__ __forceinline__ unsigned long long quad_dpp64(unsigned long long v) {
-    return ((unsigned long long)quad_dpp<kCtrl>((uint32_t)(v >> 32)) << 32) | (unsigned long long)quad_dpp<kCtrl>((uint32_t)v);
-}
 // key[0..kCovK) ascending + key[kCovK] (the smallest key not listed) of this lane and of its partner (kCtrl: quad_perm) -> those of the union
 template <int kCtrl>
 __device__ __forceinline__ void merge_with_partner(uint32_t key[kCovK + 1]) {
@@ -167,7 +151,7 @@ __global__ __launch_bounds__(256, kLpq) void cov_ring1_kernel(GridView g, uint32
     const int cx = (int)fmin(fmax(fx, 0.0), (double)(d0 - 1)), cy = (int)fmin(fmax(fy, 0.0), (double)(d1 - 1)), cz = (int)fmin(fmax(fz, 0.0), (double)(d2 - 1));
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, d0 - 1);
     // Runs in the order they are streamed: the query's OWN cell first, then its two x-neighbours, then the other eight rows -- the own cell
-    // holds most of the answer, so the bound that lets a candidate be skipped is tight after the first few groups.
+    // holds most of the answer, so the bound that lets a candidate be skipped is tight after the first few steps.
     uint32_t ra[kRuns], rb[kRuns];
     {
         const uint32_t row_c = active ? ((uint32_t)cz * (uint32_t)d1 + (uint32_t)cy) * (uint32_t)d0 : 0u;
@@ -182,65 +166,71 @@ __global__ __launch_bounds__(256, kLpq) void cov_ring1_kernel(GridView g, uint32
         const uint32_t row = in ? ((uint32_t)z * (uint32_t)d1 + (uint32_t)y) * (uint32_t)d0 : 0u;
         ra[r + 2] = g.cell_start[in ? row + (uint32_t)x0 : 0u]; rb[r + 2] = g.cell_start[in ? row + (uint32_t)x1 + 1u : 0u];
     }
-    uint32_t n_runs = 0, total = 0;
+    uint32_t total = 0;
 #pragma unroll
-    for (int r = 0; r < kRuns; ++r) {
-        if (rb[r] > ra[r]) { sh.run[n_runs][tid] = make_uint2(ra[r], rb[r]); ++n_runs; total += rb[r] - ra[r]; }
-    }
-#pragma unroll
-    for (int r = 0; r <= kRuns; ++r) if ((uint32_t)r >= n_runs) sh.run[r][tid] = make_uint2(0u, 0u);
+    for (int r = 0; r < kRuns; ++r) { const uint32_t len = rb[r] > ra[r] ? rb[r] - ra[r] : 0u; sh.run[r][tid] = make_uint2(ra[r], len); total += len; }
     // (each lane reads back only what it wrote itself: no barrier)
-    const uint32_t max_total = __builtin_amdgcn_readfirstlane(wave_max_u32(total));
+    const uint32_t max_total = wave_max_uniform(total);
     const uint32_t bits = min(32u - (uint32_t)__clz((int)(max_total | 1u)), (uint32_t)kMaxIdBits);      // wave-uniform: 2^bits > every lane's count, or the cap
     const uint32_t idmask = (1u << bits) - 1u;
     const bool too_many = total > idmask;
-    const uint32_t n_stream = too_many ? 0u : total;
-    // The lanes of a query take the groups of kGroup consecutive candidates in turn (lane p: groups p, p + kLpq, ...), so that all of them
-    // are through the own cell after the same few steps.
-    const uint32_t my_groups = (n_stream + (uint32_t)kGroup - 1u) / (uint32_t)kGroup;
-    const uint32_t groups = __builtin_amdgcn_readfirstlane((wave_max_u32(my_groups) + (uint32_t)kLpq - 1u) / (uint32_t)kLpq);
     uint32_t key[kCovK + 1];      // key[kCovK]: the smallest key that is NOT in the list
 #pragma unroll
     for (int i = 0; i <= kCovK; ++i) key[i] = kKeyEmpty;
-    RunCursor cur;
-    {
-        const uint2 r0 = sh.run[0][tid];
-        cur.k = 0; cur.j = r0.x; cur.e = r0.y; cur.nx = sh.run[1][tid];
-        if (kLpq > 1) cursor_skip(cur, sh, tid, part * (uint32_t)kGroup);
-    }
-    float4 c[kGroup];
-    if (groups) {
-#pragma unroll
-        for (int u = 0; u < kGroup; ++u) {
-            const uint32_t pos = cursor_step(cur, sh, tid);
-            c[u] = g.pts[part * (uint32_t)kGroup + (uint32_t)u < n_stream ? pos : 0u];
+    // The stream is walked by the WAVE, not by its lanes: run after run, a run in steps of kLpq x kGroup positions -- the lanes of a query
+    // take the kGroup-position pieces of a step in turn -- as many steps as the longest run of the wave needs (queries that are neighbours
+    // in cell order have the same or similar runs).  What a lane does per candidate is then an add and a compare; a per-lane cursor over
+    // the runs cost as much as the distance and the key together (measured: 52 instructions per candidate besides the list).
+    struct Step { uint32_t addr0, seq0, nv; };      // first position in the sorted array, its number in the stream, valid positions (0 .. kGroup)
+    int r_cur = -1;                 // wave-uniform iterator: run, step inside it, steps it has
+    uint32_t i_cur = 0, steps_cur = 0;
+    uint2 run_cur = make_uint2(0u, 0u);
+    uint32_t prefix = 0, prefix_next = 0;      // numbers of the stream before the current run / after it
+    auto advance = [&](Step& st) -> bool {
+        ++i_cur;
+        while (i_cur >= steps_cur) {
+            ++r_cur;
+            if (r_cur >= kRuns) return false;
+            run_cur = sh.run[r_cur][tid];
+            prefix = prefix_next; prefix_next += run_cur.y;
+            steps_cur = (wave_max_uniform(too_many ? 0u : run_cur.y) + (uint32_t)(kLpq * kGroup) - 1u) / (uint32_t)(kLpq * kGroup);
+            i_cur = 0;
         }
+        const uint32_t off0 = (i_cur * (uint32_t)kLpq + part) * (uint32_t)kGroup;
+        const uint32_t len = too_many ? 0u : run_cur.y;
+        st.addr0 = run_cur.x + off0; st.seq0 = prefix + off0; st.nv = len > off0 ? len - off0 : 0u;
+        return true;
+    };
+    Step st_next;
+    i_cur = 0; steps_cur = 0;      // (the first advance() enters run 0: ++i_cur makes 1 >= 0)
+    bool have = advance(st_next);
+    float4 nx[kGroup];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) nx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) nx[u] = g.pts[(uint32_t)u < st_next.nv ? st_next.addr0 + (uint32_t)u : 0u];
     }
     uint32_t bound = kKeyEmpty;      // no key >= this can be among the query's twenty (see below)
-    for (uint32_t gi = 0; gi < groups; ++gi) {
-        const uint32_t first = (gi * (uint32_t)kLpq + part) * (uint32_t)kGroup;      // number of this group's first candidate in the stream
-        float4 nx[kGroup];
-        if (gi + 1u < groups) {
-            if (kLpq > 1) cursor_skip(cur, sh, tid, (uint32_t)((kLpq - 1) * kGroup));
+    while (have) {
+        float4 c[kGroup];
 #pragma unroll
-            for (int u = 0; u < kGroup; ++u) {
-                const uint32_t pos = cursor_step(cur, sh, tid);
-                nx[u] = g.pts[first + (uint32_t)(kLpq * kGroup + u) < n_stream ? pos : 0u];
-            }
-        } else {
+        for (int u = 0; u < kGroup; ++u) c[u] = nx[u];
+        const Step st = st_next;
+        have = advance(st_next);
+        if (have) {
 #pragma unroll
-            for (int u = 0; u < kGroup; ++u) nx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < kGroup; ++u) nx[u] = g.pts[(uint32_t)u < st_next.nv ? st_next.addr0 + (uint32_t)u : 0u];
         }
 #pragma unroll
         for (int u = 0; u < kGroup; ++u) {
-            const uint32_t seq = first + (uint32_t)u;
             // a SCREEN (contracted arithmetic, low bits cleared): within 1e-6 relative of FLANN's value, see the proof below
             const float dx = q.x - c[u].x, dy = q.y - c[u].y, dz = q.z - c[u].z;
             float d = dx * dx;
             d = __builtin_fmaf(dy, dy, d);
             d = __builtin_fmaf(dz, dz, d);
-            uint32_t t = (__float_as_uint(d) & ~idmask) | seq;
-            t = seq < n_stream ? t : kKeyEmpty;
+            uint32_t t = (__float_as_uint(d) & ~idmask) | (st.seq0 + (uint32_t)u);
+            t = (uint32_t)u < st.nv ? t : kKeyEmpty;
             if (__any(t < bound)) {      // wave-uniform: some lane lists this candidate
 #pragma unroll
                 for (int k = 0; k < kCovK; ++k) { const uint32_t lo = min(key[k], t), hi = max(key[k], t); key[k] = lo; t = hi; }
@@ -258,8 +248,6 @@ __global__ __launch_bounds__(256, kLpq) void cov_ring1_kernel(GridView g, uint32
             m = max(m, quad_dpp<0xB1>(m)); m = max(m, quad_dpp<0x4E>(m));
             bound = min(bound, m);
         }
-#pragma unroll
-        for (int u = 0; u < kGroup; ++u) c[u] = nx[u];
     }
     // the lists of a query's lanes -> one (every lane of the query then holds it)
     if (kLpq >= 2) merge_with_partner<0xB1>(key);      // quad_perm [1, 0, 3, 2]
@@ -272,7 +260,7 @@ __global__ __launch_bounds__(256, kLpq) void cov_ring1_kernel(GridView g, uint32
         uint32_t P[kRuns], off[kRuns];
         uint32_t acc = 0;
 #pragma unroll
-        for (int t = 0; t < kRuns; ++t) { const uint2 r = sh.run[t][tid]; P[t] = acc; off[t] = r.x - acc; acc += r.y - r.x; }
+        for (int t = 0; t < kRuns; ++t) { const uint2 r = sh.run[t][tid]; P[t] = acc; off[t] = r.x - acc; acc += r.y; }
         unsigned long long mine[kPer];
         uint32_t km[kPer];
 #pragma unroll
@@ -562,7 +550,8 @@ hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, co
     hipError_t e = hipMemsetAsync(sc.count.p, 0, 4, s);
     if (e != hipSuccess) return e;
     // (development builds: PCR_COV_LPQ = lanes per query of the first kernel, PCR_COV_WAVE_BLOCKS = grid of the second)
-    static const int lpq = dev_env("PCR_COV_LPQ") ? atoi(dev_env("PCR_COV_LPQ")) : 4;
+    static const int lpq_small = dev_env("PCR_COV_LPQ") ? atoi(dev_env("PCR_COV_LPQ")) : 4, lpq_big = dev_env("PCR_COV_LPQ_BIG") ? atoi(dev_env("PCR_COV_LPQ_BIG")) : 1;
+    const int lpq = n <= 300000 ? lpq_small : lpq_big;
     static const int wb = dev_env("PCR_COV_WAVE_BLOCKS") ? atoi(dev_env("PCR_COV_WAVE_BLOCKS")) : 2048;
     const uint32_t qblocks = (uint32_t)((n * (size_t)lpq + 255) / 256);
 #define COV_LAUNCH_A(G, L) hipLaunchKernelGGL((cov_ring1_kernel<G, L>), dim3(qblocks), dim3(256), 0, s, grid.view(), (uint32_t)n, sc.nbr.as<uint32_t>(), n_cap, \

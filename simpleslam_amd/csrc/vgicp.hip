@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
                             size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch* scratch) {
     static const bool old_kernel = dev_env("PCR_COV_OLD") != nullptr;      // (development builds: A/B against the lane-per-query kernel)
-    if (scratch && n <= 300000 && n > 0 && !old_kernel) {      // scan-sized: two classes of queries (cov_search.hip)
+    static const bool all_sizes = dev_env("PCR_COV_NEW_ALL") != nullptr;      // (development builds: map-sized clouds through cov_search.hip too)
+    if (scratch && (n <= 300000 || all_sizes) && n > 0 && !old_kernel) {      // scan-sized: two classes of queries (cov_search.hip)
         const hipError_t e = scratch->reserve(n);
         return e != hipSuccess ? e : cov_search_launch(grid, coarse1, coarse2, d_orig, stride_floats, n, d_cov6, s, check, roi, *scratch);
     }
