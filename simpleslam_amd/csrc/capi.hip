@@ -58,6 +58,10 @@ std::mutex g_rccl_mu;
 
 }  // namespace
 
+#ifdef PCR_DEV_SWITCHES
+namespace pcr { int dev_stamps(unsigned long long* out, size_t count); }
+#endif
+
 struct pcr_handle {
     Method method = kLoam;
     pcr_params prm;
@@ -1783,6 +1787,10 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
     H_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
+
+#ifdef PCR_DEV_SWITCHES
+int pcr_dev_read_stamps(unsigned long long* out, size_t count) { return pcr::dev_stamps(out, count); }
+#endif
 
 int pcr_vgicp_neighbours(pcr_handle* h, size_t n, uint32_t* nbr_out, uint32_t* queued_out) {
     if (!h) return 1;

@@ -232,6 +232,23 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict
 // fully coalesced).  Launch A: tile-local exclusive scan -> cell_start, tile total -> block_sums, and the counters
 // are written back as ZERO, which is the state the next build's histogram expects (no separate clear pass).
 // Launch B: every block sums the totals of the tiles before it (a few thousand at most) and adds that offset.
+template <int kThreads>
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* sh /* >= kThreads / 64 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) { const uint32_t x = sh[w]; if (w < wave) off += x; tot += x; }
+    *total = tot;
+    return off + inc - v;
+}
 __device__ inline uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* sh /* >= 4 */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = v;
@@ -348,6 +365,14 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
 // global ones before: nothing downstream may depend on it, and nothing does (searches break distance ties on the
 // original index in .w; voxel statistics are fixed-point sums).
 // ======================================================================================================================
+#ifdef PCR_DEV_SWITCHES
+// development builds: s_memrealtime stamps of the bin and tile kernels ([kernel 0/1][block < 8192][8]), read back by pcr_dev_read_stamps
+__device__ unsigned long long* g_dev_stamps = nullptr;
+#define DEV_STAMP(kernel, slot) do { if (g_dev_stamps && threadIdx.x == 0 && blockIdx.x < 8192) g_dev_stamps[((size_t)(kernel) * 8192 + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define DEV_STAMP(kernel, slot) do { } while (0)
+#endif
+static constexpr uint32_t kHeavyTile = 2048;           // points: tiles at or above go first in the tile kernel (grid_bin_kernel: tile_order)
 static constexpr int kBinStride = 16;                  // counters 64 bytes apart: memory-side atomics on one line serialise
 static constexpr int kBinPerDefault = 8;              // points per thread and chunk of the bin kernel
 
@@ -368,12 +393,16 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start, uint32_t* __restrict__ lay_next,
                                                        const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
-                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift) {
+                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift, uint32_t* __restrict__ tile_order) {
+    // tile_order: the tiles in the order the tile kernel takes them, written by the last block: the heavy ones (>= kHeavyTile points) first --
+    // a tile is one block's work, and a ground tile of a large map holds tens of thousands of points (measured at 10 M points: the tile
+    // kernel's slowest block 151 us of its 168, started 17 us into the kernel)
     // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
     // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;
     uint32_t* const sh_lay = dyn_lds + max_bins;      // kPlace: max_bins + 1 entries
+    DEV_STAMP(0, 0);
     const GridHeader h = *hdr;
     if (h.overflow || h.empty) return;
     const uint32_t nbins_h = (uint32_t)(h.n_cells >> shift) + 1u;
@@ -415,7 +444,9 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
             base = __shfl(base, start, 64);
             loc[u] = base + (uint32_t)(lane - start);
         }
+        DEV_STAMP(0, 1);
         __syncthreads();
+        DEV_STAMP(0, 2);
         // the lane that opened a tile claims room for all the chunk's points of that tile: one global atomic per (chunk, tile)
         uint32_t cnt[kBinPer], got[kBinPer];
 #pragma unroll
@@ -426,6 +457,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) if (first[u]) hist[bin[u]] = got[u];
         __syncthreads();
+        DEV_STAMP(0, 3);
         if (kPlace) {
             bool over = false;
 #pragma unroll
@@ -452,12 +484,14 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     }
     // ---- the last block to finish turns the tile counters (64 bytes apart, written by device-scope atomics) into the compact
     //      exclusive scan the next two kernels read: bin_start[0 .. nbins] ----
+    DEV_STAMP(0, 4);
     __shared__ uint32_t sh_last, sh4[4];
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's claims have been acknowledged (they returned values)
         sh_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
+    DEV_STAMP(0, 5);
     if (!sh_last) return;
     const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
     const uint32_t per = (nbins + 255u) / 256u;      // <= kMaxBins / 256 = 32
@@ -475,6 +509,18 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     for (uint32_t j = 0; j < kMaxBins / 256; ++j)
         if (j < per && b0 + j < nbins) { bin_start[b0 + j] = off; off += c[j]; }
     if (threadIdx.x == 255) bin_start[nbins] = total;
+    {
+        __syncthreads();      // sh4 is reused
+        uint32_t heavy = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kMaxBins / 256; ++j) if (j < per && b0 + j < nbins && c[j] >= kHeavyTile) ++heavy;
+        uint32_t heavy_total;
+        uint32_t ho = block_exclusive_scan_256(heavy, &heavy_total, sh4);
+        uint32_t lo_pos = heavy_total + (min(b0, nbins) - ho);      // light tiles before this thread's = tiles before - heavy tiles before
+#pragma unroll
+        for (uint32_t j = 0; j < kMaxBins / 256; ++j)
+            if (j < per && b0 + j < nbins) { if (c[j] >= kHeavyTile) tile_order[ho++] = b0 + j; else tile_order[lo_pos++] = b0 + j; }
+    }
     // ... and into the layout the NEXT build may place its points by: every tile gets an eighth more room than it holds now
     if (kPlace && keep_mask) {      // (a build of a region: the counts are not the cloud's; the layout it came with stays)
         for (uint32_t b = threadIdx.x; b <= nbins; b += 256) lay_next[b] = lay_cur[b];
@@ -492,6 +538,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         if (j < per && b0 + j < nbins) { lay_next[b0 + j] = lo; lo += c[j] + (c[j] >> 3) + 32u; }
     if (threadIdx.x == 255) lay_next[nbins] = room_total;
     if (threadIdx.x == 0) *ticket = 0u;                        // ready for the next build
+    DEV_STAMP(0, 6);
 }
 
 template <bool kVec>
@@ -543,16 +590,17 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
 // the 0.5 m voxel lattice makes 3 350 tiles of which most hold nothing or a handful of points, they go through the kernel in 6.5 rounds of
 // 512 blocks -- 123 us.  A sparse grid is therefore served by TWO instantiations over the same tiles: kMode 1 takes the tiles of up to 256
 // points with one point per thread (few VGPRs, many blocks in flight), kMode 2 the others with sixteen; kMode 0 = every tile (dense grids).
-template <int kTilePer, int kMode>
+template <int kTilePer, int kMode, int kThreads>
 // src_start: where tile t's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
-__global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
+__global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
                                                         float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
-                                                        const uint32_t* __restrict__ src_start) {
+                                                        const uint32_t* __restrict__ src_start, const uint32_t* __restrict__ tile_order) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;                    // 1 << shift
-    __shared__ uint32_t sh4[4];
-    __shared__ unsigned long long sh_sq[4];
+    __shared__ uint32_t sh4[kThreads / 64];
+    __shared__ unsigned long long sh_sq[kThreads / 64];
+    DEV_STAMP(1, 0);
     const GridHeader h = *hdr_in;
     if (h.overflow || h.empty) return;
     const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
@@ -563,29 +611,30 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
         for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;
         return;
     }
-    for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) {
+    for (uint32_t ti = blockIdx.x; ti < nbins; ti += gridDim.x) {
+        const uint32_t tile = tile_order[ti];
         const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
         const uint32_t q0 = src_start[tile];      // first point of the tile in `tiled`
         const uint64_t cell0 = (uint64_t)tile << shift;
         if (kMode == 1 && np > 256u) continue;          // (block-uniform: the other instantiation's tile)
         if (kMode == 2 && np <= 256u) continue;
-        const bool small = np <= 256u * kTilePer;      // block-uniform
+        const bool small = np <= (uint32_t)kThreads * kTilePer;      // block-uniform
         float4 p[kTilePer];
         uint32_t cr[kTilePer];
         if (small) {
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {      // all loads in flight, issued before anything waits
-                const uint32_t j = u * 256u + threadIdx.x;
-                if (u * 256u < np) p[u] = tiled[q0 + (j < np ? j : 0u)];
+                const uint32_t j = u * (uint32_t)kThreads + threadIdx.x;
+                if (u * (uint32_t)kThreads < np) p[u] = tiled[q0 + (j < np ? j : 0u)];
             }
         }
-        for (uint32_t c = threadIdx.x * 4u; c < S; c += 1024u) *reinterpret_cast<uint4*>(hist + c) = make_uint4(0, 0, 0, 0);
+        for (uint32_t c = threadIdx.x * 4u; c < S; c += 4u * kThreads) *reinterpret_cast<uint4*>(hist + c) = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;      // the counters are left zeroed: the state the next build expects
         __syncthreads();
         if (small) {
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {
-                const uint32_t j = u * 256u + threadIdx.x;
+                const uint32_t j = u * (uint32_t)kThreads + threadIdx.x;
                 cr[u] = 0u;
                 if (j < np) {
                     uint32_t key = 0;
@@ -595,12 +644,12 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
                 }
             }
         } else {
-            for (uint32_t j0 = 0; j0 < np; j0 += 256u * kTilePer) {      // chunks of 4096 points, their loads in flight together
+            for (uint32_t j0 = 0; j0 < np; j0 += (uint32_t)kThreads * kTilePer) {      // chunks of 4096 points, their loads in flight together
 #pragma unroll
-                for (int u = 0; u < kTilePer; ++u) { const uint32_t j = j0 + u * 256u + threadIdx.x; p[u] = tiled[q0 + (j < np ? j : 0u)]; }
+                for (int u = 0; u < kTilePer; ++u) { const uint32_t j = j0 + u * (uint32_t)kThreads + threadIdx.x; p[u] = tiled[q0 + (j < np ? j : 0u)]; }
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) {
-                    const uint32_t j = j0 + u * 256u + threadIdx.x;
+                    const uint32_t j = j0 + u * (uint32_t)kThreads + threadIdx.x;
                     if (j < np) {
                         uint32_t key = 0;
                         point_key(h, p[u].x, p[u].y, p[u].z, &key);
@@ -610,16 +659,17 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
             }
         }
         __syncthreads();
+        if (ti == blockIdx.x) DEV_STAMP(1, 1);
         // exclusive scan of the tile's counters -> cell_start (+ sum of count^2, the density estimate of the header)
         unsigned long long sq = 0;
         uint32_t carry = 0;
-        for (uint32_t cb = 0; cb < S; cb += 1024) {
+        for (uint32_t cb = 0; cb < S; cb += 4u * kThreads) {
             const uint32_t c = cb + threadIdx.x * 4;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (c < S) v = *reinterpret_cast<const uint4*>(hist + c);
             sq += (unsigned long long)v.x * v.x + (unsigned long long)v.y * v.y + (unsigned long long)v.z * v.z + (unsigned long long)v.w * v.w;
             uint32_t tot;
-            const uint32_t o = block_exclusive_scan_256(v.x + v.y + v.z + v.w, &tot, sh4) + carry;
+            const uint32_t o = block_exclusive_scan<kThreads>(v.x + v.y + v.z + v.w, &tot, sh4) + carry;
             __syncthreads();      // sh4 is reused by the next round
             if (c < S) {
                 const uint4 st = make_uint4(o, o + v.x, o + v.x + v.y, o + v.x + v.y + v.z);
@@ -638,24 +688,25 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
         if ((threadIdx.x & 63) == 0) sh_sq[threadIdx.x >> 6] = sq;
         __syncthreads();
         // (one 8-byte store per tile; thousands of blocks adding into one header word serialise at the memory side for ~45 us)
-        if (threadIdx.x == 0) tile_sq[tile] = sh_sq[0] + sh_sq[1] + sh_sq[2] + sh_sq[3];
+        if (threadIdx.x == 0) { unsigned long long t_ = 0; for (int w = 0; w < kThreads / 64; ++w) t_ += sh_sq[w]; tile_sq[tile] = t_; }
+        if (ti == blockIdx.x) DEV_STAMP(1, 2);
         if (small) {
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {
-                const uint32_t j = u * 256u + threadIdx.x;
+                const uint32_t j = u * (uint32_t)kThreads + threadIdx.x;
                 if (j < np) sorted[p0 + hist[cr[u] >> 18] + (cr[u] & 0x3ffffu)] = p[u];
             }
         } else {
-            for (uint32_t j0 = 0; j0 < np; j0 += 256u * kTilePer) {
+            for (uint32_t j0 = 0; j0 < np; j0 += (uint32_t)kThreads * kTilePer) {
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) {
-                    const uint32_t j = j0 + u * 256u + threadIdx.x;
+                    const uint32_t j = j0 + u * (uint32_t)kThreads + threadIdx.x;
                     p[u] = tiled[q0 + (j < np ? j : 0u)];
                     cr[u] = scratch_rank[p0 + (j < np ? j : 0u)];
                 }
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) {
-                    const uint32_t j = j0 + u * 256u + threadIdx.x;
+                    const uint32_t j = j0 + u * (uint32_t)kThreads + threadIdx.x;
                     if (j < np) {
                         uint32_t key = 0;
                         point_key(h, p[u].x, p[u].y, p[u].z, &key);
@@ -665,7 +716,9 @@ __global__ __launch_bounds__(256) void grid_tile_kernel(const GridHeader* __rest
             }
         }
         __syncthreads();
+        if (ti == blockIdx.x) DEV_STAMP(1, 3);
     }
+    DEV_STAMP(1, 4);
 }
 
 // sum of count^2 over the cells = sum of the tiles' sums -> header (only VGICP's choice of a search cell reads it)
@@ -780,7 +833,7 @@ void DeviceBuf::release() {
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
     bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
-    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); layout[0].release(); layout[1].release(); lay_ok = false;
+    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); tile_order.release(); layout[0].release(); layout[1].release(); lay_ok = false;
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -898,6 +951,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
         PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));
+        PCR_TRY(tile_order.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         tiled_shift = tshift;
         if (!bin_count.p) {
             PCR_TRY(bin_count.reserve(((size_t)kMaxBins + 64) * kBinStride * sizeof(uint32_t)));
@@ -933,7 +987,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
 #define PCR_LAUNCH_BIN(VEC, PER, PLACE) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
                                                     bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
-                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
+                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift, tile_order.as<uint32_t>())
         if (use_layout) {
             if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, true); else PCR_LAUNCH_BIN(true, 16, true); }
             else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, true); else PCR_LAUNCH_BIN(false, 16, true); }
@@ -952,15 +1006,20 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         }
         // (a grid with many more cells than points: light tiles and heavy tiles by an instantiation each, see grid_tile_kernel)
         const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
-#define PCR_LAUNCH_TILE(PER, MODE) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE>), dim3(tile_blocks), dim3(256), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
+#define PCR_LAUNCH_TILE(PER, MODE, THREADS) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
                            bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
-                           use_layout ? lay_cur : bin_start.as<uint32_t>())
+                           use_layout ? lay_cur : bin_start.as<uint32_t>(), tile_order.as<uint32_t>())
         // dense grids: eight points per thread (135 VGPRs, three waves per SIMD) while a tile holds ~1 000 points or fewer on average, sixteen
         // beyond (A/B: 1 M points in 1 464 tiles 48.4 -> 46.8 us with eight; 5 M and 10 M points are faster with sixteen)
+        // (blocks of 1 024 threads for the 5 M and 10 M-point maps -- grid_tile_kernel<4, 0, 1024>, PCR_TILE_WIDE in a development build -- cut the
+        //  slowest tile of the 10 M-point map from 165 to 69 us and left the kernel at 165 us: one block per CU then, 19 rounds of ~8 us;
+        //  profiles/r04_notes.md)
         const uint64_t tiles_est = cells_hint ? (cells_hint >> tshift) + 1 : 0;
-        if (sparse) { PCR_LAUNCH_TILE(1, 1); PCR_LAUNCH_TILE(16, 2); }
-        else if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE(8, 0);
-        else PCR_LAUNCH_TILE(16, 0);
+        static const int wide = dev_env("PCR_TILE_WIDE") ? atoi(dev_env("PCR_TILE_WIDE")) : 0;      // (development: average points per tile from which the wide blocks are used; 0 = never)
+        if (sparse) { PCR_LAUNCH_TILE(1, 1, 256); PCR_LAUNCH_TILE(16, 2, 256); }
+        else if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE(8, 0, 256);
+        else if (wide > 0 && tiles_est && n / tiles_est >= (uint64_t)wide) PCR_LAUNCH_TILE(4, 0, 1024);
+        else PCR_LAUNCH_TILE(16, 0, 256);
 #undef PCR_LAUNCH_TILE
         lay_idx ^= 1; lay_ok = true; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
         if (!filtered) lay_n = n;
@@ -984,5 +1043,20 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     valid = true;
     return hipSuccess;
 }
+
+#ifdef PCR_DEV_SWITCHES
+// development builds: arm (allocate + clear) or read the stamp buffer of the bin / tile kernels
+static unsigned long long* g_stamps_host_ptr = nullptr;
+int dev_stamps(unsigned long long* out, size_t count) {
+    const size_t total = (size_t)2 * 8192 * 8;
+    if (!g_stamps_host_ptr) {
+        if (hipMalloc((void**)&g_stamps_host_ptr, total * 8) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dev_stamps), &g_stamps_host_ptr, sizeof(g_stamps_host_ptr)) != hipSuccess) return 1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out && hipMemcpy(out, g_stamps_host_ptr, std::min(count, total) * 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    return hipMemset(g_stamps_host_ptr, 0, total * 8) != hipSuccess;
+}
+#endif
 
 }  // namespace pcr
