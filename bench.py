@@ -269,7 +269,8 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         # one-off per target >= N_m (16 + 20*16 + 128) for the covariances + N_m (16 + 128) for the voxel map
         alg = lambda n_s, n_m: 608 * n_m
         what = "target preparation (index levels + covariance + voxel kernels), 608 B per map point"
-        workload = "pcr=vgicp, 0.5 m voxels, 65536-pt scan vs 1000000-pt submap, target rebuilt per call, inputs in HBM"
+        workload = ("pcr=vgicp, 0.5 m voxels, 65536-pt scan vs 1000000-pt submap, target rebuilt per call (covariances and voxels for the scan's region only; "
+                    "the whole target with --full-target), inputs in HBM")
     else:
         cfg, n_map, kw, mk = 5, 5_000_000, dict(beams=128, azimuths=1024), dict(spacing=0.22)
         reg = NdtRegister(device=local_rank, full_target=int(args.full_target))
@@ -280,7 +281,8 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         cores = host_cores()
         alg = lambda n_s, n_m: 16 * n_m          # voxel build reads every map point once (+104 B per voxel written)
         what = "target preparation (index + voxel Gaussians), 16 B per map point"
-        workload = "pcr=ndt, 1.0 m cells, 131072-pt 128-beam scan vs 5000000-pt submap, target rebuilt per call, inputs in HBM"
+        workload = ("pcr=ndt, 1.0 m cells, 131072-pt 128-beam scan vs 5000000-pt submap, target rebuilt per call (voxel Gaussians for the scan's region only, "
+                    "from a handle's second call on the index holds the region's points only), inputs in HBM")
     world, map_np = synth.make_map(n_map, seed=SEED + cfg, **mk)
     scans, inits = [], []
     for j in range(args.scans):
@@ -330,18 +332,80 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
     # calls so far whose pose left the region the target had been prepared for and were repeated on the whole target (pcr_stats.region_repeats)
     out["region_repeats"] = int(reg.stats().get("region_repeats", 0))
     out["region_index"] = int(reg.stats().get("region_index", 0))      # NDT: the last call indexed only the target points of the scan's region
-    ach = alg(scans[0].shape[0], n_map) / (idx_ms * 1e-3) / 1e9
-    traffic = None      # HBM bytes per scan of the preparation kernels, from the committed --pmc passes (scripts/profile_round.sh)
-    for tag in ("r03",):
-        pj = os.path.join(ROOT, "profiles", f"{tag}_{method}_pmc.json")
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_scan_preparation")
-            except Exception:
-                traffic = None
-    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                       "kernel": what, "target_prep_ms": idx_ms, "align_ms": sol_ms}
-    out["roofline"]["note"] = "target_prep_ms / align_ms come from a separate 8-scan pass with phase events (pcr_set_profile 1)"
+    # ---- rooflines computed from the work DONE: a profiling pass (pcr_set_profile 2) puts events at the kernels' own begin and end and has
+    #      the kernels count what they processed (pcr_stats: region_points / region_voxels, pairs_grad / pairs_hess) ----
+    reg.set_profile(2)
+    prof = {"kernel_ms": 0.0, "aux_kernel_ms": 0.0, "region_points": 0.0, "region_voxels": 0.0, "pairs_grad": 0.0, "pairs_hess": 0.0, "kernel_launches": 0.0, "attempts": 0.0}
+    n_prof = 8
+    for i in range(n_prof):
+        step(i); st = reg.stats()
+        for k in prof:
+            prof[k] += st[k] / n_prof
+    reg.set_profile(0)
+    pmc = {}
+    pj = os.path.join(ROOT, "profiles", f"r04_{method}_pmc.json")
+    if os.path.exists(pj):
+        try:
+            pmc = json.load(open(pj))
+        except Exception:
+            pmc = {}
+    n_s = scans[0].shape[0]
+    if method == "vgicp":
+        # covariance of one point 16 + 20 x 16 + 128 = 464 B, voxel map 16 + 128 = 144 B per point, an index build 32 B per point
+        k_s = prof["kernel_ms"] * 1e-3
+        cov_bytes = 464.0 * prof["region_points"]
+        ach = cov_bytes / k_s / 1e9 if k_s > 0 else 0.0
+        prep_bytes = 2 * 32.0 * n_map + 464.0 * prof["region_points"] + 144.0 * prof["region_points"]
+        scan_bytes = 464.0 * n_s + 2 * 32.0 * n_s
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "vgicp_cov_kernel<false> (the target's covariances inside the scan's region: the critical path of the preparation)",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": cov_bytes, "avg_launch_us": prof["kernel_ms"] * 1e3,
+            "traffic": pmc.get("hbm_bytes_per_launch_cov_target"),
+            "region_points": prof["region_points"], "region_voxels": prof["region_voxels"], "map_points": n_map,
+            "preparation": {"what": "2 index builds x 32 B x map points + (464 + 144) B x region points (covariances + voxel map), over target_prep_ms",
+                            "algorithmic_bytes": prep_bytes, "achieved": prep_bytes / (idx_ms * 1e-3) / 1e9, "frac": prep_bytes / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": pmc.get("hbm_bytes_per_scan_preparation")},
+            "scan_search": {"what": "the scan's own covariances (csrc/cov_search.hip: three kernels on the side stream), 464 B x scan points",
+                            "kernels_us": prof["aux_kernel_ms"] * 1e3, "algorithmic_bytes": 464.0 * n_s,
+                            "achieved": 464.0 * n_s / (prof["aux_kernel_ms"] * 1e-3) / 1e9 if prof["aux_kernel_ms"] > 0 else None,
+                            "frac": 464.0 * n_s / (prof["aux_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if prof["aux_kernel_ms"] > 0 else None},
+            "target_prep_ms": idx_ms, "align_ms": sol_ms}
+    else:
+        # ndt_pass_pro_kernel is bound by arithmetic: flop per (point, voxel) pair counted from ndt.hip: ndt_derivatives_body -- 130 for a pass
+        # that accumulates score + gradient, 425 with the float Hessian -- against the 157.3 TFLOP/s f32 vector peak
+        flop = 130.0 * prof["pairs_grad"] + 425.0 * prof["pairs_hess"]
+        k_s = prof["kernel_ms"] * 1e-3
+        ach = flop / k_s / 1e12 if k_s > 0 else 0.0
+        prep_bytes = alg(n_s, n_map)
+        out["roofline"] = {
+            "bound": "valu_f32", "kernel": "ndt_pass_pro_kernel (computeDerivatives / computeHessian passes of the device-resident Newton + More-Thuente loop)",
+            "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+            "flop_per_pair": {"gradient_pass": 130, "hessian_pass": 425}, "pairs_per_scan": {"gradient_passes": prof["pairs_grad"], "hessian_passes": prof["pairs_hess"]},
+            "launches_per_scan": prof["kernel_launches"], "avg_launch_us": prof["kernel_ms"] * 1e3 / max(1.0, prof["kernel_launches"]), "kernel_us_per_scan": prof["kernel_ms"] * 1e3,
+            "valu_active": pmc.get("valu_active_frac"), "traffic": None,
+            "preparation": {"what": what, "algorithmic_bytes": prep_bytes, "achieved": prep_bytes / (idx_ms * 1e-3) / 1e9, "unit": "GB/s",
+                            "frac": prep_bytes / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_scan_preparation")},
+            "target_prep_ms": idx_ms, "align_ms": sol_ms}
+    out["roofline"]["note"] = ("target_prep_ms / align_ms come from a separate 8-scan pass with phase events (pcr_set_profile 1); kernel durations and the "
+                               "counts of what was processed from another with events at the kernels' own begin and end (pcr_set_profile 2)")
+    # ---- the same scans with nothing carried across calls (pcr_params.index_no_hints = 1): the stateless twin of `value` ----
+    if world_size == 1:
+        cls = VgicpRegister if method == "vgicp" else NdtRegister
+        kw_nh = dict(vgicp_resolution=0.5) if method == "vgicp" else {}
+        reg_nh = cls(device=local_rank, index_no_hints=1, full_target=int(args.full_target), **kw_nh)
+        reg_nh.set_profile(0)
+
+        def step_nh(i):
+            pose = inits[i % args.scans].copy(); reg_nh.scan2Map(d_scans[i % args.scans], d_map, pose)
+        for i in range(5):
+            step_nh(i)
+        n_nh = max(10, steps // 2)
+        w_nh = timed_windows(step_nh, lambda: torch.cuda.synchronize(), n_nh, 3)
+        e_nh = float(np.median(w_nh)) / n_nh
+        out["no_index_hints"] = {"value": 1.0 / e_nh, "unit": "scans/s", "ms_per_step": 1e3 * e_nh,
+                                 "note": "pcr_params.index_no_hints = 1: fresh bounding boxes and build launches on every call, no tile layout, no region-only index; nothing carried across calls"}
+        del reg_nh
     if not args.no_cpu_baseline and world_size == 1:      # the CPU leg is timed at N = 1 only
         def cpu_leg(threads, budget, parity):
             n_done, t_cpu, et, er, nan_both, nan_one = 0, 0.0, [], [], 0, 0
@@ -381,6 +445,62 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def loam_10m(args, local_rank):
+    """BASELINE configs[3] at N = 1 -- pcr=loam, 65 536-pt scan vs a 10 M-point sub-map, 10 iterations, one MI355X, unsharded: the origin of
+    config 4's strong-scaling curve, driver-timed.  The index build dominates there (roofline.kernel)."""
+    import torch
+    import oracle
+    from simpleslam_amd import LoamRegister, synth
+    n_map, n_scans = 10_000_000, 4
+    world, map_np = synth.make_map(n_map, seed=SEED + 4)
+    scans, inits = [], []
+    for j in range(n_scans):
+        sc, T = synth.make_scan(world, j, seed=SEED + 4)
+        scans.append(sc); inits.append(synth.perturb(T, SEED + 4 + j))
+    dev = torch.device("cuda", local_rank)
+    d_map = torch.from_numpy(map_np).to(dev)
+    d_scans = [torch.from_numpy(sc).to(dev) for sc in scans]
+    reg = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0)
+    reg.set_profile(0)
+
+    def step(i):
+        pose = inits[i % n_scans].copy(); reg.scan2Map(d_scans[i % n_scans], d_map, pose)
+        return pose
+    for i in range(6):
+        step(i)
+    steps = max(10, args.extra_steps // 2)
+    wins = timed_windows(step, lambda: torch.cuda.synchronize(), steps, 3)
+    elapsed = float(np.median(wins))
+    reg.set_profile(2)
+    k_ms, k_n, idx_ms = 0.0, 0, 0.0
+    for i in range(8):
+        step(i); st = reg.stats(); k_ms += st["kernel_ms"]; k_n += st["kernel_launches"]; idx_ms += st["index_ms"] / 8
+    reg.set_profile(0)
+    ach = 32.0 * n_map / (idx_ms * 1e-3) / 1e9
+    out = {"metric": "scans/s (pcr=loam, 65 536-pt scan vs 10 M-pt submap, 10 GN iters, BASELINE configs[3] at N = 1)", "value": steps / elapsed, "unit": "scans/s",
+           "n_gpus": 1, "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "windows_ms": [1e3 * w for w in wins], "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"pcr=loam, {N_SCAN}-pt scan vs {n_map}-pt submap, {args.iters} GN iters, early exit off, index rebuilt per call "
+                                  "(previous call's box and tile layout as checked hints), inputs in HBM, one GPU, unsharded", "scans_cycled": n_scans},
+           "roofline": {"bound": "hbm", "kernel": "index build (grid_bin_kernel + grid_tile_kernel: the dominant cost at this map size)",
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_build": 32.0 * n_map,
+                        "index_build_us": 1e3 * idx_ms, "iterate_avg_launch_us": 1e3 * k_ms / max(1, k_n), "traffic": None}}
+    if not args.no_cpu_baseline:
+        cores = host_cores()
+        prm = oracle.loam_params(iters=args.iters, early_exit=0, threads=cores)
+        t_cpu, et, er, n_done = 0.0, [], [], 0
+        while n_done < 2 or (t_cpu < args.cpu_budget_s and n_done < n_scans):
+            c0 = time.perf_counter(); ref, _, _ = oracle.loam_scan2map(scans[n_done], map_np, inits[n_done], prm); t_cpu += time.perf_counter() - c0
+            dt, dr = synth.pose_error(step(n_done), ref)
+            et.append(dt); er.append(dr); n_done += 1
+        out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "scans/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": f"{n_done} of the same scans through the oracle (kd-tree of the 10 M-point map rebuilt per call), {t_cpu:.1f} s wall, OpenMP threads = {cores}"}
+        out["pose_rmse_vs_cpu"] = {"trans_m": float(np.sqrt(np.mean(np.square(et)))), "rot_rad": float(np.sqrt(np.mean(np.square(er)))),
+                                   "max_trans_m": float(max(et)), "max_rot_rad": float(max(er)), "scans": len(et), "tolerance": "1e-4 m / 1e-4 rad"}
+    del reg, d_map, d_scans
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -634,7 +754,59 @@ def main():
                 _pcr.host_unpin(s)
             host["note"] = ("pcr_scan2map with HOST clouds (16-byte points): map + scan cross PCIe on every call; pinned = ranges page-locked by the "
                             "caller with pcr_host_pin.  PCIe-bound: bytes / ~55 GB/s is the floor under the copy")
+            # pcl32: exactly what INTEGRATION.md's adapter hands over -- 32-byte pcl::PointXYZI records (x y z 1 | intensity pad pad pad,
+            # common/types/basic.hpp:16), uploaded verbatim (34 MB per call); `_xyz_only` = pcr_params.host_copy_xyz = 1, a pitched copy of the
+            # first 16 bytes of every record (half the bytes, and several times slower on this runtime: measured, not the default).
+            def xyzi32(a):
+                o = np.zeros((a.shape[0], 8), np.float32)
+                o[:, :3] = a[:, :3]; o[:, 3] = 1.0; o[:, 4] = a[:, 3]
+                return o
+            map32 = xyzi32(map_np)
+            scans32 = [xyzi32(sc) for sc in scans]
+            for name, pin, whole in (("pcl32", False, 0), ("pcl32_pinned", True, 0), ("pcl32_xyz_only", False, 1), ("pcl32_xyz_only_pinned", True, 1)):
+                reg_h = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0, host_copy_xyz=whole)
+                reg_h.set_profile(0)
+                if pin:
+                    _pcr.host_pin(map32)
+                    for sc in scans32:
+                        _pcr.host_pin(sc)
+
+                def step_p(i):
+                    pose = inits[i % args.scans].copy(); reg_h.scan2Map(scans32[i % args.scans], map32, pose)
+                    return pose
+                for i in range(5):
+                    step_p(i)
+                w_h = timed_windows(step_p, lambda: torch.cuda.synchronize(), n_hb, 3)
+                e_h = float(np.median(w_h)) / n_hb
+                p_dev, p_host = step(0), step_p(0)
+                host[name] = {"value": 1.0 / e_h, "unit": "scans/s", "ms_per_step": 1e3 * e_h,
+                              "bytes_crossing_pcie_per_scan": int((map32.shape[0] + scans32[0].shape[0]) * (16 if whole else 32)),
+                              "same_pose_as_device_buffers": bool(np.array_equal(p_dev, p_host))}
+                if pin:
+                    _pcr.host_unpin(map32)
+                    for sc in scans32:
+                        _pcr.host_unpin(sc)
+                del reg_h
             out["host_buffers"] = host
+            # loc_static: test/loc.cpp's flow (map loaded once from a PCD, MapManager.cpp:52-78; every scan localised against it):
+            # pcr_set_target once, pcr_align per scan with a HOST scan of 32-byte records -- only the scan crosses PCIe
+            reg_s = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0)
+            reg_s.set_profile(0)
+            reg_s.setTarget(map32)
+
+            def step_s(i):
+                pose = inits[i % args.scans].copy(); reg_s.align(scans32[i % args.scans], pose)
+                return pose
+            for i in range(10):
+                step_s(i)
+            n_ls = max(20, args.steps // 2)
+            w_s = timed_windows(step_s, lambda: torch.cuda.synchronize(), n_ls, 3)
+            e_s = float(np.median(w_s)) / n_ls
+            out["loc_static"] = {"value": 1.0 / e_s, "unit": "scans/s", "ms_per_step": 1e3 * e_s, "scans": n_ls,
+                                 "same_pose_as_scan2map": bool(np.array_equal(step_s(0), step(0))),
+                                 "note": "pcr_set_target(map) once + pcr_align(host scan, 32-byte records) per scan: the static-map localisation of test/loc.cpp; "
+                                         "only the scan (2 MB) crosses PCIe per call; never reported as value"}
+            del reg_s, map32, scans32
 
         # ---- pose parity + CPU baseline: the oracle (a port of the reference's loop, rebuilt kd-tree per call) on this host's
         #      cores, at 1 thread, at the reference's default `cores` = 4 (config/params.json:5) and at all cores, plus the same
@@ -690,6 +862,10 @@ def main():
                     out["extra"][mth] = secondary(args, method=mth, steps=args.extra_steps, warmup=5, embedded=True)
                 except Exception as e:      # noqa: BLE001 -- the headline line must survive a failure of a secondary one
                     out["extra"][mth] = {"error": repr(e)}
+            try:
+                out["extra"]["loam_10m"] = loam_10m(args, local_rank)
+            except Exception as e:      # noqa: BLE001
+                out["extra"]["loam_10m"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()

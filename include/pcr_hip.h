@@ -89,6 +89,10 @@ typedef struct pcr_params {
     int32_t host_optimiser;    /* 1: NDT, VGICP: drive the optimiser from the host (one round trip per evaluation pass) instead of on the
                                 *    device; the path handles sharded over a host-supplied collective always take.  Same state machines
                                 *    (csrc/ndt_opt.h, csrc/vgicp_opt.h), same result to rounding */
+    int32_t host_copy_xyz;     /* 1: of HOST clouds whose records are wider than 16 bytes (pcl::PointXYZI: 32) only the first 16 bytes of every record are
+                                *    uploaded (a pitched hipMemcpy2DAsync into a staging area of the same stride; registration reads x, y, z and nothing
+                                *    else).  Off by default: measured on MI355X / ROCm 7.2 the pitched copy of a 1 M-point map takes 3.5 ms where the
+                                *    verbatim copy of twice the bytes takes 0.6 ms (profiles/r04_notes.md) */
 } pcr_params;
 
 /* Per-call device timings, from HIP events on the handle's stream. */
@@ -108,6 +112,14 @@ typedef struct pcr_stats {
                              * that were therefore repeated on the whole target (pcr_params.full_target) */
     int32_t region_index;   /* NDT pcr_scan2map: 1 when the last call's target index itself held only the points of the scan's region (possible once
                              * an earlier call of the handle has left its lattice and tile layout as hints), 0 when it held the whole cloud */
+    /* Filled by a call made under pcr_set_profile(h, 2) only (events at the kernels' own begin and end, counters in the kernels): what the
+     * last NDT / VGICP pcr_scan2map really processed, so that a roofline figure can be computed from the work done.
+     *   VGICP: kernel_ms = the target's covariance kernel (vgicp_cov_kernel<false>), aux_kernel_ms = the three kernels of the scan's own
+     *          covariance search (csrc/cov_search.hip), region_points / region_voxels = target points whose covariance was computed / voxels built
+     *   NDT:   kernel_ms / kernel_launches = the evaluation launches of the device loop (ndt_pass_pro_kernel), pairs_grad / pairs_hess =
+     *          (point, voxel) pairs evaluated by the gradient-only passes / by the passes that also accumulate the float Hessian */
+    double aux_kernel_ms;
+    int64_t region_points, region_voxels, pairs_grad, pairs_hess;
 } pcr_stats;
 
 void pcr_default_params(pcr_params* p);

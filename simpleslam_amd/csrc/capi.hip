@@ -166,6 +166,12 @@ struct pcr_handle {
     // timing
     hipEvent_t ev_start = nullptr, ev_index = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_kernel;
+    // profiling passes (pcr_set_profile 2) of NDT / VGICP: counters the kernels add to ([0] target points with a covariance, [16] voxels,
+    // [32] / [48] (point, voxel) pairs of gradient-only / Hessian passes), events of the covariance kernels ([0..1] target, [2..7] scan's search)
+    DeviceBuf prof_count;
+    hipEvent_t ev_cov[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_cov_tgt_used = false, ev_cov_src_used = false;
+    int nd_prof_launches = 0;
     pcr_stats stats;
     double fitness = -1.0;
 };
@@ -180,6 +186,39 @@ namespace {
 int fail(pcr_handle* h, const std::string& msg) { h->err = msg; return 1; }
 
 bool sharded(const pcr_handle* h) { return h->comm != nullptr || h->host_ar != nullptr; }
+
+// profiling passes: the counters cleared (on the handle's stream, ahead of everything the call queues), the covariance events made
+uint32_t* prof_counters(const pcr_handle* h) { return (h->profile >= 2 && h->prof_count.p) ? h->prof_count.as<uint32_t>() : nullptr; }
+int prof_begin(pcr_handle* h) {
+    h->ev_cov_tgt_used = h->ev_cov_src_used = false; h->nd_prof_launches = 0;
+    h->stats.aux_kernel_ms = 0; h->stats.region_points = h->stats.region_voxels = h->stats.pairs_grad = h->stats.pairs_hess = 0;
+    if (h->profile < 2) return 0;
+    H_TRY(h->prof_count.reserve(64 * sizeof(uint32_t)));
+    H_TRY(hipMemsetAsync(h->prof_count.p, 0, 64 * sizeof(uint32_t), h->stream));
+    for (hipEvent_t& e : h->ev_cov) if (!e) H_TRY(hipEventCreate(&e));
+    return 0;
+}
+// ... read back once the call's work has drained
+int prof_end(pcr_handle* h) {
+    if (h->profile < 2 || !h->prof_count.p) return 0;
+    uint32_t c[64];
+    H_TRY(hipStreamSynchronize(h->stream));
+    if (h->side_stream) H_TRY(hipStreamSynchronize(h->side_stream));
+    H_TRY(hipMemcpy(c, h->prof_count.p, sizeof c, hipMemcpyDeviceToHost));
+    h->stats.region_points = c[0]; h->stats.region_voxels = c[16]; h->stats.pairs_grad = c[32]; h->stats.pairs_hess = c[48];
+    float ms = 0;
+    if (h->ev_cov_tgt_used) { H_TRY(hipEventElapsedTime(&ms, h->ev_cov[0], h->ev_cov[1])); h->stats.kernel_ms = ms; h->stats.kernel_launches = 1; }
+    if (h->ev_cov_src_used) {
+        h->stats.aux_kernel_ms = 0;
+        for (int k = 0; k < 3; ++k) { H_TRY(hipEventElapsedTime(&ms, h->ev_cov[2 + 2 * k], h->ev_cov[3 + 2 * k])); h->stats.aux_kernel_ms += ms; }
+    }
+    if (h->nd_prof_launches > 0) {
+        h->stats.kernel_ms = 0;
+        for (int k = 0; k < h->nd_prof_launches; ++k) { H_TRY(hipEventElapsedTime(&ms, h->ev_kernel[2 * k], h->ev_kernel[2 * k + 1])); h->stats.kernel_ms += ms; }
+        h->stats.kernel_launches = h->nd_prof_launches;
+    }
+    return 0;
+}
 
 // Combine n (<= 64) doubles held in host memory over the ranks of a sharded handle, in place: the caller's collective, or RCCL
 // through a device staging buffer.  The stream is idle when this is called (the values were just waited for).
@@ -500,10 +539,19 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
     return fail(h, "target index could not be sized");
 }
 
-int stage_host(pcr_handle* h, DeviceBuf* buf, const void* src, size_t n, size_t stride_bytes, const float** out) {
+// Host clouds are uploaded verbatim.  pcr_params.host_copy_xyz = 1: of records wider than 16 bytes (pcl::PointXYZI is 32: basic.hpp:16 -- what
+// the plugin adapter hands over) only the first 16 bytes cross PCIe, by a pitched copy into a staging area of the SAME stride
+// (nothing downstream changes; whole_records: every field is needed -- pcr_voxel_filter).  Measured and NOT the default: the pitched copy of a
+// 1 M-point map takes 3.5 ms, pageable or page-locked, where the verbatim copy of twice the bytes takes 0.6 ms.
+int stage_host(pcr_handle* h, DeviceBuf* buf, const void* src, size_t n, size_t stride_bytes, const float** out, bool whole_records = false) {
     const size_t bytes = n * stride_bytes;
     H_TRY(buf->reserve(bytes ? bytes : 16));
-    if (bytes) H_TRY(hipMemcpyAsync(buf->p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    if (bytes) {
+        if (stride_bytes > 16 && !whole_records && h->prm.host_copy_xyz == 1)
+            H_TRY(hipMemcpy2DAsync(buf->p, stride_bytes, src, stride_bytes, 16, n, hipMemcpyHostToDevice, h->stream));
+        else
+            H_TRY(hipMemcpyAsync(buf->p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    }
     *out = buf->as<float>();
     return 0;
 }
@@ -722,8 +770,10 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
             h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
     }
     if (e == hipSuccess && (e = vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
-                                                 h->src_cov6.as<double>(), h->side_stream, nullptr, nullptr, &h->src_scratch)) != hipSuccess)
+                                                 h->src_cov6.as<double>(), h->side_stream, nullptr, nullptr, &h->src_scratch,
+                                                 (h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000) ? h->ev_cov + 2 : nullptr)) != hipSuccess)
         h->err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
+    if (e == hipSuccess && h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000) h->ev_cov_src_used = true;
     h->fit_copied_from = nullptr;
     if (e == hipSuccess && !sharded(h) && n_src > 0) {      // the scan, kept for a later pcr_fitness() (off the critical path here)
         const size_t bytes = n_src * stride_floats * sizeof(float);
@@ -791,7 +841,7 @@ int roi_enqueue(pcr_handle* h, const RoiScan& scan, double cell, double base_m, 
                      h->roi_tmp[0].as<uint8_t>(), h->roi_tmp[1].as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream));
     h->roi_idx ^= 1;
     view->lat = h->grid.header.as<GridHeader>(); view->mask = h->roi_mask.as<uint8_t>(); view->escapes = h->roi_esc.as<uint32_t>();
-    view->mshift = ms; view->filtered = 0;
+    view->mshift = ms; view->filtered = 0; view->count = prof_counters(h);
     return 0;
 }
 RoiView roi_view(const pcr_handle* h) {      // the region the handle's target was prepared for (the mask of the LAST roi_enqueue)
@@ -832,7 +882,9 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
             h->roi_on = true;
         }
         H_TRY(vgicp_launch_cov(*cov_grid, cov_levels(n_dst) > 1 ? &h->cov_l1 : nullptr, cov_levels(n_dst) > 2 ? &h->cov_l2 : nullptr, d_dst, stride_floats,
-                               n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr, &h->tgt_scratch));
+                               n_dst, h->tgt_cov6.as<double>(), h->stream, check ? &chk : nullptr, h->roi_on ? &roi : nullptr, &h->tgt_scratch,
+                               (h->profile >= 2 && h->ev_cov[0] && n_dst > 300000) ? h->ev_cov : nullptr));
+        if (h->profile >= 2 && h->ev_cov[0] && n_dst > 300000) h->ev_cov_tgt_used = true;
         H_TRY(vgicp_launch_voxels(h->grid, h->tgt_cov6.as<double>(), h->vox.as<VgicpVoxel>(), h->stream, h->roi_on ? &roi : nullptr));
         return 0;
     };
@@ -1199,6 +1251,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     r.a.use_tile = h->use_tile; r.a.pad_ = 0;
     for (int d = 0; d < 3; ++d) { r.a.tile_lo[d] = h->tile_lo[d]; r.a.tile_hi[d] = h->tile_hi[d]; }
     r.a.roi_escapes = h->roi_on ? h->roi_esc.as<uint32_t>() : nullptr;
+    r.a.pair_count = prof_counters(h);
     {   // Gauss constants (ndt_omp_impl.hpp:86-93)
         const double res = (double)(float)h->prm.ndt_resolution;
         const double c1 = 10 * (1 - h->prm.ndt_outlier_ratio), c2 = h->prm.ndt_outlier_ratio / pow(res, 3);
@@ -1275,6 +1328,11 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         static const bool two_launches = dev_env("PCR_NDT_TWO_LAUNCHES") != nullptr;      // the round's earlier form (pass kernel + fold/controller kernel), for A/B runs
         auto launch = [&](int index) -> hipError_t {
             if (two_launches) return ndt_launch_pass(r.a, d_ctl, h->nd_out_dev, h->stream, seq);
+            if (h->profile >= 2) {      // events at every launch's own begin and end (pcr_stats.kernel_ms)
+                while ((int)h->ev_kernel.size() < 2 * (index + 1)) { hipEvent_t e; hipError_t er = hipEventCreate(&e); if (er != hipSuccess) return er; h->ev_kernel.push_back(e); }
+                h->nd_prof_launches = index + 1;
+                return ndt_launch_pass_pro(r.a, d_ctl, h->nd_partials.as<double>(), h->nd_out_dev, h->stream, seq, index, h->ev_kernel[2 * index], h->ev_kernel[2 * index + 1]);
+            }
             return ndt_launch_pass_pro(r.a, d_ctl, h->nd_partials.as<double>(), h->nd_out_dev, h->stream, seq, index);
         };
         for (; enq < first; ++enq) H_TRY_DRAIN(launch(enq));
@@ -1365,6 +1423,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
     if ((n_src && !src) || (n_dst && !dst)) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     const float *d_src, *d_dst;
+    if (h->method != kLoam && prof_begin(h)) return 1;
     if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_start, h->stream));
     if (on_device) { d_src = (const float*)src; d_dst = (const float*)dst; }
     else {
@@ -1402,6 +1461,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
             H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_end)); h->stats.total_ms = ms;
             H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_index)); h->stats.index_ms = ms;
             H_TRY(hipEventElapsedTime(&ms, h->ev_index, h->ev_end)); h->stats.solve_ms = ms;
+            if (prof_end(h)) return 1;
         }
         return 0;
     }
@@ -1450,6 +1510,7 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
             H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_end)); h->stats.total_ms = ms;
             H_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_index)); h->stats.index_ms = ms;
             H_TRY(hipEventElapsedTime(&ms, h->ev_index, h->ev_end)); h->stats.solve_ms = ms;
+            if (prof_end(h)) return 1;
         }
         return 0;
     }
@@ -1592,6 +1653,21 @@ static int prepare_target_from(pcr_handle* h, const float* d_dst, size_t n_dst, 
     return agree_prepared(h, rc);
 }
 
+// The reference keeps its target after scan2Map (setInputTarget holds the cloud; test/align.cpp aligns and scores against it afterwards).  A
+// pcr_scan2map of an NDT / VGICP handle prepares the target for that scan's region only (RoiView): a later pcr_align, pcr_vgicp_linearize or
+// pcr_ndt_derivatives on the same target finds it prepared IN FULL here -- from this handle's own staging copy when the target came in as a host
+// buffer (the plugin adapter's path).  A device buffer is the caller's and may be gone: that case asks for pcr_set_target / full_target.
+static int ensure_full_target(pcr_handle* h) {
+    if (!h->roi_on) return 0;
+    if (h->tgt_ptr != h->tgt_stage.as<float>() || !h->tgt_n || sharded(h))
+        return fail(h, "no target: pcr_scan2map prepared this device-resident target for that one scan only; call pcr_set_target (or set pcr_params.full_target) "
+                       "for a target that is kept");
+    const uint64_t id = h->map_id, gen = h->map_gen;
+    if (prepare_target_from(h, h->tgt_stage.as<float>(), h->tgt_n, h->tgt_stride * sizeof(float))) return 1;
+    h->map_id = id; h->map_gen = gen;
+    return 0;
+}
+
 int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_bytes, int on_device) {
     if (!h) return 1;
     h->err.clear();
@@ -1600,8 +1676,13 @@ int pcr_set_target(pcr_handle* h, const void* dst, size_t n_dst, size_t stride_b
     // the library copies what it keeps: the index holds its own sorted copy, but a rebuild after a
     // cell-table overflow needs the raw points, so they are staged in HBM either way
     const size_t bytes = n_dst * stride_bytes;
-    H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
-    if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (on_device) {
+        H_TRY(h->tgt_stage.reserve(bytes ? bytes : 16));
+        if (bytes) H_TRY(hipMemcpyAsync(h->tgt_stage.p, dst, bytes, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        const float* staged = nullptr;
+        if (stage_host(h, &h->tgt_stage, dst, n_dst, stride_bytes, &staged)) return 1;
+    }
     return prepare_target_from(h, h->tgt_stage.as<float>(), n_dst, stride_bytes);
 }
 
@@ -1644,7 +1725,7 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     if (n_src && !src) return fail(h, "NULL cloud with nonzero size");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->have_target || !h->grid.valid) return fail(h, "no target: call pcr_set_target first");
-    if (h->roi_on) return fail(h, "no target: pcr_scan2map prepares its target for that one scan only; call pcr_set_target for a target that is kept");
+    if (ensure_full_target(h)) return 1;
     drop_fitness_state(h);
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
@@ -1674,7 +1755,7 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
     if (n == 0) return 0;
     const size_t sf = stride_bytes / 4;
     const float* d_pts = static_cast<const float*>(pts);
-    if (!on_device && stage_host(h, &h->vf_in, pts, n, stride_bytes, &d_pts)) return 1;
+    if (!on_device && stage_host(h, &h->vf_in, pts, n, stride_bytes, &d_pts, true)) return 1;
     GridHeader hdr;
     bool settled = false;
     for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
@@ -1825,7 +1906,7 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
     if (h->method != kVgicp) return fail(h, "pcr_vgicp_linearize needs a vgicp handle");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->vg_target_ready) return fail(h, "no target: call pcr_set_target first");
-    if (h->roi_on) return fail(h, "no target: pcr_scan2map prepares its target for that one scan only; call pcr_set_target for a target that is kept");
+    if (ensure_full_target(h)) return 1;
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     // run the driver's set-up with zero iterations, then one linearisation at the given pose
@@ -1872,7 +1953,7 @@ int pcr_ndt_derivatives(pcr_handle* h, const void* src, size_t n_src, size_t str
     if (h->method != kNdt) return fail(h, "pcr_ndt_derivatives needs an ndt handle");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     if (!h->nd_target_ready) return fail(h, "no target: call pcr_set_target first");
-    if (h->roi_on) return fail(h, "no target: pcr_scan2map prepares its target for that one scan only; call pcr_set_target for a target that is kept");
+    if (ensure_full_target(h)) return 1;
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (!h->out48_host) {

@@ -537,7 +537,7 @@ void CovScratch::release() { nbr.release(); queue.release(); seed.release(); cou
 
 // The three kernels over one cloud (scratch reserved for >= n points by the caller, before anything was queued).
 hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                             size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch& sc) {
+                             size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch& sc, hipEvent_t* ev) {
     const uint32_t blocks = (uint32_t)((n + 255) / 256 ? (n + 255) / 256 : 1);
     const int levels = coarse1 ? (coarse2 ? 3 : 2) : 1;
     CovCheck chk;
@@ -554,16 +554,17 @@ hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, co
     const int lpq = n <= 300000 ? lpq_small : lpq_big;
     static const int wb = dev_env("PCR_COV_WAVE_BLOCKS") ? atoi(dev_env("PCR_COV_WAVE_BLOCKS")) : 2048;
     const uint32_t qblocks = (uint32_t)((n * (size_t)lpq + 255) / 256);
-#define COV_LAUNCH_A(G, L) hipLaunchKernelGGL((cov_ring1_kernel<G, L>), dim3(qblocks), dim3(256), 0, s, grid.view(), (uint32_t)n, sc.nbr.as<uint32_t>(), n_cap, \
-                                              sc.queue.as<uint32_t>(), sc.seed.as<unsigned long long>(), sc.count.as<uint32_t>(), rv)
+    // (ev: events stamped at each kernel's own begin and end -- profiling passes)
+#define COV_LAUNCH_A(G, L) hipExtLaunchKernelGGL((cov_ring1_kernel<G, L>), dim3(qblocks), dim3(256), 0, s, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, 0, grid.view(), (uint32_t)n, \
+                                                 sc.nbr.as<uint32_t>(), n_cap, sc.queue.as<uint32_t>(), sc.seed.as<unsigned long long>(), sc.count.as<uint32_t>(), rv)
     static const int grp = dev_env("PCR_COV_GROUP") ? atoi(dev_env("PCR_COV_GROUP")) : 4;
     if (lpq == 1) COV_LAUNCH_A(8, 1); else if (lpq == 2) { if (grp == 4) COV_LAUNCH_A(4, 2); else COV_LAUNCH_A(8, 2); } else { if (grp == 4) COV_LAUNCH_A(4, 4); else COV_LAUNCH_A(8, 4); }
 #undef COV_LAUNCH_A
     const uint32_t wave_blocks = (uint32_t)std::max(1, wb);
-    hipLaunchKernelGGL(cov_wave_kernel, dim3(wave_blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
+    hipExtLaunchKernelGGL(cov_wave_kernel, dim3(wave_blocks), dim3(256), 0, s, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, 0, grid.view(), coarse1 ? coarse1->view() : grid.view(),
                        coarse2 ? coarse2->view() : grid.view(), levels, sc.queue.as<uint32_t>(), sc.seed.as<unsigned long long>(), sc.count.as<uint32_t>(),
                        n_cap, sc.nbr.as<uint32_t>(), n_cap);
-    hipLaunchKernelGGL(cov_from_nbr_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_orig, (uint32_t)stride_floats, (uint32_t)n, sc.nbr.as<uint32_t>(), n_cap,
+    hipExtLaunchKernelGGL(cov_from_nbr_kernel, dim3(blocks), dim3(256), 0, s, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr, 0, grid.view(), d_orig, (uint32_t)stride_floats, (uint32_t)n, sc.nbr.as<uint32_t>(), n_cap,
                        d_cov6, check ? 1 : 0, chk);
     return hipGetLastError();
 }

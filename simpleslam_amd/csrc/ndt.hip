@@ -465,6 +465,7 @@ __device__ __forceinline__ void ndt_derivatives_body(const NdtArgs& a, const Ndt
             uint32_t slots[7];
             int nn = ndt_neighbours(h, a.vox_slot, tp[0], tp[1], tp[2], slots, a.roi_escapes);
             if (a.use_tile && !ndt_in_tile(a, tp)) nn = 0;       // another rank's query
+            if (a.pair_count && nn > 0) atomicAdd(a.pair_count + (kHessian ? 48 : 32), (uint32_t)nn);      // (profiling passes only)
             if (nn > 0) {
                 // computePointDerivatives (float): :399-440
                 float pg[3][6];
@@ -1079,7 +1080,8 @@ hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipSt
     return hipGetLastError();
 }
 // launch `index` of the one-launch-per-pass loop: d_ctl2 = two NdtCtl, d_rows2 = two buffers of kProRows * 48 doubles
-hipError_t ndt_launch_pass_pro(const NdtArgs& a_in, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index) {
+hipError_t ndt_launch_pass_pro(const NdtArgs& a_in, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index,
+                               hipEvent_t start, hipEvent_t stop) {
     uint32_t nb = (a_in.n_src + kProBlock - 1) / kProBlock;
     nb = nb < 1 ? 1 : (nb > (uint32_t)kProRows ? (uint32_t)kProRows : nb);
     NdtArgs a = a_in;
@@ -1089,7 +1091,9 @@ hipError_t ndt_launch_pass_pro(const NdtArgs& a_in, NdtCtl* d_ctl2, double* d_ro
     pa.ctl_prev = index == 0 ? d_ctl2 : d_ctl2 + ((index + 1) & 1);
     pa.ctl_next = d_ctl2 + (index & 1);
     pa.out = d_out; pa.seq = seq; pa.rows_prev_n = nb; pa.first = index == 0 ? 1 : 0;
-    hipLaunchKernelGGL(ndt_pass_pro_kernel, dim3(nb), dim3(kProBlock), 0, s, a, pa);
+    // (start / stop: events the packet processor stamps at the kernel's own begin and end -- profiling passes)
+    if (start || stop) hipExtLaunchKernelGGL(ndt_pass_pro_kernel, dim3(nb), dim3(kProBlock), 0, s, start, stop, 0, a, pa);
+    else hipLaunchKernelGGL(ndt_pass_pro_kernel, dim3(nb), dim3(kProBlock), 0, s, a, pa);
     return hipGetLastError();
 }
 

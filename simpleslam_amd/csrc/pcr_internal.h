@@ -1,6 +1,7 @@
 // pcr_internal.h -- shared host/device declarations of libpcr_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <functional>
 #include <string>
@@ -251,6 +252,7 @@ struct RoiView {
     uint32_t* escapes;
     int32_t mshift;
     int32_t filtered;            // the index itself holds the region's points only (BuildFilter): NDT then treats EVERY cell outside the mask as unprepared
+    uint32_t* count;             // profiling passes only (pcr_set_profile >= 2), else nullptr: [0] += target points whose covariance was computed, [16] += voxels built
 };
 __host__ __device__ inline uint32_t roi_macro(const GridHeader& h, int mshift, int cx, int cy, int cz) {      // cell (cx, cy, cz) inside the lattice
     const uint32_t m0 = ((uint32_t)h.dims[0] + (1u << mshift) - 1u) >> mshift, m1 = ((uint32_t)h.dims[1] + (1u << mshift) - 1u) >> mshift;
@@ -299,11 +301,13 @@ struct CovScratch {
     hipError_t reserve(size_t n);
     void release();
 };
+// ev (optional, profiling passes): 6 events = begin / end of the three kernels
 hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                             size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch& sc);
+                             size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch& sc, hipEvent_t* ev = nullptr);
 // scratch: scan-sized clouds (n <= 300 000) go through cov_search.hip when given one
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr, const RoiView* roi = nullptr, CovScratch* scratch = nullptr);
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check = nullptr, const RoiView* roi = nullptr, CovScratch* scratch = nullptr,
+                            hipEvent_t* ev = nullptr);
 hipError_t vgicp_launch_voxels(const GridIndex& grid, const double* d_cov6, VgicpVoxel* d_vox, hipStream_t s, const RoiView* roi = nullptr);
 // (seq: written last into d_out32[31] / d_out48[47], host-mapped: the completion word the host spins on)
 hipError_t vgicp_launch_linearize(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
@@ -349,6 +353,7 @@ struct NdtArgs {
     int32_t use_tile, pad_;  // sharded target: only source points whose transformed position lies in [tile_lo, tile_hi)
     double tile_lo[3], tile_hi[3];
     uint32_t* roi_escapes;   // target prepared for one scan (RoiView): count of lookups that hit a voxel it was not prepared for; else NULL
+    uint32_t* pair_count;    // profiling passes only (pcr_set_profile >= 2), else NULL: [32] += (point, voxel) pairs of gradient-only passes, [48] += of passes with a Hessian
 };
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
                              int min_points, double eig_mult, hipStream_t s, const RoiView* roi = nullptr);
@@ -360,7 +365,8 @@ struct NdtOut;
 hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay = 0,
                                uint32_t* d_roi_escapes = nullptr);
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq);
-hipError_t ndt_launch_pass_pro(const NdtArgs& a, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index);
+hipError_t ndt_launch_pass_pro(const NdtArgs& a, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index,
+                               hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums48, hipStream_t s);
 hipError_t ndt_launch_ctl(const NdtArgs& a, NdtCtl* d_ctl, const double* d_sums48, NdtOut* d_out, hipStream_t s, double seq, int batch_mark);
 uint32_t ndt_blocks(uint32_t n_src);

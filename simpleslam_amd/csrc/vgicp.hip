@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, kBatch ? 1 : 4) void vgicp_cov_kernel(GridView
         const float4 q = g.pts[j];
         // a target prepared for one scan: only the points whose voxel the scan can reach (the search itself always sees the whole cloud)
         if (roi.mask && !roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z)) continue;
+        if (roi.count) atomicAdd(roi.count, 1u);      // (profiling passes only)
         KeyList<kCovK> L;
         ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L, kBatch ? sh_rows : nullptr);
         uint32_t nb_idx[kCovK];
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void vgicp_voxel_kernel(GridView g, const doub
         if (!lattice_key(h, (double)q.x, (double)q.y, (double)q.z, &key, c)) continue;
         if (g.cell_start[key] != j) continue;                 // not the first point of its voxel
         if (roi.mask && roi.mask[roi_macro(h, roi.mshift, (int)(c[0] - h.org[0]), (int)(c[1] - h.org[1]), (int)(c[2] - h.org[2]))] == 0) continue;      // out of the scan's reach
+        if (roi.count) atomicAdd(roi.count + 16, 1u);      // (profiling passes only)
         const uint32_t e = g.cell_start[key + 1];
         const double ox = (c[0] + h.shift) * h.cell, oy = (c[1] + h.shift) * h.cell, oz = (c[2] + h.shift) * h.cell;   // lower corner
         const uint32_t cnt = e - j;
@@ -684,12 +686,12 @@ __global__ __launch_bounds__(256) void fitness_kernel(GridView g, const float* _
 
 // ---- host launchers ---------------------------------------------------------------
 hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,
-                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch* scratch) {
+                            size_t n, double* d_cov6, hipStream_t s, const CovCheck* check, const RoiView* roi, CovScratch* scratch, hipEvent_t* ev) {
     static const bool old_kernel = dev_env("PCR_COV_OLD") != nullptr;      // (development builds: A/B against the lane-per-query kernel)
     static const bool all_sizes = dev_env("PCR_COV_NEW_ALL") != nullptr;      // (development builds: map-sized clouds through cov_search.hip too)
     if (scratch && (n <= 300000 || all_sizes) && n > 0 && !old_kernel) {      // scan-sized: two classes of queries (cov_search.hip)
         const hipError_t e = scratch->reserve(n);
-        return e != hipSuccess ? e : cov_search_launch(grid, coarse1, coarse2, d_orig, stride_floats, n, d_cov6, s, check, roi, *scratch);
+        return e != hipSuccess ? e : cov_search_launch(grid, coarse1, coarse2, d_orig, stride_floats, n, d_cov6, s, check, roi, *scratch, ev);
     }
     const int blocks = (int)std::min<size_t>(65535, (n + 255) / 256 ? (n + 255) / 256 : 1);
     const int levels = coarse1 ? (coarse2 ? 3 : 2) : 1;
@@ -699,12 +701,16 @@ hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, con
     RoiView rv;
     memset(&rv, 0, sizeof rv);
     if (roi) rv = *roi;
-    if (n <= 300000)      // scan-sized (the same threshold as the choice of search levels, capi.hip: cov_levels)
-        hipLaunchKernelGGL(vgicp_cov_kernel<true>, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
-                           coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv);
-    else
-        hipLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(blocks), dim3(256), 0, s, grid.view(), coarse1 ? coarse1->view() : grid.view(),
-                           coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv);
+    // (ev: events stamped at the kernel's own begin and end -- profiling passes)
+#define PCR_COV_ARGS grid.view(), coarse1 ? coarse1->view() : grid.view(), coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv
+    if (n <= 300000) {      // scan-sized (the same threshold as the choice of search levels, capi.hip: cov_levels)
+        if (ev) hipExtLaunchKernelGGL(vgicp_cov_kernel<true>, dim3(blocks), dim3(256), 0, s, ev[0], ev[1], 0, PCR_COV_ARGS);
+        else hipLaunchKernelGGL(vgicp_cov_kernel<true>, dim3(blocks), dim3(256), 0, s, PCR_COV_ARGS);
+    } else {
+        if (ev) hipExtLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(blocks), dim3(256), 0, s, ev[0], ev[1], 0, PCR_COV_ARGS);
+        else hipLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(blocks), dim3(256), 0, s, PCR_COV_ARGS);
+    }
+#undef PCR_COV_ARGS
     return hipGetLastError();
 }
 

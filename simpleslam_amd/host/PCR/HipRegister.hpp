@@ -192,12 +192,40 @@ public:
     scalar_t getFitnessScore() override { return pcr_fitness(h_); }
 };
 
+// The static-map adapter: test/loc.cpp loads the global map ONCE (MapManager::MapManager(pcd_file), frontend/src/MapManager.cpp:52-78) and
+// registers every scan against it -- through the unchanged scan2Map(src, dst, res) interface.  Wrapped around any registrar above it
+// indexes `dst` at its first call (pcr_set_target: the map crosses PCIe once) and aligns every later scan against what the device holds
+// (pcr_align: only the scan is uploaded).  The CALLER says when the map's content has changed -- invalidate() -- the adapter never keys
+// anything on the pointer it was handed (a cloud edited in place keeps its address).  Same poses as scan2Map, bit for bit.
+class StaticMapRegister : public PointCloudRegister {
+    std::shared_ptr<HipRegister> reg_;
+    bool have_target_ = false;
+public:
+    explicit StaticMapRegister(std::shared_ptr<HipRegister> reg) : reg_(std::move(reg)) {}
+    void invalidate() { have_target_ = false; }
+    bool scan2Map(const PC_cPtr& src, const PC_cPtr& dst, pose_t& res) override {
+        if (!have_target_) {
+            try { reg_->setTarget(dst); } catch (const std::exception& e) { logError(e.what()); return isConverge = false; }
+            have_target_ = true;
+        }
+        isConverge = reg_->align(src, res);
+        lastError_ = reg_->lastError();
+        return isConverge;
+    }
+    scalar_t getFitnessScore() override { return reg_->getFitnessScore(); }
+    HipRegister& inner() { return *reg_; }
+};
+
 // frontend/src/LidarOdometry.cpp:44-54
 inline PointCloudRegister::Ptr makeRegister(const std::string& pcr_type) {
     if (pcr_type == "loam") return std::make_shared<LoamRegister>();
     if (pcr_type == "ndt") return std::make_shared<NdtRegister>();
     if (pcr_type == "vgicp") return std::make_shared<VgicpRegister>();
     throw std::runtime_error("such pcr type(" + pcr_type + ") is not exist, please implemented your self!");
+}
+// ... the same registrar behind the static-map adapter (localisation against a map that is loaded once)
+inline std::shared_ptr<StaticMapRegister> makeStaticMapRegister(const std::string& pcr_type) {
+    return std::make_shared<StaticMapRegister>(std::dynamic_pointer_cast<HipRegister>(makeRegister(pcr_type)));
 }
 
 }  // namespace PCR

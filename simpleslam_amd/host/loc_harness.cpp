@@ -1,6 +1,6 @@
 // loc_harness.cpp -- ROS-free counterpart of one pass of the reference's test/loc.cpp +
 // LidarOdometry::generateOdom (frontend/src/LidarOdometry.cpp:170-184), reading what test/loc.cpp reads:
-//   loc_harness <params.json> <scan.pcd> <init_pose.txt> [--no-downsample]
+//   loc_harness <params.json> <scan.pcd> <init_pose.txt> [--no-downsample] [--static <more_scans.txt>]
 // params.json is the reference's configuration file (JSON with comments, config/params.hpp:30); the keys used are
 //   "cores"                    -> PointCloudRegister's OpenMP team (PointCloudRegister.hpp:28-32; printed, the GPU has no use for it)
 //   "downSampleVoxelGridSize"  -> leaf of the voxel filter of the map (MapManager.cpp:57,78) and of every scan (LidarOdometry.cpp:33,36,170-171)
@@ -8,6 +8,9 @@
 //   "frontend"."pcr"           -> loam | ndt | vgicp, the factory of LidarOdometry.cpp:32,44-54 (unknown: throws, as there)
 // The scan (what LidarDataProxy would deliver) is a PCD too; init_pose.txt is a 4x4 row-major pose (test/align.cpp:85-93).
 // --no-downsample skips both voxel filters for fixtures that already have the sizes BASELINE config 1 fixes (65 536 x 100 k).
+// --static <list>: the localisation loop of test/loc.cpp -- the map is loaded once, scan after scan is registered against it.  The list holds
+// one line per FURTHER scan, "<scan.pcd> <init_pose.txt>"; every scan (the first included) goes through PCR::StaticMapRegister (the map is
+// indexed at the first call and stays in HBM) AND through a fresh plain registrar's scan2Map: both poses are printed and must be equal.
 // Prints the refined pose (17 significant digits), the converged flag and the elapsed time of scan2Map.
 //
 // Older forms, kept for the raw-float fixtures of the test suite (x y z intensity records):
@@ -19,6 +22,8 @@
 #include <cstdio>
 #include <fstream>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "PCR/HipRegister.hpp"
 #include "config/params.hpp"
@@ -70,6 +75,38 @@ static int run_from_config(int argc, char** argv) {
     const size_t scan_before = scan->size();
     if (downsample) pcp::voxelDownSample(scan, grid_size);                           // LidarOdometry.cpp:170-171
     PCR::pose_t pose = read_pose(argv[3]);
+    for (int i = 4; i + 1 < argc; ++i) {
+        if (std::string(argv[i]) != "--static") continue;
+        // the static-map loop: scans[0] = the one of the command line, the others from the list
+        std::vector<std::pair<PCR::PC_Ptr, PCR::pose_t>> work{{scan, pose}};
+        std::ifstream lf(argv[i + 1]);
+        if (!lf) throw std::runtime_error(std::string("cannot open ") + argv[i + 1]);
+        std::string sf, pf;
+        while (lf >> sf >> pf) {
+            auto sc = std::make_shared<PCR::PointCloud>();
+            if (pcp::loadPCDFile(sf, *sc) == -1) throw std::runtime_error("can't load scan from: " + sf);
+            if (downsample) pcp::voxelDownSample(sc, grid_size);
+            work.push_back({sc, read_pose(pf.c_str())});
+        }
+        auto loc = PCR::makeStaticMapRegister(pcr_type);
+        int differing = 0;
+        double sec_static = 0;
+        std::printf("pcr %s  static map %zu -> %zu  scans %zu\n", pcr_type.c_str(), map_before, map->size(), work.size());
+        for (auto& w : work) {
+            PCR::pose_t a = w.second, b = w.second;
+            const auto t0 = std::chrono::steady_clock::now();
+            const bool ca = loc->scan2Map(w.first, map, a);
+            sec_static += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const bool cb = PCR::makeRegister(pcr_type)->scan2Map(w.first, map, b);
+            bool same = ca == cb;
+            for (int k = 0; k < 16; ++k) same = same && a.m[k] == b.m[k];
+            differing += same ? 0 : 1;
+            std::printf("scan %zu converged %d %d  %s\n", w.first->size(), (int)ca, (int)cb, same ? "same pose" : "POSES DIFFER");
+            for (int r = 0; r < 4; ++r) std::printf("%.17g %.17g %.17g %.17g\n", a(r, 0), a(r, 1), a(r, 2), a(r, 3));
+        }
+        std::printf("static-map registrations %.6f s in all, differing %d\n", sec_static, differing);
+        return differing ? 4 : 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const bool conv = reg->scan2Map(scan, map, pose);                                // LidarOdometry.cpp:184
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -36,6 +36,7 @@ class PcrParams(C.Structure):
         ("record_trace", C.c_int32),
         ("index_no_hints", C.c_int32), ("ndt_evaluate_repeats", C.c_int32), ("loam_disable_cache", C.c_int32), ("record_timeline", C.c_int32),
         ("loam_coresident", C.c_int32), ("loam_clamp_margin_mm", C.c_int32), ("full_target", C.c_int32), ("host_optimiser", C.c_int32),
+        ("host_copy_xyz", C.c_int32),
     ]
 
 
@@ -44,6 +45,7 @@ class PcrStats(C.Structure):
         ("total_ms", C.c_double), ("index_ms", C.c_double), ("solve_ms", C.c_double), ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_int32), ("iterations", C.c_int32), ("n_src", C.c_int64), ("n_dst", C.c_int64),
         ("attempts", C.c_int32), ("target_builds", C.c_int32), ("region_repeats", C.c_int32), ("region_index", C.c_int32),
+                ("aux_kernel_ms", C.c_double), ("region_points", C.c_int64), ("region_voxels", C.c_int64), ("pairs_grad", C.c_int64), ("pairs_hess", C.c_int64),
     ]
 
 

@@ -206,3 +206,40 @@ def test_loc_harness_refuses_an_unknown_pcr_and_a_missing_map(gpu, world_small, 
     loc_inputs.write_params(tmp_path / "p2.json", tmp_path / "nowhere.pcd", pcr="loam")
     bad = subprocess.run([exe, str(tmp_path / "p2.json"), str(tmp_path / "scan.pcd"), str(tmp_path / "init.txt")], capture_output=True, text=True)
     assert bad.returncode == 1 and "can't load globalmap from" in bad.stderr                   # MapManager.cpp:68-73
+
+
+@pytest.mark.parametrize("method", ["loam", "ndt", "vgicp"])
+def test_static_map_adapter_registers_eight_scans_against_one_pcd_map(gpu, world_small, tmp_path, method):
+    """test/loc.cpp's loop: the map is loaded once from a PCD (MapManager.cpp:52-78), scan after scan is localised against it.
+    PCR::StaticMapRegister (host/PCR/HipRegister.hpp) keeps the unchanged scan2Map(src, dst, res) interface, indexes the map at the first
+    call (pcr_set_target) and aligns the others against what the device holds (pcr_align): eight scans, each pose equal -- bit for bit --
+    to a fresh plain registrar's scan2Map and to the Python mirror's."""
+    from simpleslam_amd import make_register, synth
+    from tests import loc_inputs
+    exe = os.path.join(ROOT, "simpleslam_amd", "lib", "loc_harness")
+    w = world_small
+    loc_inputs.write_pcd(tmp_path / "map.pcd", w["map"], "binary_pcl")
+    loc_inputs.write_params(tmp_path / "params.json", tmp_path / "map.pcd", pcr=method, cores=1, grid=0.5)
+    scans, inits = [], []
+    for k in range(8):
+        sc, T = synth.make_scan(w["world"], k % 3, seed=77 + k, beams=16, azimuths=256)
+        scans.append(sc); inits.append(synth.perturb(T, 77 + k, trans=0.15, rot_deg=0.8))
+        loc_inputs.write_pcd(tmp_path / f"scan{k}.pcd", sc, "binary")
+        np.savetxt(tmp_path / f"init{k}.txt", inits[k], fmt="%.17g")
+    with open(tmp_path / "more.txt", "w") as f:
+        for k in range(1, 8):
+            f.write(f"{tmp_path / f'scan{k}.pcd'} {tmp_path / f'init{k}.txt'}\n")
+    out = subprocess.run([exe, str(tmp_path / "params.json"), str(tmp_path / "scan0.pcd"), str(tmp_path / "init0.txt"), "--no-downsample",
+                          "--static", str(tmp_path / "more.txt")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0].startswith(f"pcr {method}  static map") and lines[0].endswith("scans 8"), lines[0]
+    assert lines[-1].endswith("differing 0"), lines[-1]
+    assert sum("same pose" in ln for ln in lines) == 8
+    reg = make_register(method)
+    for k in range(8):
+        rows = lines[2 + 5 * k: 6 + 5 * k]
+        pose_cpp = np.array([[float(x) for x in r.split()] for r in rows])
+        pose_py = inits[k].copy()
+        reg.scan2Map(scans[k], w["map"], pose_py)
+        np.testing.assert_array_equal(pose_cpp, pose_py, err_msg=f"scan {k}")

@@ -87,7 +87,7 @@ def test_the_product_library_reads_no_environment_variable():
     assert r.returncode == 0, r.stderr
     assert "getenv" not in r.stdout
     p = default_params()
-    for f in ("index_no_hints", "ndt_evaluate_repeats", "loam_disable_cache", "record_timeline", "loam_coresident", "loam_clamp_margin_mm", "full_target", "host_optimiser"):
+    for f in ("index_no_hints", "ndt_evaluate_repeats", "loam_disable_cache", "record_timeline", "loam_coresident", "loam_clamp_margin_mm", "full_target", "host_optimiser", "host_copy_xyz"):
         assert getattr(p, f) == 0
     assert not hasattr(p, "reserved")
 

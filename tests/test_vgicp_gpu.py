@@ -337,10 +337,51 @@ def test_target_prepared_for_the_scans_region_only(gpu, vg_world, off):
     rep = reg.stats()["region_repeats"]
     assert full.stats()["region_repeats"] == 0
     assert rep == 0 if off < 1.0 else rep in (0, 1), rep      # 0.25 m stays inside the margin; a start 4 m off may end (or wander) outside it
-    # the handle must not pass a partially prepared target on to pcr_align
-    if rep == 0:
-        with pytest.raises(Exception, match="prepares its target for that one scan only"):
-            reg.align(w["scan"], T0.copy())
+    # The reference keeps its target after scan2Map (setInputTarget persists; test/align.cpp aligns and scores afterwards).  A host target lies in
+    # the handle's staging copy: the next pcr_align finds it prepared in full -- never the partial preparation -- and equals setTarget + align.
+    kept = VgicpRegister(); kept.setTarget(w["map"])
+    pk = T0.copy(); ck = kept.align(w["scan"], pk)
+    pa = T0.copy(); ca = reg.align(w["scan"], pa)
+    assert ca == ck
+    np.testing.assert_array_equal(pa, pk)
+    lin = reg.linearize(w["scan"], w["truth"]); lin_k = kept.linearize(w["scan"], w["truth"])
+    assert lin["n"] == lin_k["n"] and lin["err"] == lin_k["err"]
+
+
+@pytest.mark.parametrize("method", ["vgicp", "ndt"])
+def test_align_after_scan2map_of_a_device_target_says_what_to_do(gpu, vg_world, method):
+    """a DEVICE target is the caller's buffer and may be gone after the call: the region-only preparation is not passed on to pcr_align, the
+    message names the two ways out (pcr_set_target, pcr_params.full_target); with full_target = 1 the same sequence works"""
+    import torch
+    from simpleslam_amd import NdtRegister
+    from simpleslam_amd.pcr import PcrError
+    w = vg_world
+    cls = VgicpRegister if method == "vgicp" else NdtRegister
+    d_scan, d_map = torch.from_numpy(w["scan"]).cuda(), torch.from_numpy(w["map"]).cuda()
+    reg = cls()
+    pose = w["init"].copy(); reg.scan2Map(d_scan, d_map, pose)
+    if reg.stats()["region_repeats"] == 0:
+        with pytest.raises(PcrError, match="pcr_set_target"):
+            reg.align(d_scan, w["init"].copy())
+    full = cls(full_target=1)
+    pose = w["init"].copy(); full.scan2Map(d_scan, d_map, pose)
+    p2 = w["init"].copy(); full.align(d_scan, p2)
+    np.testing.assert_array_equal(p2, pose)
+
+
+def test_ndt_align_after_scan2map_of_a_host_target(gpu, vg_world):
+    """NDT: second call of a handle (region-only INDEX) with host clouds, then pcr_align on the same target = set_target + align"""
+    from simpleslam_amd import NdtRegister
+    w = vg_world
+    reg = NdtRegister()
+    for _ in range(2):
+        pose = w["init"].copy(); reg.scan2Map(w["scan"], w["map"], pose)
+    kept = NdtRegister(); kept.setTarget(w["map"])
+    pk = w["init"].copy(); ck = kept.align(w["scan"], pk)
+    pa = w["init"].copy(); ca = reg.align(w["scan"], pa)
+    assert ca == ck
+    np.testing.assert_array_equal(pa, pk)
+    np.testing.assert_array_equal(pa, pose)
 
 
 def test_gated_fitness_against_a_region_only_index_of_a_device_target_is_refused(gpu, vg_world):
