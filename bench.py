@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; value = the median window")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (vgicp) and configs[4] (ndt) lines embedded as \"extra\"")
     ap.add_argument("--extra-steps", type=int, default=40)
+    ap.add_argument("--secondary-map-points", type=int, default=0, help="--method vgicp|ndt: map size instead of the configuration's (rehearsals and tests)")
     args = ap.parse_args()
     if args.map_points is None:
         args.map_points = 10_000_000 if args.shard_map else 1_000_000
@@ -283,6 +284,8 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         what = "target preparation (index + voxel Gaussians), 16 B per map point"
         workload = ("pcr=ndt, 1.0 m cells, 131072-pt 128-beam scan vs 5000000-pt submap, target rebuilt per call (voxel Gaussians for the scan's region only, "
                     "from a handle's second call on the index holds the region's points only), inputs in HBM")
+    if args.secondary_map_points and not embedded:
+        n_map = int(args.secondary_map_points)
     world, map_np = synth.make_map(n_map, seed=SEED + cfg, **mk)
     scans, inits = [], []
     for j in range(args.scans):
@@ -291,6 +294,39 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         scans.append(s); inits.append(synth.perturb(T, SEED + cfg + k, **pert))
     d_map = torch.from_numpy(map_np).to(dev)
     d_scans = [torch.from_numpy(s).to(dev) for s in scans]
+    d_map_full = d_map
+    scaling = "weak"
+    parallelism = f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"
+    rank_info = {"rank": rank, "device": local_rank, "map_points": int(map_np.shape[0])}
+    sharded = bool(args.shard_map) and not embedded
+    if sharded:
+        # BASELINE configs[4] ("1 -> 8 GPU scaling curve") / configs[2] sharded: the map cut into tiles on the method's voxel lattice, every rank
+        # prepares its tile + halo and handles the scan points that land in it, one all-reduce of the 43 sums per evaluation pass
+        # (reference loops being sharded: ndt_omp_impl.hpp:206-285, fast_vgicp_impl.hpp:135-177)
+        from simpleslam_amd import shard
+        res = 0.5 if method == "vgicp" else 1.0
+        tile = shard.tile_for_method(map_np, rank, world_size, method, resolution=res)
+        d_map = torch.from_numpy(tile.points).to(dev)
+        reg.set_shard(tile.lo, tile.hi, tile.halo)
+        if rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
+            reg.comm_init_host(shard.gloo_collective(), rank, world_size)
+        else:
+            uid = [shard.unique_id() if rank == 0 else None]
+            if world_size > 1:
+                dist.broadcast_object_list(uid, src=0)
+            reg.comm_init(uid[0], rank, world_size)
+        # one scan is split over the tiles: the SAME scans and guesses on every rank (rank 0's)
+        scans, inits = [], []
+        for j in range(args.scans):
+            sc, T = synth.make_scan(world, j, seed=SEED + cfg, **kw)
+            scans.append(sc); inits.append(synth.perturb(T, SEED + cfg + j, **pert))
+        d_scans = [torch.from_numpy(sc).to(dev) for sc in scans]
+        scaling = "strong"
+        ci = reg.comm_info()
+        rccl_ranks = ci["nranks"] if ci["transport"] == "rccl" else 0
+        parallelism = f"map tiles x{world_size} + all-reduce of the 43 sums per evaluation pass over {ci['transport']}"
+        rank_info.update(tile_points=int(tile.points.shape[0]), tile_core_points=int(tile.n_core), tile_axis=int(tile.axis),
+                         tile_lo=float(tile.lo[tile.axis]), tile_hi=float(tile.hi[tile.axis]), halo=float(tile.halo), transport=ci["transport"])
 
     def step(i):
         pose = inits[i % args.scans].copy()
@@ -312,18 +348,53 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wins = [float(v) for v in t.tolist()]
     elapsed = float(np.median(wins))
+    if sharded:
+        # every rank has to take part in every further call (each one is a chain of collectives): the per-rank report and, on rank 0 alone,
+        # the N = 1 origin of the curve (the SAME scans against the WHOLE map, an unsharded handle) while the others wait at a barrier
+        reg.set_profile(1)
+        prep = aln = 0.0
+        for i in range(4):
+            step(i); st = reg.stats(); prep += st["index_ms"] / 4; aln += st["solve_ms"] / 4
+        reg.set_profile(0)
+        rank_info.update(target_prep_ms=prep, align_ms=aln)
+        all_ranks = gather_ranks(dist, world_size, rank_info)
+        n1 = None
+        if world_size > 1:
+            if rank == 0:
+                cls = VgicpRegister if method == "vgicp" else NdtRegister
+                reg1 = cls(device=local_rank, **(dict(vgicp_resolution=0.5) if method == "vgicp" else {}))
+                reg1.set_profile(0)
+
+                def step1(i):
+                    pose = inits[i % args.scans].copy(); reg1.scan2Map(d_scans[i % args.scans], d_map_full, pose)
+                for i in range(5):
+                    step1(i)
+                w1 = timed_windows(step1, lambda: torch.cuda.synchronize(), steps, 3)
+                e1 = float(np.median(w1))
+                n1 = {"value": steps / e1, "unit": "scans/s", "ms_per_step": 1e3 * e1 / steps,
+                      "note": "same scans, whole map, one GPU, unsharded handle (the N = 1 point of this strong-scaling curve)"}
+                del reg1
+            dist.barrier()
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
         return
-    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": steps * world_size / elapsed, "unit": "scans/s",
+    out = {"metric": f"scans/s ({workload.split(',')[0]}, BASELINE configs[{cfg - 1}])", "value": steps * (1 if sharded else world_size) / elapsed, "unit": "scans/s",
            "n_gpus": world_size, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
            "windows_ms": [1e3 * v for v in wins],
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if method == "vgicp" else "f32",
+           "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64" if method == "vgicp" else "f32",
            "data": "synthetic" + (" (REHEARSAL: all ranks on one card)" if rehearse else ""),
-           "config": {"workload": workload, "scans_cycled": args.scans,
-                      "parallelism": f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"},
+           "config": {"workload": workload, "scans_cycled": args.scans, "parallelism": parallelism},
            "rccl_ranks": rccl_ranks, "gpus_arg": args.gpus, "launcher": launcher_name(world_size)}
+    if sharded:
+        out["ranks"] = all_ranks
+        if n1:
+            out["n1"] = n1
+        print(json.dumps(out), flush=True)
+        if world_size > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     reg.set_profile(1)
     idx_ms = sol_ms = 0.0
     for i in range(8):

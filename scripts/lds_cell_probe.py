@@ -93,7 +93,12 @@ def run(mode, dq, nq, blocks=None, reps=200):
 
 
 # every query, the scan's own order (what loam_iterate_kernel sees)
-t_all, _ = run(0, q4(q), q.shape[0])
+t_all, ref_all = run(0, q4(q), q.shape[0])
+# round 4: four / two adjacent lanes per query, lists merged in registers
+t_q4, got4 = run(2, q4(q), q.shape[0])
+t_q2, got2 = run(3, q4(q), q.shape[0])
+assert np.array_equal(got4, ref_all) and np.array_equal(got2, ref_all), "the multi-lane searches disagree with the one-lane stream"
+print(f"one lane per query {t_all:7.2f} us | two lanes per query {t_q2:7.2f} us | four lanes per query {t_q4:7.2f} us   (all {q.shape[0]} queries, scan order, same result words)")
 # the crowded half: scan order, cell order, staged
 qc, kc = q[crowded], kq[crowded]
 t_c, ref = run(0, q4(qc), qc.shape[0])

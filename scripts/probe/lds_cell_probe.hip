@@ -117,6 +117,65 @@ __global__ __launch_bounds__(256) void staged_kernel(const float4* __restrict__ 
     }
 }
 
+// mode 2 / 3 (round 4): kLpq = 4 / 2 ADJACENT lanes per query.  Each lane takes the groups of four consecutive candidates of
+// every run in turn (lane p: candidates 4 (p + kLpq i) .. + 3), keeps its own eight smallest keys; the lists of a query's lanes are merged in
+// registers through DPP (partner's list reversed, min -> the eight smallest of the two as a sequence that rises and falls, sorted by a bitonic
+// merge network of 12 comparators).  Same keys, same result word as stream_kernel (the sum over the eight listed sequence numbers' buckets).
+template <int kCtrl> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kCtrl, 0xf, 0xf, false); }
+template <int kCtrl>
+__device__ __forceinline__ void merge8(uint32_t key[kNb]) {
+    uint32_t c[kNb];
+#pragma unroll
+    for (int i = 0; i < kNb; ++i) c[i] = min(key[i], quad_dpp<kCtrl>(key[kNb - 1 - i]));
+    // c rises and then falls: bitonic merge, descending, then reversed
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int i = 0; i < kNb; ++i) if ((i & d) == 0) { const uint32_t hi = max(c[i], c[i + d]), lo = min(c[i], c[i + d]); c[i] = hi; c[i + d] = lo; }
+    }
+#pragma unroll
+    for (int i = 0; i < kNb; ++i) key[i] = c[kNb - 1 - i];
+}
+
+template <int kLpq>
+__global__ __launch_bounds__(256) void quad_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, const Geo g,
+                                                   const float4* __restrict__ q, uint32_t nq, uint32_t* __restrict__ out) {
+    constexpr int kShift = kLpq == 4 ? 2 : 1;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x, i = t >> kShift, part = t & (kLpq - 1);
+    const bool live = i < nq;
+    const float4 qq = q[live ? i : 0];
+    const int cx = (int)floor(((double)qq.x - g.org[0]) * g.inv_cell), cy = (int)floor(((double)qq.y - g.org[1]) * g.inv_cell),
+              cz = (int)floor(((double)qq.z - g.org[2]) * g.inv_cell);
+    uint32_t ra[9], rb[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t ck = ((uint32_t)(cz + r / 3 - 1) * (uint32_t)g.dims[1] + (uint32_t)(cy + r % 3 - 1)) * (uint32_t)g.dims[0] + (uint32_t)cx;
+        ra[r] = cell_start[ck - 1]; rb[r] = live ? cell_start[ck + 2] : ra[r];
+    }
+    uint32_t key[kNb];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) key[k] = kEmpty;
+    uint32_t seq0 = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        // this lane's groups of the run: the numbering of the candidates (seq) is the one-lane stream's
+        for (uint32_t j = ra[r] + 4u * part; j < rb[r]; j += 4u * kLpq) {
+            float4 c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = pts[j + u < rb[r] ? j + u : j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t tk = j + u < rb[r] ? make_key(qq.x, qq.y, qq.z, c[u], seq0 + (j - ra[r]) + u) : kEmpty; insert8(key, tk); }
+        }
+        seq0 += (rb[r] - ra[r] + 7u) & ~7u;      // (stream_kernel numbers every run in steps of eight)
+    }
+    merge8<0xB1>(key);
+    if (kLpq == 4) merge8<0x4E>(key);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) s += key[k] == kEmpty ? 0u : (key[k] >> 12);
+    if (live && part == 0) out[i] = s;
+}
+
 extern "C" int probe_run(int mode, const void* pts, const void* cell_start, const double org[3], double cell, const int dims[3], const void* q, unsigned nq,
                          const void* blk_first, const void* blk_count, const void* blk_cell, unsigned nblk, void* out, int reps, float* us_per_launch) {
     Geo g;
@@ -125,7 +184,9 @@ extern "C" int probe_run(int mode, const void* pts, const void* cell_start, cons
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
     auto launch = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(stream_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, (const float4*)pts, (const uint32_t*)cell_start, g, (const float4*)q, nq, (uint32_t*)out);
+        if (mode == 2) hipLaunchKernelGGL(quad_kernel<4>, dim3((nq * 4 + 255) / 256), dim3(256), 0, 0, (const float4*)pts, (const uint32_t*)cell_start, g, (const float4*)q, nq, (uint32_t*)out);
+        else if (mode == 3) hipLaunchKernelGGL(quad_kernel<2>, dim3((nq * 2 + 255) / 256), dim3(256), 0, 0, (const float4*)pts, (const uint32_t*)cell_start, g, (const float4*)q, nq, (uint32_t*)out);
+        else if (mode == 0) hipLaunchKernelGGL(stream_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, (const float4*)pts, (const uint32_t*)cell_start, g, (const float4*)q, nq, (uint32_t*)out);
         else hipLaunchKernelGGL(staged_kernel, dim3(nblk), dim3(256), 0, 0, (const float4*)pts, (const uint32_t*)cell_start, g, (const float4*)q, (const uint32_t*)blk_first,
                                 (const uint32_t*)blk_count, (const uint32_t*)blk_cell, (uint32_t*)out);
     };

@@ -100,3 +100,24 @@ def test_two_ranks_rehearsed_on_one_card(shard):
         assert d["ranks"][0]["tile_hi"] == d["ranks"][1]["tile_lo"]
     else:
         assert d["scaling"] == "weak" and "n1" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["ndt", "vgicp"])
+def test_two_ranks_rehearsed_sharded_ndt_and_vgicp(method):
+    """`bench.py --method ndt|vgicp --shard-map --gpus 2` (BASELINE configs[4]'s "1 -> 8 GPU scaling curve", configs[2] sharded), rehearsed
+    on one card: tiles on the method's voxel lattice with its halo, the 43 sums of every evaluation pass all-reduced (gloo here, RCCL
+    between GPUs), the per-rank report and the N = 1 origin of the curve in the line."""
+    env = _clean_env()
+    env["PCR_BENCH_REHEARSE"] = "1"
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--method", method, "--shard-map", "--steps", "4", "--warmup", "2", "--windows", "1", "--scans", "2",
+           "--secondary-map-points", "300000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and d["scaling"] == "strong" and "REHEARSAL" in d["data"]
+    assert d["value"] > 0 and d["n1"]["value"] > 0
+    assert [x["rank"] for x in d["ranks"]] == [0, 1]
+    assert sum(x["tile_core_points"] for x in d["ranks"]) == 300000
+    assert all(x["tile_points"] > x["tile_core_points"] and x["transport"] == "host" and x["halo"] > 0 for x in d["ranks"])
+    assert d["ranks"][0]["tile_hi"] == d["ranks"][1]["tile_lo"]
