@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--scans", type=int, default=8, help="distinct synthetic scans cycled through")
     ap.add_argument("--shard-map", action="store_true", help="shard map tiles across ranks + RCCL all-reduce (config 4)")
+    ap.add_argument("--transport", choices=["rccl", "peer"], default="rccl",
+                    help="--shard-map, loam: the exchange of the 32 sums -- rccl (reduce kernel + ncclAllReduce) or peer (pcr_comm_init_peer: the ranks push into "
+                         "each other's receive buffers mapped with hipIpc, one launch per linearisation; prototype)")
     ap.add_argument("--method", choices=["loam", "vgicp", "ndt"], default="loam",
                     help="loam = the headline line (BASELINE configs[1]); vgicp / ndt = configs[2] / configs[4], extra lines")
     ap.add_argument("--streams", type=int, default=1,
@@ -622,7 +625,14 @@ def main():
         tile = shard.tile_for_method(map_np, rank, world_size, "loam")
         d_map = torch.from_numpy(tile.points).to(dev)
         reg.set_shard(tile.lo, tile.hi, tile.halo)
-        if rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
+        if args.transport == "peer":      # (works in a rehearsal too: two processes may map each other's buffers on one card)
+            handles = [None] * world_size
+            if world_size > 1:
+                dist.all_gather_object(handles, reg.comm_peer_export())
+            else:
+                handles = [reg.comm_peer_export()]
+            reg.comm_init_peer(handles, rank, world_size)
+        elif rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
             reg.comm_init_host(shard.gloo_collective(), rank, world_size)
         else:
             uid = [shard.unique_id() if rank == 0 else None]

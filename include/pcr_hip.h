@@ -332,7 +332,7 @@ int pcr_set_query_tile(pcr_handle* h, const double lo[3], const double hi[3]);
  * caller (e.g. torch.distributed broadcast).  librccl is dlopen'ed here, never before. */
 int pcr_comm_unique_id(void* out128);
 int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks);
-/* Who takes part in this handle's exchange: *transport = 0 none (unsharded), 1 RCCL, 2 the caller's collective.  With RCCL
+/* Who takes part in this handle's exchange: *transport = 0 none (unsharded), 1 RCCL, 2 the caller's collective, 3 the peer exchange.  With RCCL
  * rank and nranks are read back from the communicator (ncclCommUserRank / ncclCommCount), not from the arguments it was
  * created with -- bench.py reports them as "rccl_ranks". */
 int pcr_comm_info(const pcr_handle* h, int* rank, int* nranks, int* transport);
@@ -343,6 +343,15 @@ int pcr_comm_info(const pcr_handle* h, int* rank, int* nranks, int* transport);
  * linearisation: the fallback and test path; RCCL keeps the exchange on the device).  fn == NULL clears it. */
 typedef int (*pcr_allreduce_fn)(double* inout, size_t count, int op, void* user);
 int pcr_comm_init_host(pcr_handle* h, pcr_allreduce_fn fn, void* user, int rank, int nranks);
+/* Peer exchange (PROTOTYPE, loam handles): the ranks' 32 sums without a collective library -- every rank pushes its values into a slot of
+ * every peer's receive buffer (stores over xGMI into memory mapped through hipIpc), waits for its own buffer to fill and folds the slots in
+ * rank order; one small launch per linearisation instead of a reduce kernel + ncclAllReduce (csrc/loam.hip: peer_exchange_block).
+ *   1. every rank: pcr_comm_peer_export(h, handle)  -> 64 bytes (a hipIpcMemHandle_t) naming its receive buffer
+ *   2. the caller shares the handles (any channel: MPI, gloo, a file), in rank order
+ *   3. every rank: pcr_comm_init_peer(h, handles (nranks x 64 bytes), rank, nranks)      (nranks <= 8: one node)
+ * A rank that does not arrive within 2 s fails the exchange on every rank that waited for it (no device hang).  pcr_comm_info: transport 3. */
+int pcr_comm_peer_export(pcr_handle* h, void* ipc_handle64);
+int pcr_comm_init_peer(pcr_handle* h, const void* ipc_handles, int rank, int nranks);
 /* Tile of a sharded target, all three methods: the handle processes the scan points whose transformed position lies in
  * [lo, hi) (as pcr_set_query_tile) and is promised that the target cloud it is given holds EVERY map point inside
  * [lo - halo, hi + halo) (faces at +-1e30 are open).  What the halo must cover:

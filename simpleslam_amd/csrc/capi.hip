@@ -148,6 +148,11 @@ struct pcr_handle {
     bool have_halo = false;          // pcr_set_shard: the target holds every map point inside [tile_lo - halo, tile_hi + halo)
     double halo = 0.0;
     void* comm = nullptr;            // RCCL communicator (pcr_comm_init)
+    // peer exchange (pcr_comm_init_peer): this rank's receive buffer (fine-grained HBM, exported over IPC), every rank's as mapped here
+    double* peer_own = nullptr;
+    bool peer_on = false;
+    PeerComm peer{};
+    double peer_seq = 0.0;
     pcr_allreduce_fn host_ar = nullptr;     // or the caller's collective (pcr_comm_init_host)
     void* host_ar_user = nullptr;
     int nranks = 1, rank = 0;
@@ -185,7 +190,7 @@ namespace {
 
 int fail(pcr_handle* h, const std::string& msg) { h->err = msg; return 1; }
 
-bool sharded(const pcr_handle* h) { return h->comm != nullptr || h->host_ar != nullptr; }
+bool sharded(const pcr_handle* h) { return h->comm != nullptr || h->host_ar != nullptr || h->peer_on; }
 
 // profiling passes: the counters cleared (on the handle's stream, ahead of everything the call queues), the covariance events made
 uint32_t* prof_counters(const pcr_handle* h) { return (h->profile >= 2 && h->prof_count.p) ? h->prof_count.as<uint32_t>() : nullptr; }
@@ -226,6 +231,16 @@ int ranks_allreduce(pcr_handle* h, double* v, int n, int op = 0) {
     if (h->host_ar) {
         const int rc = h->host_ar(v, (size_t)n, op, h->host_ar_user);
         if (rc != 0) return fail(h, "the caller's all-reduce failed with code " + std::to_string(rc));
+        return 0;
+    }
+    if (h->peer_on) {
+        H_TRY(h->ar_stage.reserve(64 * sizeof(double)));
+        H_TRY(hipMemcpyAsync(h->ar_stage.p, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->peer_seq += 1.0;
+        H_TRY(peer_launch_allreduce(h->ar_stage.as<double>(), n, op, h->peer, h->peer_seq, h->stream));
+        H_TRY(hipMemcpyAsync(v, h->ar_stage.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < n; ++i) if (v[i] != v[i]) return fail(h, "peer exchange: a rank did not arrive within 2 s");
         return 0;
     }
     if (h->comm) {
@@ -462,6 +477,10 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
                 H_TRY(loam_launch_reduce(a, k, h->red_dev, h->stream));
                 H_TRY(hipStreamSynchronize(h->stream));
                 if (ranks_allreduce(h, h->red_host, kAccum)) return 1;
+            } else if (h->peer_on) {
+                // fold + push to every peer + fold what arrived, one launch (the sums never leave the device)
+                h->peer_seq += 1.0;
+                H_TRY(loam_launch_peer_exchange(a, k, h->peer, h->peer_seq, h->loam_reduced.as<double>(), h->stream));
             } else if (h->comm) {
                 H_TRY(loam_launch_reduce(a, k, h->loam_reduced.as<double>(), h->stream));
                 int rc = g_rccl.allreduce(h->loam_reduced.p, h->loam_reduced.p, kAccum, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
@@ -1593,6 +1612,10 @@ void pcr_destroy(pcr_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
+    if (h->peer_on) { for (int p = 0; p < h->peer.nranks; ++p) if (p != h->peer.rank && h->peer.buf[p]) (void)hipIpcCloseMemHandle(h->peer.buf[p]); }
+    if (h->peer_own) (void)hipFree(h->peer_own);
+    h->prof_count.release();
+    for (hipEvent_t e : h->ev_cov) if (e) (void)hipEventDestroy(e);
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release(); h->src_scratch.release(); h->tgt_scratch.release();
@@ -2315,9 +2338,56 @@ int pcr_comm_info(const pcr_handle* h, int* rank, int* nranks, int* transport) {
         if (g_rccl.comm_count && g_rccl.comm_count(h->comm, &n) != 0) return 1;
         if (g_rccl.comm_user_rank && g_rccl.comm_user_rank(h->comm, &r) != 0) return 1;
     } else if (h->host_ar) t = 2;
+    else if (h->peer_on) t = 3;
     if (rank) *rank = r;
     if (nranks) *nranks = n;
     if (transport) *transport = t;
+    return 0;
+}
+
+int pcr_comm_peer_export(pcr_handle* h, void* ipc_handle64) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!ipc_handle64) return fail(h, "ipc_handle64 is NULL");
+    if (set_device(h)) return 1;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI says 64 bytes");
+    const size_t bytes = (size_t)2 * kMaxPeers * kPeerSlot * sizeof(double);
+    if (!h->peer_own) {
+        // fine-grained: the peers' stores and this rank's polls meet in memory, not in a cache that nobody invalidates inside a kernel
+        if (hipExtMallocWithFlags((void**)&h->peer_own, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            H_TRY(hipMalloc((void**)&h->peer_own, bytes));
+        }
+        H_TRY(hipMemset(h->peer_own, 0, bytes));
+        H_TRY(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t mh;
+    H_TRY(hipIpcGetMemHandle(&mh, h->peer_own));
+    memcpy(ipc_handle64, &mh, 64);
+    return 0;
+}
+
+int pcr_comm_init_peer(pcr_handle* h, const void* ipc_handles, int rank, int nranks) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!ipc_handles || nranks < 1 || nranks > kMaxPeers || rank < 0 || rank >= nranks) return fail(h, "bad peer-exchange arguments (at most 8 ranks)");
+    if (h->method != kLoam) return fail(h, "the peer exchange is a prototype for loam handles (ndt / vgicp: pcr_comm_init or pcr_comm_init_host)");
+    if (!h->peer_own) return fail(h, "call pcr_comm_peer_export first (every rank), then share the handles");
+    if (set_device(h)) return 1;
+    memset(&h->peer, 0, sizeof h->peer);
+    for (int p = 0; p < nranks; ++p) {
+        if (p == rank) { h->peer.buf[p] = h->peer_own; continue; }
+        hipIpcMemHandle_t mh;
+        memcpy(&mh, (const char*)ipc_handles + (size_t)p * 64, 64);
+        void* mapped = nullptr;
+        H_TRY(hipIpcOpenMemHandle(&mapped, mh, hipIpcMemLazyEnablePeerAccess));
+        h->peer.buf[p] = (double*)mapped;
+    }
+    h->peer.rank = rank; h->peer.nranks = nranks;
+    h->rank = rank; h->nranks = nranks;
+    h->peer_seq = 0.0;
+    h->peer_on = true;
+    h->comm = nullptr; h->host_ar = nullptr;
     return 0;
 }
 

@@ -1215,6 +1215,100 @@ __global__ __launch_bounds__(256) void loam_reduce_kernel(const LoamArgs a, cons
     }
 }
 
+// ------------------------------------------------------------------------------
+// Peer exchange (prototype, pcr_comm_init_peer): the ranks' sums without a collective library.  Every rank owns a RECEIVE buffer in its HBM
+// (fine-grained, exported by hipIpcGetMemHandle and mapped by every peer): [2 parities][kMaxPeers writers][kPeerSlot doubles], word
+// kPeerFlag of a slot = the sequence number of what the slot holds.  An exchange: write my values into MY slot of EVERY peer's buffer
+// (stores that go out over xGMI), release to system scope, write the sequence number behind them; wait until every writer's slot of my OWN
+// buffer carries this exchange's number (local polls), acquire, fold the slots IN RANK ORDER (so every rank gets the same bits).  Two parities:
+// a rank can be at most one exchange ahead of the slowest (it needs that rank's contribution to go on), so the slot it overwrites has been read.
+// The wait is bounded (kPeerTimeoutTicks of the 100 MHz clock): a peer that never arrives makes the exchange FAIL, it does not hang the device.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ bool peer_exchange_block(const PeerComm& pc, double seq, const double* vals /* LDS or regs by thread t < n */, double v_mine, int n, int op,
+                                                    double* __restrict__ out) {
+    const int t = threadIdx.x;
+    const int par = (int)((unsigned long long)seq & 1ull);
+    __shared__ int sh_ok;
+    if (t == 0) sh_ok = 1;
+    // my values into my slot of every peer's buffer
+    if (t < n) {
+        for (int p = 0; p < pc.nranks; ++p) {
+            double* slot = pc.buf[p] + ((size_t)par * kMaxPeers + (size_t)pc.rank) * kPeerSlot;
+            __hip_atomic_store(slot + t, v_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // Every store above is a system-scope store (write-through past every cache) and so is every load below: once this wave's stores have
+    // been acknowledged they are where the peers will read them, and the sequence word may follow.  (A release FENCE here would write back
+    // the whole L2 -- the iterate kernel has just left 12 MB of cache entries in it: measured, the exchange then cost more than
+    // reduce + ncclAllReduce.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t < pc.nranks) {
+        double* slot = pc.buf[t] + ((size_t)par * kMaxPeers + (size_t)pc.rank) * kPeerSlot;
+        __hip_atomic_store(slot + kPeerFlag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // every writer's slot of MY buffer
+    if (t < pc.nranks) {
+        const double* flag = pc.buf[pc.rank] + ((size_t)par * kMaxPeers + (size_t)t) * kPeerSlot + kPeerFlag;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (wall_clock64() - t0 > kPeerTimeoutTicks) { sh_ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool ok = sh_ok != 0;
+    if (t < n) {
+        double acc = op == 1 ? -1e308 : 0.0;
+        for (int r = 0; r < pc.nranks; ++r) {
+            const double* slot = pc.buf[pc.rank] + ((size_t)par * kMaxPeers + (size_t)r) * kPeerSlot;
+            const double x = __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            acc = op == 1 ? fmax(acc, x) : acc + x;
+        }
+        out[t] = ok ? acc : __longlong_as_double(0x7ff8000000000000ll);      // (a peer never arrived: NaN, the caller fails the call)
+    }
+    (void)vals;
+    return ok;
+}
+
+// the fold of this rank's partial sums (loam_reduce_kernel) + the exchange, one launch per linearisation
+__global__ __launch_bounds__(256) void loam_peer_exchange_kernel(const LoamArgs a, const int k, const PeerComm pc, const double seq, double* __restrict__ out) {
+    __shared__ double sh_sum[8 * 32];
+    const int t = threadIdx.x, comp = t & 31, slice = t >> 5;
+    const LoamState* st = &a.state[k & 1];
+    double acc = 0.0;
+    if (!st->done) {
+        const double* part = a.partials + (size_t)(k & 1) * kMaxPartials * kAccum;
+        for (uint32_t b = slice; b < a.n_partials; b += 8) acc += part[(size_t)b * kAccum + comp];
+    }
+    sh_sum[slice * 32 + comp] = acc;
+    __syncthreads();
+    double v = 0.0;
+    if (t < 32) {
+        v = sh_sum[t];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) v += sh_sum[s * 32 + t];
+        if (t == kSlotRankFail) v = (a.rank_fail || a.grid.hdr->overflow) ? 1.0 : 0.0;
+    }
+    const bool ok = peer_exchange_block(pc, seq, nullptr, v, kAccum, 0, out);
+    if (!ok && t == kSlotRankFail) out[t] = 1.0;      // every rank that timed out stops its loop (fail = 2); the sums are not used then
+}
+// n <= 64 doubles of a device buffer, in place (op 0 = sum, 1 = max): the agreement exchanges around the loops
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(double* __restrict__ inout, const int n, const int op, const PeerComm pc, const double seq) {
+    const int t = threadIdx.x;
+    const double v = t < n ? inout[t] : 0.0;
+    peer_exchange_block(pc, seq, nullptr, v, n, op, inout);
+}
+hipError_t loam_launch_peer_exchange(const LoamArgs& a, int k, const PeerComm& pc, double seq, double* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(loam_peer_exchange_kernel, dim3(1), dim3(256), 0, s, a, k, pc, seq, d_out);
+    return hipGetLastError();
+}
+hipError_t peer_launch_allreduce(double* d_inout, int n, int op, const PeerComm& pc, double seq, hipStream_t s) {
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, s, d_inout, n, op, pc, seq);
+    return hipGetLastError();
+}
+
 uint32_t loam_grid_blocks(uint32_t n_src) {
     uint32_t b = (n_src + 255) / 256;
     if (b < 1) b = 1;

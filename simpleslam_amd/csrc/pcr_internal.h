@@ -371,6 +371,14 @@ hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums4
 hipError_t ndt_launch_ctl(const NdtArgs& a, NdtCtl* d_ctl, const double* d_sums48, NdtOut* d_out, hipStream_t s, double seq, int batch_mark);
 uint32_t ndt_blocks(uint32_t n_src);
 
+// peer exchange (loam.hip): receive buffers of all ranks as THIS process maps them
+static constexpr int kMaxPeers = 8;
+static constexpr int kPeerSlot = 72;                       // doubles per (parity, writer) slot: 64 values + the sequence word + padding
+static constexpr int kPeerFlag = 64;
+static constexpr unsigned long long kPeerTimeoutTicks = 200000000ull;      // 2 s of the 100 MHz clock
+struct PeerComm { double* buf[kMaxPeers]; int32_t rank, nranks; };
+hipError_t loam_launch_peer_exchange(const LoamArgs& a, int k, const PeerComm& pc, double seq, double* d_out, hipStream_t s);
+hipError_t peer_launch_allreduce(double* d_inout, int n, int op, const PeerComm& pc, double seq, hipStream_t s);
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s);
 hipError_t loam_launch_reduce(const LoamArgs& a, int k, double* d_out, hipStream_t s);

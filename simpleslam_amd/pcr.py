@@ -53,7 +53,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device", "pcr_host_pin", "pcr_host_unpin",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
-    "pcr_vgicp_covariances", "pcr_vgicp_neighbours", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info",
+    "pcr_vgicp_covariances", "pcr_vgicp_neighbours", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info", "pcr_comm_peer_export", "pcr_comm_init_peer",
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices", "pcr_map_generation", "pcr_scan2map_submap",
@@ -143,6 +143,8 @@ def load_library():
     L.pcr_set_query_tile.argtypes = [vp, dp, dp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.pcr_comm_peer_export.argtypes = [vp, vp]
+    L.pcr_comm_init_peer.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.pcr_comm_init_host.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int, C.c_int]
     L.pcr_comm_info.argtypes = [vp, ip, ip, ip]
     L.pcr_set_shard.argtypes = [vp, dp, dp, C.c_double]
@@ -364,7 +366,19 @@ class PointCloudRegister:
         """pcr_comm_info -> dict(rank, nranks, transport): who takes part in this handle's exchange, as the communicator reports it."""
         r, n, t = C.c_int(0), C.c_int(1), C.c_int(0)
         self._check(self._lib.pcr_comm_info(self._h, C.byref(r), C.byref(n), C.byref(t)))
-        return dict(rank=r.value, nranks=n.value, transport={0: "none", 1: "rccl", 2: "host"}[t.value])
+        return dict(rank=r.value, nranks=n.value, transport={0: "none", 1: "rccl", 2: "host", 3: "peer"}[t.value])
+
+    def comm_peer_export(self):
+        """64 bytes naming this rank's receive buffer of the peer exchange (pcr_comm_peer_export): share them in rank order, then comm_init_peer"""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.pcr_comm_peer_export(self._h, buf))
+        return bytes(buf.raw)
+
+    def comm_init_peer(self, handles, rank, nranks):
+        """pcr_comm_init_peer: `handles` = every rank's comm_peer_export(), in rank order"""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * nranks
+        self._check(self._lib.pcr_comm_init_peer(self._h, blob, rank, nranks))
 
     def comm_init_host(self, fn, rank, nranks):
         """The exchange of a sharded call through the caller's collective (pcr_comm_init_host): fn(ptr, count, op, user) -> 0,

@@ -357,3 +357,100 @@ def test_rccl_transport_with_a_one_rank_communicator(gpu, nd_w, vg_w, method):
         for _ in range(5):                                         # batches enqueued beyond the end must not leak into the next call
             pc = w["init"].copy(); dev.scan2Map(w["scan"], w["map"], pc)
             np.testing.assert_array_equal(pc, first)
+
+
+def _peer_worker(rank, world_size, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world, m = synth.make_map(300_000, seed=S + 9)
+    scan, T = synth.make_scan(world, 0, seed=S + 9)
+    init = synth.perturb(T, S + 9)
+    tile = shard.tile_for_method(m, rank, world_size, "loam")
+    reg = make_register("loam", loam_iters=10, loam_early_exit=0)
+    reg.set_shard(tile.lo, tile.hi, tile.halo)
+    handles = [None] * world_size
+    dist.all_gather_object(handles, reg.comm_peer_export())
+    reg.comm_init_peer(handles, rank, world_size)
+    info = reg.comm_info()
+    d_scan, d_tile = torch.from_numpy(scan).cuda(), torch.from_numpy(tile.points).cuda()
+    poses = []
+    for _ in range(3):      # (several calls: the sequence numbers and the two parities of the slots keep working)
+        pose = init.copy()
+        conv = reg.scan2Map(d_scan, d_tile, pose)
+        poses.append(pose)
+    import time
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        pose = init.copy(); reg.scan2Map(d_scan, d_tile, pose)
+    dt = (time.perf_counter() - t0) / 20
+    q.put((rank, dict(poses=poses, conv=conv, info=info, ms=dt * 1e3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_between_two_processes_on_one_card(gpu):
+    """pcr_comm_init_peer (prototype): the sums of a sharded LOAM call cross the ranks through receive buffers mapped with hipIpc -- every rank
+    pushes its 32 doubles into its slot of every peer's buffer and folds what arrived in rank order, one launch per linearisation, no
+    collective library.  Two processes share the one card here (between GPUs the same stores go out over xGMI): both ranks' poses bitwise
+    equal, equal to the unsharded pose to rounding, over several calls."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 777) % 2000)
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    world, m = synth.make_map(300_000, seed=S + 9)
+    scan, T = synth.make_scan(world, 0, seed=S + 9)
+    init = synth.perturb(T, S + 9)
+    ref = init.copy()
+    c = make_register("loam", loam_iters=10, loam_early_exit=0).scan2Map(scan, m, ref)
+    assert got[0]["info"]["transport"] == "peer" and got[0]["info"]["nranks"] == 2 and got[1]["info"]["rank"] == 1
+    for k in range(3):
+        np.testing.assert_array_equal(got[0]["poses"][k], got[1]["poses"][k])
+        np.testing.assert_array_equal(got[0]["poses"][k], got[0]["poses"][0])
+    assert got[0]["conv"] == c
+    dt, dr = synth.pose_error(got[0]["poses"][0], ref)
+    assert dt <= 1e-12 and dr <= 1e-12, (dt, dr)
+    print(f"peer exchange, 2 ranks on one card: {got[0]['ms']:.3f} / {got[1]['ms']:.3f} ms per sharded scan2map")
+
+
+def test_peer_exchange_with_one_rank_runs_the_whole_protocol(gpu):
+    """one rank pushing to itself runs the whole protocol (system-scope stores, sequence word, poll, fold): same pose as the unsharded handle
+    bit for bit; the per-iteration price of the exchange is printed next to RCCL's one-rank figure (measured on MI355X: 14.4 us against 13.1 us
+    -- three dependent trips to fine-grained memory inside one launch cost what RCCL's two launches cost; what the push buys is that its
+    length does not grow with the number of ranks)"""
+    import time
+    import torch
+    world, m = synth.make_map(300_000, seed=S + 9)
+    scan, T = synth.make_scan(world, 0, seed=S + 9)
+    init = synth.perturb(T, S + 9)
+    d_scan, d_map = torch.from_numpy(scan).cuda(), torch.from_numpy(m).cuda()
+    def timed(reg):
+        for _ in range(5):
+            p = init.copy(); reg.scan2Map(d_scan, d_map, p)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(40):
+            p = init.copy(); reg.scan2Map(d_scan, d_map, p)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 40, p
+    plain = make_register("loam", loam_iters=10, loam_early_exit=0)
+    t_plain, p_plain = timed(plain)
+    peer = make_register("loam", loam_iters=10, loam_early_exit=0)
+    peer.comm_init_peer([peer.comm_peer_export()], 0, 1)
+    t_peer, p_peer = timed(peer)
+    rccl = make_register("loam", loam_iters=10, loam_early_exit=0)
+    rccl.comm_init(shard.unique_id(), 0, 1)
+    t_rccl, p_rccl = timed(rccl)
+    np.testing.assert_array_equal(p_peer, p_plain)
+    np.testing.assert_array_equal(p_rccl, p_plain)
+    print(f"per iteration over the unsharded call: peer exchange {(t_peer - t_plain) * 1e5:.2f} us, reduce + ncclAllReduce {(t_rccl - t_plain) * 1e5:.2f} us")
+    assert t_peer < 2.0 * t_rccl, (t_plain, t_peer, t_rccl)
