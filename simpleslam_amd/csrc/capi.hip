@@ -165,6 +165,7 @@ struct pcr_handle {
     // region of interest of a target prepared for one scan (RoiView): two marking buffers used alternately, the dilated mask, the escape counter
     DeviceBuf roi_mark[2], roi_tmp[2], roi_mask, roi_esc;
     int roi_idx = 0, roi_mshift = 0;
+    uint64_t roi_cells_seen = 0;     // cell count of the lattice the mark buffers were last used with (a change clears them in full)
     bool roi_on = false;             // the target structures the handle holds cover only the region of the scan they were prepared for
     long long roi_repeats = 0;       // calls that left the region and were repeated on the whole target
 
@@ -637,7 +638,7 @@ static double src_cell0() { static const double v = dev_env("PCR_COV_CELL0") ? a
 static double cov_ratio() { static const double v = dev_env("PCR_COV_RATIO") ? atof(dev_env("PCR_COV_RATIO")) : 6.0; return v; }
 int cov_levels(size_t n) { return n <= 300000 ? cov_levels_small() : 1; }
 
-int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, bool marked = false);
+int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, bool marked = false, std::string* errp = nullptr);
 int vgicp_side_init(pcr_handle* h) {
     if (!h->side_stream) {
         // The three streams of a VGICP call must be three HARDWARE queues.  The runtime spreads the streams of a process over a small pool
@@ -668,7 +669,11 @@ int vgicp_side_init(pcr_handle* h) {
 // and leave early; whatever they wrote is written again by the caller.
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
                       double shift0, GridHeader* hdr0_out, bool may_cut = false, double ahead_cell = 0.0, bool* ahead_ok = nullptr,
-                      const std::function<int()>* after_ahead = nullptr, bool* after_clean = nullptr, const std::function<int()>* before_wait = nullptr) {
+                      const std::function<int()>* after_ahead = nullptr, bool* after_clean = nullptr, const std::function<int()>* before_wait = nullptr,
+                      bool scan_levels = false) {
+    // scan_levels: the levels of a SCAN (the source of an alignment that did not come through vgicp_source_enqueue: pcr_set_target + pcr_align,
+    // pcr_vgicp_covariances, the redo path): built like vgicp_source_enqueue builds them -- one-level path, no hints: one scan's box and tile
+    // layout do not hold the next (walls at other distances; measured there: every hint failed and the redo cost 0.9 ms)
     GridIndex* lv[3] = {&g, &l1, &l2};
     const double cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n);
@@ -702,8 +707,9 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
             if (!todo[l]) continue;
             // (the box and the tile layout of this index's previous build serve as hints -- GridIndex::hint_ok: a sub-map changes by a key frame
             //  at a time, a scan's box in the sensor frame hardly at all; a cloud that does not fit raises header.stale and is built afresh)
-            lv[l]->no_hints = h->prm.index_no_hints != 0;
-            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, true) != hipSuccess) { if (aux) (void)hipStreamSynchronize(h->aux_stream); return 1; }
+            lv[l]->no_hints = h->prm.index_no_hints != 0 || scan_levels;
+            if (scan_levels) { lv[l]->prefer_one_level = true; lv[l]->header_mirror = nullptr; lv[l]->twin = nullptr; }
+            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, !scan_levels) != hipSuccess) { if (aux) (void)hipStreamSynchronize(h->aux_stream); return 1; }
             if (l == 0 && hdr0_out) H_TRY_AUX(lv[l]->enqueue_density(h->stream));
             H_TRY_AUX(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
@@ -758,13 +764,17 @@ int vgicp_source_mark(pcr_handle* h) {
     H_TRY(hipEventRecord(h->ev_side_in, h->stream));
     return 0;
 }
-int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, bool marked) {
+// errp: where messages go (the worker thread's own string while the calling thread may be writing h->err)
+int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, bool marked, std::string* errp) {
+    std::string& err = errp ? *errp : h->err;
+#define S_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(_e); return 1; } } while (0)
     h->side_pending = false;
-    if (vgicp_side_init(h)) return 1;
+    if (!marked && vgicp_side_init(h)) return 1;      // (marked: vgicp_source_mark has made the streams and events)
     if (n_src > 0xfffffff0ull) return 0;                         // run_vgicp reports it
-    H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
-    if (!marked) H_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
-    H_TRY(hipStreamWaitEvent(h->side_stream, h->ev_side_in, 0));
+    S_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
+    if (!marked) S_TRY(hipEventRecord(h->ev_side_in, h->stream));             // the scan's staging copy (if any) is on the main stream
+    S_TRY(hipStreamWaitEvent(h->side_stream, h->ev_side_in, 0));
+#undef S_TRY
     GridIndex* lv[3] = {&h->src_grid, &h->src_l1, &h->src_l2};
     const double cell = h->prm.vgicp_resolution, cells[3] = {cell, cov_ratio() * cell, cov_ratio() * cov_ratio() * cell};
     const int levels = cov_levels(n_src);
@@ -783,24 +793,24 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
         lv[l]->header_mirror = &h->side_hdr[l];
         lv[l]->twin = (l == 0 && levels > 1) ? lv[1] : nullptr;
         lv[l]->twin_cell = src_cell0() * cells[1];
-        e = lv[l]->build(d_src, n_src, stride_floats, src_cell0() * cells[l], h->side_stream, &h->err, 0.0);
+        e = lv[l]->build(d_src, n_src, stride_floats, src_cell0() * cells[l], h->side_stream, &err, 0.0);
         lv[l]->twin = nullptr;
         if (e == hipSuccess && !lv[l]->mirrored && (e = hipMemcpyAsync(&h->side_hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->side_stream)) != hipSuccess)
-            h->err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
+            err = std::string("hipMemcpyAsync(side header): ") + hipGetErrorString(e);
     }
     if (e == hipSuccess && (e = vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
                                                  h->src_cov6.as<double>(), h->side_stream, nullptr, nullptr, &h->src_scratch,
                                                  (h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000) ? h->ev_cov + 2 : nullptr)) != hipSuccess)
-        h->err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
+        err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
     if (e == hipSuccess && h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000) h->ev_cov_src_used = true;
     h->fit_copied_from = nullptr;
     if (e == hipSuccess && !sharded(h) && n_src > 0) {      // the scan, kept for a later pcr_fitness() (off the critical path here)
         const size_t bytes = n_src * stride_floats * sizeof(float);
         if ((e = h->fit_src.reserve(bytes)) != hipSuccess || (e = hipMemcpyAsync(h->fit_src.p, d_src, bytes, hipMemcpyDeviceToDevice, h->side_stream)) != hipSuccess)
-            h->err = std::string("keeping the scan for the fitness score: ") + hipGetErrorString(e);
+            err = std::string("keeping the scan for the fitness score: ") + hipGetErrorString(e);
         else h->fit_copied_from = d_src;
     }
-    if (e == hipSuccess && (e = hipEventRecord(h->ev_side_done, h->side_stream)) != hipSuccess) h->err = std::string("hipEventRecord: ") + hipGetErrorString(e);
+    if (e == hipSuccess && (e = hipEventRecord(h->ev_side_done, h->side_stream)) != hipSuccess) err = std::string("hipEventRecord: ") + hipGetErrorString(e);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->side_stream); return 1; }
     h->side_pending = true; h->side_src = d_src; h->side_n = n_src; h->side_stride = stride_floats;
     return 0;
@@ -827,7 +837,7 @@ int vgicp_source_settle(pcr_handle* h, const float* d_src, size_t n_src, size_t 
         h->side_pending = false;
         H_TRY(hipEventSynchronize(h->ev_side_done));             // never leave side work in flight behind the caller's back
     }
-    if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_src, n_src, stride_floats, h->prm.vgicp_resolution, 0.0, nullptr)) return 1;
+    if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_src, n_src, stride_floats, h->prm.vgicp_resolution, 0.0, nullptr, false, 0.0, nullptr, nullptr, nullptr, nullptr, true)) return 1;
     H_TRY(h->src_cov6.reserve((n_src + 1) * 6 * sizeof(double)));
     H_TRY(vgicp_launch_cov(h->src_grid, levels > 1 ? &h->src_l1 : nullptr, levels > 2 ? &h->src_l2 : nullptr, d_src, stride_floats, n_src,
                            h->src_cov6.as<double>(), h->stream, nullptr, nullptr, &h->src_scratch));
@@ -850,6 +860,13 @@ int roi_enqueue(pcr_handle* h, const RoiScan& scan, double cell, double base_m, 
         const void* before = b->p;
         H_TRY(b->reserve(bytes));
         if (b->p != before) H_TRY(hipMemsetAsync(b->p, 0, b->cap, h->stream));      // the marks start out clear; every call clears the other buffer for the next
+    }
+    // Every call clears the OTHER mark buffer for the next one -- over the macro cells of ITS lattice only.  When the lattice changes
+    // (another box, another cell count) marks of the old one would survive beyond the new one's extent as spurious region: harmless for the
+    // result (the mask only grows), wasteful.  An asynchronous memset then.
+    if (h->roi_cells_seen != h->grid.cells_hint) {
+        for (DeviceBuf* b : {&h->roi_mark[0], &h->roi_mark[1]}) H_TRY(hipMemsetAsync(b->p, 0, b->cap, h->stream));
+        h->roi_cells_seen = h->grid.cells_hint;
     }
     for (DeviceBuf* b : {&h->roi_tmp[0], &h->roi_tmp[1], &h->roi_mask}) H_TRY(b->reserve(bytes));      // (written in full by every call)
     H_TRY(h->roi_esc.reserve(64));
@@ -1501,6 +1518,8 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         // they are searched in two classes (cov_search.hip: ~190 us with the scan's index levels) the target is the long pole, and the
         // dozen launches of the scan's side cost the host ~100 us during which the main stream sat empty.  Now the target's builds are
         // queued first and the scan's side while the host waits for their headers (settle_cov_levels: before_wait).
+        // (Measured and not kept: the scan's side queued by a host thread of its own at the same time as the target's -- 0.481 / 0.495 against
+        //  0.496 / 0.494 ms: with both sides on the device from the start the call is bound by the device's work, not by the host's launches.)
         static const bool src_first = dev_env("PCR_VG_SRC_FIRST") != nullptr;      // (development builds: the old order, for A/B runs)
         int prc = 0;
         bool src_queued = false;
@@ -1882,7 +1901,7 @@ int pcr_vgicp_covariances(pcr_handle* h, const void* pts, size_t n, size_t strid
     const float* d_pts = (const float*)pts;
     if (!on_device && stage_host(h, &h->src_stage, pts, n, stride_bytes, &d_pts)) return 1;
     if (h->side_pending) { H_TRY(hipEventSynchronize(h->ev_side_done)); h->side_pending = false; }
-    if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution, 0.0, nullptr)) return 1;
+    if (settle_cov_levels(h, h->src_grid, h->src_l1, h->src_l2, d_pts, n, stride_bytes / 4, h->prm.vgicp_resolution, 0.0, nullptr, false, 0.0, nullptr, nullptr, nullptr, nullptr, true)) return 1;
     H_TRY(h->src_cov6.reserve((n + 1) * 6 * sizeof(double)));
     H_TRY(hipMemsetAsync(h->src_cov6.p, 0, (n + 1) * 6 * sizeof(double), h->stream));
     H_TRY(vgicp_launch_cov(h->src_grid, cov_levels(n) > 1 ? &h->src_l1 : nullptr, cov_levels(n) > 2 ? &h->src_l2 : nullptr, d_pts, stride_bytes / 4, n,
@@ -2309,7 +2328,13 @@ int pcr_host_unpin(const void* ptr) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pinned.size(); ++i)
         if (g_pinned[i].p == ptr) {
-            (void)hipDeviceSynchronize();      // no copy out of the range may still be in flight
+            {   // no copy out of the range may still be in flight -- on ANY device (a handle on another GPU may have staged from it)
+                int cur = 0, ndev = 0;
+                if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess) {
+                    for (int d = 0; d < ndev; ++d) if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+                    (void)hipSetDevice(cur);
+                } else (void)hipDeviceSynchronize();
+            }
             const hipError_t e = hipHostUnregister(const_cast<void*>(ptr));
             g_pinned.erase(g_pinned.begin() + (long)i);
             if (e != hipSuccess) { (void)hipGetLastError(); g_create_error = std::string("hipHostUnregister: ") + hipGetErrorString(e); return 1; }
@@ -2334,6 +2359,7 @@ int pcr_comm_info(const pcr_handle* h, int* rank, int* nranks, int* transport) {
     int r = h->rank, n = h->nranks, t = 0;
     if (h->comm) {
         // what the communicator itself reports, not what the caller passed to pcr_comm_init
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
         t = 1;
         if (g_rccl.comm_count && g_rccl.comm_count(h->comm, &n) != 0) return 1;
         if (g_rccl.comm_user_rank && g_rccl.comm_user_rank(h->comm, &r) != 0) return 1;

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void roi_mark_kernel(const float* __restrict__
 // r <= 11), so every cell the exact dilation holds is held (a few more are: harmless).  A scatter from the marks was 90 us (a handful of
 // lanes per wave walking cubes of hundreds of bytes); the three gathers read contiguous bytes.  The first pass clears the marks of the
 // NEXT call (two buffers, alternating, like NDT's candidate counters): no memset per call.
-static constexpr int kRoiMaxRadius = 12;      // macro cells (24 m at 2 m macro cells)
+static constexpr int kRoiMaxRadius = 11;      // macro cells (22 m at 2 m macro cells): the bound of the separable gather above (per_m * sqrt 3 * r < 1)
 __global__ __launch_bounds__(256) void roi_dilate_axis_kernel(const GridHeader* __restrict__ lat, const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ clear_next, int axis, int mshift, double sx, double sy, double sz,
                                                               double base_m, double per_m) {

@@ -104,6 +104,8 @@ inline int loadPCDFile(const std::string& path, PCR::PointCloud& cloud) {
         else if (fields[i].name == "intensity") ii = (int)i;
     }
     if (ix < 0 || iy < 0 || iz < 0) throw std::runtime_error("pcd: fields x, y, z are required (" + path + ")");
+    for (int k : {ix, iy, iz, ii})      // a field that is READ must hold at least one element (COUNT 0 would read past the record)
+        if (k >= 0 && fields[(size_t)k].count < 1) throw std::runtime_error("pcd: COUNT of field " + fields[(size_t)k].name + " must be at least 1 (" + path + ")");
     cloud.points.clear();
     cloud.points.resize(points);
     if (data_kind == "ascii") {
