@@ -4,10 +4,15 @@ corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in Ki
 import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+
+
+def kname(n):
+    """kernel name without its argument list (the kernels of an anonymous namespace keep their own name)"""
+    return n.replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def newest(pattern):
@@ -22,7 +27,7 @@ if f:
         o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
-            o.write(",".join([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+            o.write(",".join([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
 
 for m in ("vgicp", "ndt"):
     f = newest(f"stats_{m}/**/*kernel_stats.csv")
@@ -32,7 +37,7 @@ for m in ("vgicp", "ndt"):
             o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --method {m} --steps 40 --warmup 5 --no-cpu-baseline\n")
             o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
             for r in rows:
-                o.write(",".join([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+                o.write(",".join([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
 
 
 def means(pattern):
@@ -40,7 +45,7 @@ def means(pattern):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in acc.items()}
 
 
@@ -69,6 +74,7 @@ if "FETCH_SIZE" in it and "WRITE_SIZE" in it:
         "note": "mean over all launches of the bench run (full-search and cache-hit iterations); FETCH_SIZE doubled per the gfx950 correction",
     }
     json.dump(out, open(os.path.join(dst, "loam_iterate_pmc.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(dst, f"{tag}_loam_iterate_pmc.json"), "w"), indent=1)
     print(out)
 # configs[2] / configs[4]: HBM bytes per scan of everything but the optimiser's passes (= target preparation, plus the scan's own two index
 # levels and covariances for VGICP), from the per-dispatch counters: sum over the kernels of (mean bytes per dispatch x dispatches per scan)
@@ -86,7 +92,23 @@ for m in ("vgicp", "ndt"):
         rows.append({"kernel": k, "dispatches_per_scan": n / max(1, scans), "fetch_kib": f_kib, "write_kib": w_kib, "hbm_bytes_per_scan": per_scan, "target_preparation": not is_pass})
         total += per_scan
         prep += 0.0 if is_pass else per_scan
-    json.dump({"method": m, "scans": scans, "hbm_bytes_per_scan_preparation": prep, "hbm_bytes_per_scan_total": total, "kernels": rows,
+    extra = {}
+    sq = means(f"pmc_sq_{m}/**/*counter_collection.csv")
+    with open(os.path.join(dst, f"{tag}_{m}_pmc_sq_means.csv"), "w") as o:
+        o.write("# mean SQ counter value per dispatch (own rocprofv3 --pmc pass)\nKernel,Counter,MeanPerDispatch,Dispatches\n")
+        for k in sorted(sq):
+            for c in sorted(sq[k]):
+                o.write(f"{k},{c},{sq[k][c][0]:.1f},{sq[k][c][1]}\n")
+    if m == "ndt":
+        pk = next((v for k, v in sq.items() if "ndt_pass_pro_kernel" in k), None)
+        if pk and "SQ_ACTIVE_INST_VALU" in pk and "SQ_WAVE_CYCLES" in pk:
+            extra["valu_active_frac"] = pk["SQ_ACTIVE_INST_VALU"][0] / pk["SQ_WAVE_CYCLES"][0]
+            extra["valu_active_note"] = "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of ndt_pass_pro_kernel, mean over its dispatches"
+    if m == "vgicp":
+        for k in rows:
+            if "vgicp_cov_kernel<false>" in k["kernel"]:
+                extra["hbm_bytes_per_launch_cov_target"] = (2 * k["fetch_kib"] + k["write_kib"]) * 1024
+    json.dump({"method": m, "scans": scans, "hbm_bytes_per_scan_preparation": prep, "hbm_bytes_per_scan_total": total, **extra, "kernels": rows,
                "note": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, one counter per pass), FETCH doubled per the gfx950 correction; "
                        "preparation = every kernel but the optimiser's passes"}, open(os.path.join(dst, f"{tag}_{m}_pmc.json"), "w"), indent=1)
     print(m, "HBM bytes per scan: preparation", prep, "total", total)

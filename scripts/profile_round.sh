@@ -3,7 +3,7 @@
 # counters of the dominant kernel, each PMC group in its own pass (MI355X_MICROARCH.md, "HBM" / "rocprofv3 PMC").
 # Output under gpurun_out/prof_<tag>; the summaries are then copied into profiles/ by scripts/collect_profiles.py.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -21,5 +21,6 @@ for m in vgicp ndt; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -- python3 $MARGS > $OUT/stats_$m.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$m -- python3 $MARGS > $OUT/pmc_fetch_$m.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$m -- python3 $MARGS > $OUT/pmc_write_$m.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_$m -- python3 $MARGS > $OUT/pmc_sq_$m.log 2>&1
 done
 echo done
