@@ -372,7 +372,6 @@ __device__ unsigned long long* g_dev_stamps = nullptr;
 #else
 #define DEV_STAMP(kernel, slot) do { } while (0)
 #endif
-static constexpr uint32_t kHeavyTile = 2048;           // points: tiles at or above go first in the tile kernel (grid_bin_kernel: tile_order)
 static constexpr int kBinStride = 16;                  // counters 64 bytes apart: memory-side atomics on one line serialise
 static constexpr int kBinPerDefault = 8;              // points per thread and chunk of the bin kernel
 
@@ -393,10 +392,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start, uint32_t* __restrict__ lay_next,
                                                        const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
-                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift, uint32_t* __restrict__ tile_order) {
-    // tile_order: the tiles in the order the tile kernel takes them, written by the last block: the heavy ones (>= kHeavyTile points) first --
-    // a tile is one block's work, and a ground tile of a large map holds tens of thousands of points (measured at 10 M points: the tile
-    // kernel's slowest block 151 us of its 168, started 17 us into the kernel)
+                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift) {
     // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
     // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
@@ -509,18 +505,6 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     for (uint32_t j = 0; j < kMaxBins / 256; ++j)
         if (j < per && b0 + j < nbins) { bin_start[b0 + j] = off; off += c[j]; }
     if (threadIdx.x == 255) bin_start[nbins] = total;
-    {
-        __syncthreads();      // sh4 is reused
-        uint32_t heavy = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kMaxBins / 256; ++j) if (j < per && b0 + j < nbins && c[j] >= kHeavyTile) ++heavy;
-        uint32_t heavy_total;
-        uint32_t ho = block_exclusive_scan_256(heavy, &heavy_total, sh4);
-        uint32_t lo_pos = heavy_total + (min(b0, nbins) - ho);      // light tiles before this thread's = tiles before - heavy tiles before
-#pragma unroll
-        for (uint32_t j = 0; j < kMaxBins / 256; ++j)
-            if (j < per && b0 + j < nbins) { if (c[j] >= kHeavyTile) tile_order[ho++] = b0 + j; else tile_order[lo_pos++] = b0 + j; }
-    }
     // ... and into the layout the NEXT build may place its points by: every tile gets an eighth more room than it holds now
     if (kPlace && keep_mask) {      // (a build of a region: the counts are not the cloud's; the layout it came with stays)
         for (uint32_t b = threadIdx.x; b <= nbins; b += 256) lay_next[b] = lay_cur[b];
@@ -595,7 +579,7 @@ template <int kTilePer, int kMode, int kThreads>
 __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
                                                         float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
-                                                        const uint32_t* __restrict__ src_start, const uint32_t* __restrict__ tile_order) {
+                                                        const uint32_t* __restrict__ src_start) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;                    // 1 << shift
     __shared__ uint32_t sh4[kThreads / 64];
@@ -611,8 +595,9 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
         for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;
         return;
     }
-    for (uint32_t ti = blockIdx.x; ti < nbins; ti += gridDim.x) {
-        const uint32_t tile = tile_order[ti];
+    for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) {
+        // (taking the heavy tiles first -- an order written by the bin kernel's last block -- was measured: the kernel's span is its heaviest
+        //  tile's own 24 us wherever it starts, and the extra scan cost the bin kernel's serial tail 3 us; profiles/r04_notes.md)
         const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
         const uint32_t q0 = src_start[tile];      // first point of the tile in `tiled`
         const uint64_t cell0 = (uint64_t)tile << shift;
@@ -659,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
             }
         }
         __syncthreads();
-        if (ti == blockIdx.x) DEV_STAMP(1, 1);
+        if (tile == blockIdx.x) DEV_STAMP(1, 1);
         // exclusive scan of the tile's counters -> cell_start (+ sum of count^2, the density estimate of the header)
         unsigned long long sq = 0;
         uint32_t carry = 0;
@@ -689,7 +674,7 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
         __syncthreads();
         // (one 8-byte store per tile; thousands of blocks adding into one header word serialise at the memory side for ~45 us)
         if (threadIdx.x == 0) { unsigned long long t_ = 0; for (int w = 0; w < kThreads / 64; ++w) t_ += sh_sq[w]; tile_sq[tile] = t_; }
-        if (ti == blockIdx.x) DEV_STAMP(1, 2);
+        if (tile == blockIdx.x) DEV_STAMP(1, 2);
         if (small) {
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {
@@ -716,7 +701,7 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
             }
         }
         __syncthreads();
-        if (ti == blockIdx.x) DEV_STAMP(1, 3);
+        if (tile == blockIdx.x) DEV_STAMP(1, 3);
     }
     DEV_STAMP(1, 4);
 }
@@ -833,7 +818,7 @@ void DeviceBuf::release() {
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
     bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
-    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); tile_order.release(); layout[0].release(); layout[1].release(); lay_ok = false;
+    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); layout[0].release(); layout[1].release(); lay_ok = false;
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -951,7 +936,6 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
         PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));
-        PCR_TRY(tile_order.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         tiled_shift = tshift;
         if (!bin_count.p) {
             PCR_TRY(bin_count.reserve(((size_t)kMaxBins + 64) * kBinStride * sizeof(uint32_t)));
@@ -987,7 +971,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
 #define PCR_LAUNCH_BIN(VEC, PER, PLACE) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
                                                     bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
-                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift, tile_order.as<uint32_t>())
+                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
         if (use_layout) {
             if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, true); else PCR_LAUNCH_BIN(true, 16, true); }
             else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, true); else PCR_LAUNCH_BIN(false, 16, true); }
@@ -1008,7 +992,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
 #define PCR_LAUNCH_TILE(PER, MODE, THREADS) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
                            bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
-                           use_layout ? lay_cur : bin_start.as<uint32_t>(), tile_order.as<uint32_t>())
+                           use_layout ? lay_cur : bin_start.as<uint32_t>())
         // dense grids: eight points per thread (135 VGPRs, three waves per SIMD) while a tile holds ~1 000 points or fewer on average, sixteen
         // beyond (A/B: 1 M points in 1 464 tiles 48.4 -> 46.8 us with eight; 5 M and 10 M points are faster with sixteen)
         // (blocks of 1 024 threads for the 5 M and 10 M-point maps -- grid_tile_kernel<4, 0, 1024>, PCR_TILE_WIDE in a development build -- cut the

@@ -177,7 +177,7 @@ struct BuildFilter {
 
 struct GridIndex {
     DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header, keys, ranks, ticket;
-    DeviceBuf tiled, bin_count, bin_start, tile_sq, tile_order;      // tiled build path: points grouped by tile, points per tile, first point of every tile, sum of count^2 per tile
+    DeviceBuf tiled, bin_count, bin_start, tile_sq;      // tiled build path: points grouped by tile, points per tile, first point of every tile, sum of count^2 per tile
     int tiled_shift = -1;                       // log2(cells per tile) of the last build when it took the tiled path
     // Bounding-box hint: a build whose header the host has seen to be good (confirm()) lets the NEXT build of the same kind skip
     // the bounding-box pass and reuse that header -- a sub-map changes by a key frame at a time.  The bin kernel checks every
