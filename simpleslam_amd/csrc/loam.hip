@@ -755,9 +755,10 @@ __device__ __forceinline__ int loam_point(const LoamArgs& a, const GridHeader& h
         const bool proven = state == 2u || (state == 1u && (s.idx[4] == 0xffffffffu ? !(bound_sq < a.c.knn_max_sq) : s.d[4] < bound_sq));
         if (searched && !proven) {
             double nxt;
+            uint32_t rp2[kNb];      // (an array of its own: handing &rp to the out-of-line function made the compiler keep rp in scratch memory on EVERY path -- eight stores per point)
             knn8_exact(h.origin[0], h.origin[1], h.origin[2], h.inv_cell, (uint32_t)h.dims[0], (uint32_t)h.dims[1], a.grid.pts, a.grid.cell_start, qx, qy, qz,
-                       a.c.knn_max_sq, rp, &nxt);
-            for (int j = 0; j < kNb; ++j) nb8_set(s, j, a.grid.pts[rp[j] != kNoPos ? rp[j] : 0u], rp[j] != kNoPos, qx, qy, qz);
+                       a.c.knn_max_sq, rp2, &nxt);
+            for (int j = 0; j < kNb; ++j) nb8_set(s, j, a.grid.pts[rp2[j] != kNoPos ? rp2[j] : 0u], rp2[j] != kNoPos, qx, qy, qz);
             nb8_sort(s);
             bound_sq = nxt;
         }
