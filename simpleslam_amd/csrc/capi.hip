@@ -1187,11 +1187,6 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
         bf.mask = roi.mask; bf.mshift = roi.mshift;
         return hipSuccess;
     };
-    if (deferred) {
-        if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true, want_roi && !no_filter ? &bf : nullptr) != hipSuccess) return 1;
-    } else if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
-    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
-    H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
     // setMinPointPerVoxel (pclomp/voxel_grid_covariance_omp.h:229-240): "Covariance calculation requires at least 3 points"
     const int min_points = std::max(3, h->prm.ndt_min_points);
     const size_t max_vox = n_dst / (size_t)min_points + 2;      // a voxel needs min_points points
@@ -1202,14 +1197,27 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
         H_TRY(hipMemsetAsync(h->nd_count.p, 0, 256, h->stream));
     }
     h->nd_count_idx ^= 1;
+    uint32_t* const nd_count = h->nd_count.as<uint32_t>() + 32 * h->nd_count_idx;
+    uint32_t* const nd_count_next = h->nd_count.as<uint32_t>() + 32 * (h->nd_count_idx ^ 1);
+    if (deferred) {
+        // (the cell table keeps its size in a deferred build, so the slots can be sized before it: a region-only build lists the voxel cells
+        //  and writes the slots in its tile pass -- TileTail)
+        if (h->grid.ensure_tables(h->stream, &h->err) != hipSuccess) return 1;
+        H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
+        bf.want_tail = true;
+        bf.tail.vox_slot = h->nd_slot.as<uint32_t>(); bf.tail.list = h->nd_list.as<uint32_t>(); bf.tail.count = nd_count; bf.tail.count_next = nd_count_next;
+        bf.tail.min_points = min_points; bf.tail.capacity = (uint32_t)std::min<size_t>(max_vox, 0xffffffffu);
+        if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true, want_roi && !no_filter ? &bf : nullptr) != hipSuccess) return 1;
+    } else if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
+    h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
+    H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
     if (bf.applied) { roi.filtered = 1; h->roi_on = true; }
     else if (want_roi) {
         if (roi_enqueue(h, *roi_scan, res, 1.0 + res, &roi)) return 1;
         h->roi_on = true;
     }
-    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), h->nd_count.as<uint32_t>() + 32 * h->nd_count_idx,
-                            h->nd_count.as<uint32_t>() + 32 * (h->nd_count_idx ^ 1), h->nd_list.as<uint32_t>(),
-                            max_vox, min_points, 0.01, h->stream, h->roi_on ? &roi : nullptr));
+    H_TRY(ndt_launch_voxels(h->grid, h->nd_slot.as<uint32_t>(), h->nd_vox.as<NdtVoxel>(), nd_count, nd_count_next, h->nd_list.as<uint32_t>(),
+                            max_vox, min_points, 0.01, h->stream, h->roi_on ? &roi : nullptr, bf.tail_applied));
     h->nd_target_ready = true;
     return 0;
 }

@@ -574,18 +574,24 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
 // the 0.5 m voxel lattice makes 3 350 tiles of which most hold nothing or a handful of points, they go through the kernel in 6.5 rounds of
 // 512 blocks -- 123 us.  A sparse grid is therefore served by TWO instantiations over the same tiles: kMode 1 takes the tiles of up to 256
 // points with one point per thread (few VGPRs, many blocks in flight), kMode 2 the others with sixteen; kMode 0 = every tile (dense grids).
-template <int kTilePer, int kMode, int kThreads>
+// kTail (NDT's region-only targets, pcr_internal.h: TileTail): while a tile's cell counts are in registers the cells that will carry a voxel
+// are listed and every cell's slot is written -- ndt_candidates_kernel's work without its launch and without reading the table again.
+template <int kTilePer, int kMode, int kThreads, bool kTail = false>
 // src_start: where tile t's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
 __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
                                                         float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
-                                                        const uint32_t* __restrict__ src_start) {
+                                                        const uint32_t* __restrict__ src_start, const TileTail tail) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;                    // 1 << shift
     __shared__ uint32_t sh4[kThreads / 64];
     __shared__ unsigned long long sh_sq[kThreads / 64];
+    __shared__ uint32_t sh_tail_base;
     DEV_STAMP(1, 0);
+    if (kTail && blockIdx.x == 0 && threadIdx.x == 0) *tail.count_next = 0u;      // (the other of two counters, for the next call: before anything can return)
     const GridHeader h = *hdr_in;
+    if (kTail && h.empty && !h.overflow)      // nothing indexed: no cell carries a voxel
+        for (uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x; t < h.n_cells; t += (uint64_t)gridDim.x * kThreads) tail.vox_slot[t] = 0u;
     if (h.overflow || h.empty) return;
     const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
     const uint32_t S = 1u << shift;
@@ -648,10 +654,31 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
         // exclusive scan of the tile's counters -> cell_start (+ sum of count^2, the density estimate of the header)
         unsigned long long sq = 0;
         uint32_t carry = 0;
+        uint32_t listed = 0;      // kTail: bit (4 * round + k) = cell k of this thread's four in that round goes on the list (<= 8 rounds: 2^13 cells per tile)
         for (uint32_t cb = 0; cb < S; cb += 4u * kThreads) {
             const uint32_t c = cb + threadIdx.x * 4;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (c < S) v = *reinterpret_cast<const uint4*>(hist + c);
+            if (kTail && c < S && cell0 + c < h.n_cells) {
+                // the four cells are neighbours along x: one decode serves them unless the row ends in between
+                const uint32_t g32 = (uint32_t)(cell0 + c), d0 = (uint32_t)h.dims[0], d1 = (uint32_t)h.dims[1], row = g32 / d0, cz = row / d1, cx0 = g32 - row * d0;
+                const uint32_t mrow = roi_macro(h, tail.mshift, 0, (int)(row - cz * d1), (int)cz);
+                const uint32_t cnt[4] = {v.x, v.y, v.z, v.w};
+                uint32_t sl[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((uint64_t)g32 + k < h.n_cells) {
+                        const bool in = cx0 + k < d0 ? tail.mask[mrow + ((cx0 + k) >> tail.mshift)] != 0 : roi_mask_holds_cell(h, tail.mask, tail.mshift, g32 + k);
+                        if (in && (int)cnt[k] >= tail.min_points) listed |= 1u << ((cb / (4u * kThreads)) * 4u + k);
+                        sl[k] = in ? 0u : kNdtUnprepared;      // (the index holds nothing outside the mask: every cell there is unprepared)
+                    }
+                }
+                if ((uint64_t)g32 + 3 < h.n_cells) *reinterpret_cast<uint4*>(tail.vox_slot + g32) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if ((uint64_t)g32 + k < h.n_cells) tail.vox_slot[g32 + k] = sl[k];
+                }
+            }
             sq += (unsigned long long)v.x * v.x + (unsigned long long)v.y * v.y + (unsigned long long)v.z * v.z + (unsigned long long)v.w * v.w;
             uint32_t tot;
             const uint32_t o = block_exclusive_scan<kThreads>(v.x + v.y + v.z + v.w, &tot, sh4) + carry;
@@ -674,6 +701,20 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
         __syncthreads();
         // (one 8-byte store per tile; thousands of blocks adding into one header word serialise at the memory side for ~45 us)
         if (threadIdx.x == 0) { unsigned long long t_ = 0; for (int w = 0; w < kThreads / 64; ++w) t_ += sh_sq[w]; tile_sq[tile] = t_; }
+        if (kTail) {
+            // room on the list for all of the tile's cells with ONE atomic (the order of the list is immaterial: ndt_voxel_kernel takes a cell per thread)
+            uint32_t tot;
+            uint32_t pos = block_exclusive_scan<kThreads>((uint32_t)__popc(listed), &tot, sh4);
+            if (threadIdx.x == 0) sh_tail_base = tot ? atomicAdd(tail.count, tot) : 0u;
+            __syncthreads();
+            pos += sh_tail_base;
+            while (listed) {
+                const uint32_t b = (uint32_t)__ffs((int)listed) - 1u;
+                listed &= listed - 1u;
+                if (pos < tail.capacity) tail.list[pos] = (uint32_t)cell0 + (b >> 2) * 4u * kThreads + threadIdx.x * 4u + (b & 3u);      // (capacity = points / min_points: never short)
+                ++pos;
+            }
+        }
         if (tile == blockIdx.x) DEV_STAMP(1, 2);
         if (small) {
 #pragma unroll
@@ -874,7 +915,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
                             int pcl_mode, const ClampBox* clamp, bool allow_hint, BuildFilter* filter) {
     valid = false;
     filtered = false;
-    if (filter) filter->applied = false;
+    if (filter) { filter->applied = false; filter->tail_applied = false; }
     const bool force_atomic_path = dev_env("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
     PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
@@ -990,9 +1031,12 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         }
         // (a grid with many more cells than points: light tiles and heavy tiles by an instantiation each, see grid_tile_kernel)
         const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
-#define PCR_LAUNCH_TILE(PER, MODE, THREADS) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
+        TileTail tail;
+        memset(&tail, 0, sizeof tail);
+#define PCR_LAUNCH_TILE_T(PER, MODE, THREADS, TAIL) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS, TAIL>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
                            bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
-                           use_layout ? lay_cur : bin_start.as<uint32_t>())
+                           use_layout ? lay_cur : bin_start.as<uint32_t>(), tail)
+#define PCR_LAUNCH_TILE(PER, MODE, THREADS) PCR_LAUNCH_TILE_T(PER, MODE, THREADS, false)
         // dense grids: eight points per thread (135 VGPRs, three waves per SIMD) while a tile holds ~1 000 points or fewer on average, sixteen
         // beyond (A/B: 1 M points in 1 464 tiles 48.4 -> 46.8 us with eight; 5 M and 10 M points are faster with sixteen)
         // (blocks of 1 024 threads for the 5 M and 10 M-point maps -- grid_tile_kernel<4, 0, 1024>, PCR_TILE_WIDE in a development build -- cut the
@@ -1000,11 +1044,16 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         //  profiles/r04_notes.md)
         const uint64_t tiles_est = cells_hint ? (cells_hint >> tshift) + 1 : 0;
         static const int wide = dev_env("PCR_TILE_WIDE") ? atoi(dev_env("PCR_TILE_WIDE")) : 0;      // (development: average points per tile from which the wide blocks are used; 0 = never)
+        // (the tile pass lists NDT's voxel cells beside its own work: dense grids, tiles of at most 2^13 cells -- 32 per thread)
+        const bool with_tail = filtered && filter->want_tail && !sparse && tshift <= 13 && dev_env("PCR_NDT_NO_TAIL") == nullptr;
+        if (with_tail) { tail = filter->tail; tail.mask = keep_mask; tail.mshift = keep_mshift; filter->tail_applied = true; }
         if (sparse) { PCR_LAUNCH_TILE(1, 1, 256); PCR_LAUNCH_TILE(16, 2, 256); }
+        else if (with_tail) { if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE_T(8, 0, 256, true); else PCR_LAUNCH_TILE_T(16, 0, 256, true); }
         else if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE(8, 0, 256);
         else if (wide > 0 && tiles_est && n / tiles_est >= (uint64_t)wide) PCR_LAUNCH_TILE(4, 0, 1024);
         else PCR_LAUNCH_TILE(16, 0, 256);
 #undef PCR_LAUNCH_TILE
+#undef PCR_LAUNCH_TILE_T
         lay_idx ^= 1; lay_ok = true; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
         if (!filtered) lay_n = n;
         PCR_TRY(hipGetLastError());

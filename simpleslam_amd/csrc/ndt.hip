@@ -78,7 +78,6 @@ static constexpr double kFix2 = 1099511627776.0;    // 2^40 for sums of (x - c)(
 // the memory side, 31 us) and then writes them; the order of the list is immaterial.
 // roi (a target prepared for one scan, pcr_internal.h: RoiView): a qualifying cell OUTSIDE the region is not listed; its slot is set to
 // kNdtUnprepared, which the lookups of the optimiser count as an escape.
-static constexpr uint32_t kNdtUnprepared = 0xffffffffu;
 __device__ __forceinline__ bool ndt_cell_in_roi(const GridHeader& h, const RoiView& roi, uint64_t t) {
     return roi_mask_holds_cell(h, roi.mask, roi.mshift, (uint32_t)t);
 }
@@ -1041,12 +1040,13 @@ uint32_t ndt_blocks(uint32_t n_src) {
 }
 
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
-                             int min_points, double eig_mult, hipStream_t s, const RoiView* roi) {
+                             int min_points, double eig_mult, hipStream_t s, const RoiView* roi, bool listed_by_tile_pass) {
     const int blocks = (int)std::min<size_t>(512, grid.cell_capacity / 1024 + 1);
     RoiView rv;
     memset(&rv, 0, sizeof rv);
     if (roi) rv = *roi;
-    hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, d_count_next, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu), rv);
+    // (a region-only index has listed the cells and written the slots in its own tile pass: TileTail, grid_index.hip)
+    if (!listed_by_tile_pass) hipLaunchKernelGGL(ndt_candidates_kernel, dim3(blocks), dim3(256), 0, s, grid.view(), d_slot, d_list, d_count, d_count_next, min_points, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu), rv);
     const int vblocks = (int)std::min<size_t>(65535, list_capacity / 256 + 1);
     hipLaunchKernelGGL(ndt_voxel_kernel, dim3(vblocks), dim3(256), 0, s, grid.view(), d_list, d_count, d_slot, d_vox, eig_mult, (uint32_t)std::min<size_t>(list_capacity, 0xffffffffu));
     return hipGetLastError();

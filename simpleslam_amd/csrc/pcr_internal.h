@@ -168,11 +168,24 @@ static constexpr int kMaxTileShift = 13; // a tile's cells are histogrammed in L
 // build reuses the header and the tile layout of a previous FULL build (the lattice the mask is laid over must be known before the
 // points are binned, and the room of every tile is the full cloud's): build() then calls enqueue_mask -- which queues the marking of the
 // region on the build's stream and fills mask / mshift -- and sets `applied`; otherwise it builds in full and leaves `applied` false.
+// What the tile pass of a FILTERED build does for NDT while a tile's cell counts are still in LDS (grid_index.hip: grid_tile_kernel<.., kTail>):
+// the cells inside the mask with at least min_points points are appended to `list` (one atomic on `count` per tile), the slot of every cell is
+// written -- 0 inside the mask, kNdtUnprepared outside -- and `count_next` is cleared: what ndt_candidates_kernel does in a launch of its own
+// by reading the finished table again (ndt.hip).
+static constexpr uint32_t kNdtUnprepared = 0xffffffffu;      // slot of a cell the target was not prepared for (ndt.hip)
+struct TileTail {
+    uint32_t* vox_slot; uint32_t* list; uint32_t* count; uint32_t* count_next;
+    int32_t min_points; uint32_t capacity;
+    const uint8_t* mask; int32_t mshift;      // (filled by build() from the filter's mask)
+};
 struct BuildFilter {
     std::function<hipError_t()> enqueue_mask;
     const uint8_t* mask = nullptr;      // one byte per macro cell of the lattice (RoiView::mask)
     int mshift = 0;
     bool applied = false;
+    bool want_tail = false;             // `tail` is filled in: the tile pass may list NDT's voxel cells
+    TileTail tail = {};
+    bool tail_applied = false;          // ... and did (only together with `applied`, on the dense tile kernel)
 };
 
 struct GridIndex {
@@ -356,7 +369,7 @@ struct NdtArgs {
     uint32_t* pair_count;    // profiling passes only (pcr_set_profile >= 2), else NULL: [32] += (point, voxel) pairs of gradient-only passes, [48] += of passes with a Hessian
 };
 hipError_t ndt_launch_voxels(const GridIndex& grid, uint32_t* d_slot, NdtVoxel* d_vox, uint32_t* d_count, uint32_t* d_count_next, uint32_t* d_list, size_t list_capacity,
-                             int min_points, double eig_mult, hipStream_t s, const RoiView* roi = nullptr);
+                             int min_points, double eig_mult, hipStream_t s, const RoiView* roi = nullptr, bool listed_by_tile_pass = false);
 hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, int compute_hessian, double* d_out48, hipStream_t s, double seq = 0.0);
 hipError_t ndt_launch_hessian(const NdtArgs& a, const NdtPose& T, const NdtAngles& ang, double* d_out48, hipStream_t s, double seq = 0.0);
 // device-resident optimiser (ndt_opt.h): controller state in HBM, result in host-mapped memory
