@@ -163,7 +163,7 @@ struct pcr_handle {
     DeviceBuf cov_viol;              // VGICP halo check: number of neighbourhoods that reach past the halo
     double clamp_margin = 10.0;      // LOAM ClampBox: room around the scan, doubled when a query reached a cut face
     // region of interest of a target prepared for one scan (RoiView): two marking buffers used alternately, the dilated mask, the escape counter
-    DeviceBuf roi_mark[2], roi_tmp[2], roi_mask, roi_esc;
+    DeviceBuf roi_mark[2], roi_tmp, roi_mask, roi_esc;
     int roi_idx = 0, roi_mshift = 0;
     uint64_t roi_cells_seen = 0;     // cell count of the lattice the mark buffers were last used with (a change clears them in full)
     bool roi_on = false;             // the target structures the handle holds cover only the region of the scan they were prepared for
@@ -868,13 +868,13 @@ int roi_enqueue(pcr_handle* h, const RoiScan& scan, double cell, double base_m, 
         for (DeviceBuf* b : {&h->roi_mark[0], &h->roi_mark[1]}) H_TRY(hipMemsetAsync(b->p, 0, b->cap, h->stream));
         h->roi_cells_seen = h->grid.cells_hint;
     }
-    for (DeviceBuf* b : {&h->roi_tmp[0], &h->roi_tmp[1], &h->roi_mask}) H_TRY(b->reserve(bytes));      // (written in full by every call)
+    for (DeviceBuf* b : {&h->roi_tmp, &h->roi_mask}) H_TRY(b->reserve(bytes));      // (written in full by every call)
     H_TRY(h->roi_esc.reserve(64));
     Pose16 T;
     for (int i = 0; i < 16; ++i) T.m[i] = (double)(float)scan.pose[i];
     const int k = h->roi_idx;
     H_TRY(roi_launch(h->grid, scan.d_src, scan.n_src, scan.stride_floats, T, ms, h->roi_mark[k].as<uint8_t>(), h->roi_mark[k ^ 1].as<uint8_t>(),
-                     h->roi_tmp[0].as<uint8_t>(), h->roi_tmp[1].as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream));
+                     h->roi_tmp.as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream));
     h->roi_idx ^= 1;
     view->lat = h->grid.header.as<GridHeader>(); view->mask = h->roi_mask.as<uint8_t>(); view->escapes = h->roi_esc.as<uint32_t>();
     view->mshift = ms; view->filtered = 0; view->count = prof_counters(h);
@@ -1658,7 +1658,7 @@ void pcr_destroy(pcr_handle* h) {
     if (h->result_host) (void)hipHostFree(h->result_host);
     if (h->red_host) (void)hipHostFree(h->red_host);
     h->ar_stage.release(); h->dummy_grid.release(); h->cov_viol.release();
-    h->roi_mark[0].release(); h->roi_mark[1].release(); h->roi_tmp[0].release(); h->roi_tmp[1].release(); h->roi_mask.release(); h->roi_esc.release();
+    h->roi_mark[0].release(); h->roi_mark[1].release(); h->roi_tmp.release(); h->roi_mask.release(); h->roi_esc.release();
     for (hipEvent_t e : h->ev_kernel) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_index) (void)hipEventDestroy(h->ev_index);

@@ -762,12 +762,35 @@ __global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restric
 }
 
 // ---- region of interest of a target prepared for one scan (pcr_internal.h: RoiView) ----------------------------------
-// mark: the macro cell every scan point lands in at the initial pose (a byte store, skipped when the byte is already set: neighbouring
-// lanes are neighbouring beams).  A point outside the lattice marks the nearest boundary macro cell.
+// A marked macro cell stands for points that a change of the pose can move by base_m metres (translation, and the reach of the optimiser's
+// neighbourhood) + per_m metres per metre of distance from the sensor (rotation: a far point moves by range x angle): every macro cell within
+// that Chebyshev radius r of a mark belongs to the region.  Three launches:
+//   mark   the macro cell every scan point lands in at the initial pose (a point outside the lattice: the nearest boundary macro cell), and --
+//          by the first lane to find the cell unmarked -- the cells within r(mark) + 1 of it along x.  Byte stores, skipped when the byte is
+//          already set (neighbouring lanes are neighbouring beams): bit 1 = "a point landed here and its row has been spread", bit 0 = region;
+//          the stores race and the loser is a plain 1 over a 3, which costs a later point of that cell a second spread, never a cell.
+//   y, z   a 1-D GATHER each, with the radius R = r + 1 evaluated at the OUTPUT cell: the radius changes by at most one macro cell over its
+//          own reach (per_m * sqrt 3 * r < 1 for r <= 11), so every cell the exact dilation holds is held (a few more are: harmless).  The
+//          y pass also clears the marks of the NEXT call (two buffers, alternating, like NDT's candidate counters): no memset per call.
+// (Round 3 gathered along x too, in a launch of its own.  Measured and not kept: y and z in ONE 2-D gather -- 225 loads per cell where the
+//  two passes need 30: 25 us against 12; a scatter from the marks in all three directions -- 90 us, a handful of lanes per wave walking
+//  cubes of hundreds of bytes.)
+static constexpr int kRoiMaxRadius = 11;      // macro cells (22 m at 2 m macro cells): the bound of the gather's "+ 1" above (per_m * sqrt 3 * r < 1)
+__device__ __forceinline__ int roi_radius(const GridHeader& h, int mshift, uint32_t x, uint32_t y, uint32_t z, double sx, double sy, double sz, double base_m, double per_m) {
+    const double edge = h.cell * (double)(1u << mshift);
+    // centre of the macro cell in metres: cell i of axis d spans [(org_d + shift + i) cell, + cell)
+    const double cx = (h.org[0] + h.shift) * h.cell + ((double)x + 0.5) * edge, cy = (h.org[1] + h.shift) * h.cell + ((double)y + 0.5) * edge,
+                 cz = (h.org[2] + h.shift) * h.cell + ((double)z + 0.5) * edge;
+    const double range = sqrt((cx - sx) * (cx - sx) + (cy - sy) * (cy - sy) + (cz - sz) * (cz - sz)) + 0.87 * edge;
+    double rr = ceil((base_m + per_m * range) / edge);
+    if (!(rr >= 1.0)) rr = 1.0;
+    return (int)fmin(rr, (double)kRoiMaxRadius) + 1;
+}
 __global__ __launch_bounds__(256) void roi_mark_kernel(const float* __restrict__ src, uint32_t n, uint32_t stride, const Pose16 T, const GridHeader* __restrict__ lat,
-                                                       uint8_t* __restrict__ mark, int mshift) {
+                                                       uint8_t* __restrict__ mark, int mshift, double base_m, double per_m) {
     const GridHeader h = *lat;
     if (h.overflow || h.empty || h.stale) return;
+    const uint32_t m0 = ((uint32_t)h.dims[0] + (1u << mshift) - 1u) >> mshift;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float* sp = src + (size_t)i * stride;
         const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
@@ -782,38 +805,29 @@ __global__ __launch_bounds__(256) void roi_mark_kernel(const float* __restrict__
         }
         if (!ok) continue;      // a non-finite point lands nowhere
         const uint32_t m = roi_macro(h, mshift, c[0], c[1], c[2]);
-        if (mark[m] == 0) mark[m] = 1;
+        if (mark[m] & 2) continue;
+        mark[m] = 3;
+        const int x = c[0] >> mshift;
+        const int R = roi_radius(h, mshift, (uint32_t)x, (uint32_t)c[1] >> mshift, (uint32_t)c[2] >> mshift, T.m[12], T.m[13], T.m[14], base_m, per_m);
+        const int k0 = max(x - R, 0), k1 = min(x + R, (int)m0 - 1);
+        uint8_t* row = mark + ((size_t)m - (size_t)x);
+        for (int k = k0; k <= k1; ++k) if (row[k] == 0) row[k] = 1;
     }
 }
-// spread: a marked macro cell stands for points that a change of the pose can move by base_m metres (translation, and the reach of the
-// optimiser's neighbourhood) + per_m metres per metre of distance from the sensor (rotation: a far point moves by range x angle): every
-// macro cell within that Chebyshev radius of a mark belongs to the region.  Done as three 1-D passes (x, y, z), each a GATHER of radius
-// R(m) = r(m) + 1 evaluated at the OUTPUT cell -- the radius changes by at most one macro cell over its own reach (per_m * sqrt 3 * r < 1 for
-// r <= 11), so every cell the exact dilation holds is held (a few more are: harmless).  A scatter from the marks was 90 us (a handful of
-// lanes per wave walking cubes of hundreds of bytes); the three gathers read contiguous bytes.  The first pass clears the marks of the
-// NEXT call (two buffers, alternating, like NDT's candidate counters): no memset per call.
-static constexpr int kRoiMaxRadius = 11;      // macro cells (22 m at 2 m macro cells): the bound of the separable gather above (per_m * sqrt 3 * r < 1)
-__global__ __launch_bounds__(256) void roi_dilate_axis_kernel(const GridHeader* __restrict__ lat, const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                              uint8_t* __restrict__ clear_next, int axis, int mshift, double sx, double sy, double sz,
-                                                              double base_m, double per_m) {
+// one 1-D gather (axis 1 = y, 2 = z); clear_next (the y pass): the marks of the next call
+__global__ __launch_bounds__(256) void roi_spread_axis_kernel(const GridHeader* __restrict__ lat, const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                              uint8_t* __restrict__ clear_next, int axis, int mshift, double sx, double sy, double sz, double base_m, double per_m) {
     const GridHeader h = *lat;
     if (h.overflow || h.empty) return;
     const uint32_t m0 = ((uint32_t)h.dims[0] + (1u << mshift) - 1u) >> mshift, m1 = ((uint32_t)h.dims[1] + (1u << mshift) - 1u) >> mshift,
                    m2 = ((uint32_t)h.dims[2] + (1u << mshift) - 1u) >> mshift;
     const uint32_t total = m0 * m1 * m2;
-    const double edge = h.cell * (double)(1u << mshift);
     for (uint32_t m = blockIdx.x * 256 + threadIdx.x; m < total; m += gridDim.x * 256) {
         if (clear_next) clear_next[m] = 0;
         const uint32_t row = m / m0, x = m - row * m0, z = row / m1, y = row - z * m1;
-        // centre of the macro cell in metres: cell i of axis d spans [(org_d + shift + i) cell, + cell)
-        const double cx = (h.org[0] + h.shift) * h.cell + ((double)x + 0.5) * edge, cy = (h.org[1] + h.shift) * h.cell + ((double)y + 0.5) * edge,
-                     cz = (h.org[2] + h.shift) * h.cell + ((double)z + 0.5) * edge;
-        const double range = sqrt((cx - sx) * (cx - sx) + (cy - sy) * (cy - sy) + (cz - sz) * (cz - sz)) + 0.87 * edge;
-        double rr = ceil((base_m + per_m * range) / edge);
-        if (!(rr >= 1.0)) rr = 1.0;
-        const int R = (int)fmin(rr, (double)kRoiMaxRadius) + 1;
-        const int pos = axis == 0 ? (int)x : (axis == 1 ? (int)y : (int)z), len = axis == 0 ? (int)m0 : (axis == 1 ? (int)m1 : (int)m2);
-        const size_t step = axis == 0 ? 1u : (axis == 1 ? (size_t)m0 : (size_t)m0 * m1);
+        const int R = roi_radius(h, mshift, x, y, z, sx, sy, sz, base_m, per_m);
+        const int pos = axis == 1 ? (int)y : (int)z, len = axis == 1 ? (int)m1 : (int)m2;
+        const size_t step = axis == 1 ? (size_t)m0 : (size_t)m0 * m1;
         const int k0 = max(pos - R, 0), k1 = min(pos + R, len - 1);
         const uint8_t* p = in + ((size_t)m - (size_t)(pos - k0) * step);
         uint8_t any = 0;
@@ -823,15 +837,14 @@ __global__ __launch_bounds__(256) void roi_dilate_axis_kernel(const GridHeader* 
 }
 
 hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
-                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp_a, uint8_t* d_tmp_b, uint8_t* d_mask, double base_m, double per_m, hipStream_t s) {
+                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp, uint8_t* d_mask, double base_m, double per_m, hipStream_t s) {
     const int mb = (int)std::min<size_t>(1024, (n_src + 255) / 256 ? (n_src + 255) / 256 : 1);
-    hipLaunchKernelGGL(roi_mark_kernel, dim3(mb), dim3(256), 0, s, d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, lattice.header.as<GridHeader>(), d_mark, mshift);
+    hipLaunchKernelGGL(roi_mark_kernel, dim3(mb), dim3(256), 0, s, d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, lattice.header.as<GridHeader>(), d_mark, mshift, base_m, per_m);
     const size_t macros = (lattice.cell_capacity >> (3 * mshift)) + 1024;      // (an estimate is enough: the kernels stride)
     const int db = (int)std::min<size_t>(4096, (macros + 255) / 256);
     const GridHeader* hdr = lattice.header.as<GridHeader>();
-    hipLaunchKernelGGL(roi_dilate_axis_kernel, dim3(db), dim3(256), 0, s, hdr, (const uint8_t*)d_mark, d_tmp_a, d_mark_next, 0, mshift, T.m[12], T.m[13], T.m[14], base_m, per_m);
-    hipLaunchKernelGGL(roi_dilate_axis_kernel, dim3(db), dim3(256), 0, s, hdr, (const uint8_t*)d_tmp_a, d_tmp_b, (uint8_t*)nullptr, 1, mshift, T.m[12], T.m[13], T.m[14], base_m, per_m);
-    hipLaunchKernelGGL(roi_dilate_axis_kernel, dim3(db), dim3(256), 0, s, hdr, (const uint8_t*)d_tmp_b, d_mask, (uint8_t*)nullptr, 2, mshift, T.m[12], T.m[13], T.m[14], base_m, per_m);
+    hipLaunchKernelGGL(roi_spread_axis_kernel, dim3(db), dim3(256), 0, s, hdr, (const uint8_t*)d_mark, d_tmp, d_mark_next, 1, mshift, T.m[12], T.m[13], T.m[14], base_m, per_m);
+    hipLaunchKernelGGL(roi_spread_axis_kernel, dim3(db), dim3(256), 0, s, hdr, (const uint8_t*)d_tmp, d_mask, (uint8_t*)nullptr, 2, mshift, T.m[12], T.m[13], T.m[14], base_m, per_m);
     return hipGetLastError();
 }
 

@@ -284,7 +284,7 @@ __device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHe
 }
 #endif
 hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
-                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp_a, uint8_t* d_tmp_b, uint8_t* d_mask, double base_m, double per_m, hipStream_t s);
+                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp, uint8_t* d_mask, double base_m, double per_m, hipStream_t s);
 
 struct VgicpArgs {
     const float* src; uint32_t n_src, src_stride;
