@@ -164,6 +164,9 @@ struct pcr_handle {
     double clamp_margin = 10.0;      // LOAM ClampBox: room around the scan, doubled when a query reached a cut face
     // region of interest of a target prepared for one scan (RoiView): two marking buffers used alternately, the dilated mask, the escape counter
     DeviceBuf roi_mark[2], roi_tmp, roi_mask, roi_esc;
+    BlobStore blob;                  // the optimiser's initial state as a rider of the region's mark pass (pcr_internal.h: BlobStore)
+    bool blob_pending = false;       //   filled in by this call and not launched yet
+    bool blob_stored = false;        //   launched by this call: run_ndt needs no launch of its own for it
     int roi_idx = 0, roi_mshift = 0;
     uint64_t roi_cells_seen = 0;     // cell count of the lattice the mark buffers were last used with (a change clears them in full)
     bool roi_on = false;             // the target structures the handle holds cover only the region of the scan they were prepared for
@@ -873,8 +876,11 @@ int roi_enqueue(pcr_handle* h, const RoiScan& scan, double cell, double base_m, 
     Pose16 T;
     for (int i = 0; i < 16; ++i) T.m[i] = (double)(float)scan.pose[i];
     const int k = h->roi_idx;
+    const bool rider = h->blob_pending;
+    if (rider) h->blob.zero = h->roi_esc.as<uint32_t>();      // (the escape counter starts at zero with the state)
     H_TRY(roi_launch(h->grid, scan.d_src, scan.n_src, scan.stride_floats, T, ms, h->roi_mark[k].as<uint8_t>(), h->roi_mark[k ^ 1].as<uint8_t>(),
-                     h->roi_tmp.as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream));
+                     h->roi_tmp.as<uint8_t>(), h->roi_mask.as<uint8_t>(), base_m, kRoiPerMetre, h->stream, rider ? &h->blob : nullptr));
+    if (rider) { h->blob_pending = false; h->blob_stored = true; }
     h->roi_idx ^= 1;
     view->lat = h->grid.header.as<GridHeader>(); view->mask = h->roi_mask.as<uint8_t>(); view->escapes = h->roi_esc.as<uint32_t>();
     view->mshift = ms; view->filtered = 0; view->count = prof_counters(h);
@@ -1241,6 +1247,15 @@ void euler_xyz(const float R[9], float out[3]) {
 struct NdtRun {
     pcr_handle* h; NdtArgs a; NdtPose T; NdtAngles ang;
 };
+// the guess as the optimiser starts from it: handed over as Matrix4f (NdtRegister.cpp:27), its Euler angles as the parameters
+void ndt_initial_pose(const double pose[16], NdtPose* T0, double p0[6]) {
+    float G[16];
+    for (int i = 0; i < 16; ++i) G[i] = (float)pose[i];
+    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) T0->R[rr * 3 + c] = G[c * 4 + rr]; T0->t[rr] = G[12 + rr]; }
+    float eul[3];
+    ndt_host::euler_xyz(T0->R, eul);     // Transform::rotation() taken as the linear part
+    p0[0] = T0->t[0]; p0[1] = T0->t[1]; p0[2] = T0->t[2]; p0[3] = eul[0]; p0[4] = eul[1]; p0[5] = eul[2];
+}
 
 // computeDerivatives at parameters p with the cloud transformed by T: score, gradient, Hessian
 int ndt_derivatives(NdtRun* r, const double p[6], bool compute_hessian, double* score, double grad[6], double hess[36]) {
@@ -1304,14 +1319,9 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         r.a.d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / r.a.d1);
     }
     h->nd_iters = h->nd_deriv = h->nd_hess = 0;
-    // guess handed over as Matrix4f (NdtRegister.cpp:27)
-    float G[16];
-    for (int i = 0; i < 16; ++i) G[i] = (float)pose[i];
     NdtPose T0;
-    for (int rr = 0; rr < 3; ++rr) { for (int c = 0; c < 3; ++c) T0.R[rr * 3 + c] = G[c * 4 + rr]; T0.t[rr] = G[12 + rr]; }
-    float eul[3];
-    euler_xyz(T0.R, eul);     // Transform::rotation() taken as the linear part
-    const double p0[6] = {T0.t[0], T0.t[1], T0.t[2], eul[0], eul[1], eul[2]};
+    double p0[6];
+    ndt_initial_pose(pose, &T0, p0);
 
     NdtPose final_T = T0;
     int conv = 0, nr_it = 0;
@@ -1363,8 +1373,11 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         NdtOut* out = h->nd_out_host;
         h->seq += 1.0;
         const double seq = h->seq;
-        H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats,
-                                  r.a.roi_escapes));
+        // (a scan2map call whose region was marked has stored this state with the mark pass: do_scan2map, BlobStore)
+        const bool stored = h->blob_stored && h->roi_on;
+        h->blob_stored = false;
+        if (!stored) H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats,
+                                               r.a.roi_escapes));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 5;        // an iteration takes at most 1 + 10 + 1 passes; one launch more finishes
         if ((double)limit >= kProgressWindow) return fail(h, "ndt_max_iters exceeds the device loop's pass window (2^20 passes)");
         int enq = 0;
@@ -1487,9 +1500,21 @@ int do_scan2map(pcr_handle* h, const void* src, size_t n_src, const void* dst, s
         const RoiScan rs{d_src, n_src, stride_bytes / 4, pose_in};
         for (int attempt = 0; attempt < 3; ++attempt) {
             const bool deferred = try_deferred && attempt == 0;
-            if (agree_prepared(h, ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4, deferred, use_roi ? &rs : nullptr))) return 1;
+            h->blob_pending = h->blob_stored = false;
+            if (use_roi) {      // the optimiser's initial state rides on the launch that marks the region (run_ndt then starts without a launch for it)
+                NdtPose T0;
+                double p0[6];
+                ndt_initial_pose(pose, &T0, p0);
+                H_TRY(h->nd_ctl.reserve(2 * sizeof(NdtCtl)));
+                ndt_ctl_init_blob(&h->blob, h->nd_ctl.as<NdtCtl>(), T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->prm.ndt_evaluate_repeats);
+                h->blob_pending = true;
+            }
+            const int prep_rc = ndt_prepare_target(h, d_dst, n_dst, stride_bytes / 4, deferred, use_roi ? &rs : nullptr);
+            h->blob_pending = false;
+            if (agree_prepared(h, prep_rc)) { h->blob_stored = false; return 1; }
             if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_index, h->stream));
             const int rrc = run_ndt(h, d_src, n_src, stride_bytes / 4, pose, converged);
+            h->blob_stored = false;
             if (rrc == 2) { use_roi = false; memcpy(pose, pose_in, sizeof pose_in); if (deferred && h->nd_grid_checked && !h->nd_grid_bad && !h->nd_grid_empty) { h->grid.confirm(); h->grid.note_cells(h->nd_grid_cells); } continue; }
             if (rrc) return 1;
             if (!deferred) break;

@@ -787,7 +787,12 @@ __device__ __forceinline__ int roi_radius(const GridHeader& h, int mshift, uint3
     return (int)fmin(rr, (double)kRoiMaxRadius) + 1;
 }
 __global__ __launch_bounds__(256) void roi_mark_kernel(const float* __restrict__ src, uint32_t n, uint32_t stride, const Pose16 T, const GridHeader* __restrict__ lat,
-                                                       uint8_t* __restrict__ mark, int mshift, double base_m, double per_m) {
+                                                       uint8_t* __restrict__ mark, int mshift, double base_m, double per_m, const BlobStore blob) {
+    // (a rider: words for a later launch on this stream, stored by the last block whatever the header says -- pcr_internal.h: BlobStore)
+    if (blob.n && blockIdx.x == gridDim.x - 1) {
+        for (uint32_t t = threadIdx.x; t < blob.n; t += 256) blob.dst[t] = blob.w[t];
+        if (blob.zero && threadIdx.x == 0) *blob.zero = 0u;
+    }
     const GridHeader h = *lat;
     if (h.overflow || h.empty || h.stale) return;
     const uint32_t m0 = ((uint32_t)h.dims[0] + (1u << mshift) - 1u) >> mshift;
@@ -837,9 +842,11 @@ __global__ __launch_bounds__(256) void roi_spread_axis_kernel(const GridHeader* 
 }
 
 hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
-                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp, uint8_t* d_mask, double base_m, double per_m, hipStream_t s) {
+                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp, uint8_t* d_mask, double base_m, double per_m, hipStream_t s, const BlobStore* blob) {
     const int mb = (int)std::min<size_t>(1024, (n_src + 255) / 256 ? (n_src + 255) / 256 : 1);
-    hipLaunchKernelGGL(roi_mark_kernel, dim3(mb), dim3(256), 0, s, d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, lattice.header.as<GridHeader>(), d_mark, mshift, base_m, per_m);
+    static BlobStore no_blob;      // (zero-initialised: n = 0)
+    hipLaunchKernelGGL(roi_mark_kernel, dim3(mb), dim3(256), 0, s, d_src, (uint32_t)n_src, (uint32_t)stride_floats, T, lattice.header.as<GridHeader>(), d_mark, mshift, base_m, per_m,
+                       blob ? *blob : no_blob);
     const size_t macros = (lattice.cell_capacity >> (3 * mshift)) + 1024;      // (an estimate is enough: the kernels stride)
     const int db = (int)std::min<size_t>(4096, (macros + 255) / 256);
     const GridHeader* hdr = lattice.header.as<GridHeader>();

@@ -1060,18 +1060,29 @@ hipError_t ndt_launch_derivatives(const NdtArgs& a, const NdtPose& T, const NdtA
     return hipGetLastError();
 }
 
+static void ndt_initial_ctl(NdtCtl* c, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, int no_replay_arg) {
+    static_assert(sizeof(NdtCtl) % 4 == 0, "NdtCtl is copied word by word");
+    memset(c, 0, sizeof *c);
+    ndt_opt::ctl_init(c, T0, p, step_size, trans_eps, max_iters);
+    static const bool no_replay = dev_env("PCR_NDT_NO_REPLAY") != nullptr;
+    c->replay_off = (no_replay || no_replay_arg) ? 1 : 0;
+}
 hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay_arg,
                                uint32_t* d_roi_escapes) {
-    static_assert(sizeof(NdtCtl) % 4 == 0, "NdtCtl is copied word by word");
     NdtCtl c;
-    memset(&c, 0, sizeof c);
-    ndt_opt::ctl_init(&c, T0, p, step_size, trans_eps, max_iters);
-    static const bool no_replay = dev_env("PCR_NDT_NO_REPLAY") != nullptr;
-    c.replay_off = (no_replay || no_replay_arg) ? 1 : 0;
+    ndt_initial_ctl(&c, T0, p, step_size, trans_eps, max_iters, no_replay_arg);
     NdtCtlArg a;
     memcpy(a.w, &c, sizeof c);
     hipLaunchKernelGGL(ndt_ctl_store_kernel, dim3(1), dim3(512), 0, s, d_ctl, a, d_roi_escapes);
     return hipGetLastError();
+}
+// the same state as a rider of another launch (pcr_internal.h: BlobStore; `zero` = the escape counter is filled in by whoever launches it)
+void ndt_ctl_init_blob(BlobStore* b, NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, int no_replay_arg) {
+    static_assert(sizeof(NdtCtl) <= sizeof(b->w), "NdtCtl must fit a BlobStore");
+    NdtCtl c;
+    ndt_initial_ctl(&c, T0, p, step_size, trans_eps, max_iters, no_replay_arg);
+    memcpy(b->w, &c, sizeof c);
+    b->dst = reinterpret_cast<uint32_t*>(d_ctl); b->zero = nullptr; b->n = (uint32_t)(sizeof c / 4); b->pad = 0;
 }
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq) {
     const uint32_t nb = ndt_blocks(a.n_src);

@@ -283,8 +283,13 @@ __device__ __forceinline__ bool roi_holds_point(const RoiView& roi, const GridHe
     return roi.mask[roi_macro(lat, roi.mshift, (int)fx, (int)fy, (int)fz)] != 0;
 }
 #endif
+// A few hundred words a kernel stores on the side for a later launch on its stream: the initial state of NDT's device-resident optimiser rides
+// on the first launch of its call (the region's mark pass).  A launch of its own cost ~5 us -- a kernel reads its argument block over PCIe --
+// and ~2 us of gap, on a stream where nothing else could run meanwhile.
+struct BlobStore { uint32_t* dst; uint32_t* zero; uint32_t n; uint32_t pad; uint32_t w[416]; };
 hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src, size_t stride_floats, const Pose16& T, int mshift,
-                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp, uint8_t* d_mask, double base_m, double per_m, hipStream_t s);
+                      uint8_t* d_mark, uint8_t* d_mark_next, uint8_t* d_tmp, uint8_t* d_mask, double base_m, double per_m, hipStream_t s,
+                      const BlobStore* blob = nullptr);
 
 struct VgicpArgs {
     const float* src; uint32_t n_src, src_stride;
@@ -377,6 +382,7 @@ struct NdtCtl;
 struct NdtOut;
 hipError_t ndt_launch_ctl_init(NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, hipStream_t s, int no_replay = 0,
                                uint32_t* d_roi_escapes = nullptr);
+void ndt_ctl_init_blob(BlobStore* b, NdtCtl* d_ctl, const NdtPose& T0, const double p[6], double step_size, double trans_eps, int max_iters, int no_replay_arg);
 hipError_t ndt_launch_pass(const NdtArgs& a, NdtCtl* d_ctl, NdtOut* d_out, hipStream_t s, double seq);
 hipError_t ndt_launch_pass_pro(const NdtArgs& a, NdtCtl* d_ctl2, double* d_rows2, NdtOut* d_out, hipStream_t s, double seq, int index,
                                hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
