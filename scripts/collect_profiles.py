@@ -82,7 +82,8 @@ for m in ("vgicp", "ndt"):
     fm, wm = means(f"pmc_fetch_{m}/**/*counter_collection.csv"), means(f"pmc_write_{m}/**/*counter_collection.csv")
     if not fm or not wm:
         continue
-    scans = next((v["FETCH_SIZE"][1] for k, v in fm.items() if "ctl_store" in k), 0)
+    # one call = one launch of the kernel that builds the voxels (the optimiser's initial state no longer has a launch of its own in NDT)
+    scans = next((v["FETCH_SIZE"][1] for k, v in fm.items() if "ctl_store" in k and m == "vgicp"), 0) or next((v["FETCH_SIZE"][1] for k, v in fm.items() if "_voxel_kernel" in k), 0)
     rows, prep, total = [], 0.0, 0.0
     for k in sorted(set(fm) | set(wm)):
         f_kib, n = fm.get(k, {}).get("FETCH_SIZE", (0.0, 0))
