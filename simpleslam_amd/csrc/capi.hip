@@ -903,7 +903,6 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     if (h->prm.vgicp_k_corr != 20) return fail(h, "this build supports vgicp_k_corr = 20 (the reference's value) only");
     if (!keep_clamp) h->clamp.use = 0;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats;
-    // (unsharded: a cloud too spread out for dense tables is cut to its bulk, settle_cov_levels; a rank of a sharded call refuses it)
     static const bool no_ahead = dev_env("PCR_COV_NO_AHEAD") != nullptr;      // (A/B runs)
     static const bool no_early = dev_env("PCR_COV_NO_EARLY") != nullptr;
     bool ahead_ok = false;
@@ -935,7 +934,9 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     const std::function<int()> early = [&]() -> int { return enqueue_rest(&h->cov_l1); };
     bool early_clean = false;
     const bool try_early = want_roi && !no_early && ahead_cell > 0.0 && !h->clamp.use;
-    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, !sharded(h), ahead_cell, &ahead_ok,
+    // (may_cut: a cloud too spread out for dense tables -- a stray point kilometres off -- is indexed over its bulk.  A rank of a sharded call
+    //  too: its cloud is its own, the cut is its own decision, and a scan that reaches the cut fails the call on EVERY rank, run_vgicp)
+    if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, true, ahead_cell, &ahead_ok,
                           try_early ? &early : nullptr, &early_clean, before_wait)) return 1;
     if (h->clamp.use) { ahead_ok = false; early_clean = false; }      // (the target was cut to its bulk in there: the grid built ahead covers the uncut cloud)
     h->have_target = true;
@@ -1101,14 +1102,15 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         x0 = c.x0; conv = c.conv != 0;
         h->vg_outer = c.outer; h->vg_lin = c.n_lin; h->vg_err = c.n_err;
     }
+    uint32_t esc = 0;
     if (a.escapes) {
-        uint32_t esc = 0;
         H_TRY(hipMemcpyAsync(&esc, a.escapes, sizeof esc, hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
         // the scan reaches (the reach of a covariance of) a face the index was cut at: 3 -- the caller cuts the target around THIS scan
-        // and repeats (vgicp_align_recut); a rank of a sharded call cannot (its peers would be left in their collectives)
-        if (esc) { h->err = "the target is too spread out for the dense voxel tables (a stray point far from the map?) and was cut to its bulk, but the scan reaches "
-                            "the part that was left out"; return 3; }
+        // and repeats (vgicp_align_recut).  A rank of a sharded call cannot, and must not leave either (its peers would wait in their
+        // next collective): the count travels with the fitness sums below and every rank fails the call.
+        if (esc && !shard) { h->err = "the target is too spread out for the dense voxel tables (a stray point far from the map?) and was cut to its bulk, but the scan reaches "
+                                      "the part that was left out"; return 3; }
     }
     for (int i = 0; i < 16; ++i) pose[i] = (double)(float)x0.m[i];     // final_transformation_ is a Matrix4f
     if (converged) *converged = conv ? 1 : 0;
@@ -1132,7 +1134,10 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     H_TRY(fitness_launch(h->grid, d_src, n_src, stride_floats, pose, 1.7976931348623157e308, h->vg_partials.as<double>(), h->out32_dev, h->stream, h->seq,
                          h->use_tile ? &ft : nullptr));
     if (wait_result(h, &h->out32_host[31], h->seq)) return 1;
-    if (shard && ranks_allreduce(h, h->out32_host, 3)) return 1;
+    h->out32_host[3] = (double)esc;      // (this rank's scan points that reached a cut face of its index)
+    if (shard && ranks_allreduce(h, h->out32_host, 4)) return 1;
+    if (h->out32_host[3] > 0) { h->err = "a rank's target is too spread out for the dense voxel tables (a stray point far from the map?) and was cut to its bulk, but the scan reaches "
+                                         "the part that was left out"; return 3; }
     h->fitness = h->out32_host[1] > 0 ? h->out32_host[0] / h->out32_host[1] : 1.7976931348623157e308;
     // sharded: a source point farther from every map point than its rank's halo has its nearest neighbour on another rank; the
     // score is then not the map's and is reported as unavailable (the pose is unaffected)

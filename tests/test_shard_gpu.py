@@ -213,6 +213,38 @@ def test_vgicp_sharded_equals_unsharded(gpu, vg_w, n_ranks):
     assert dt <= 1e-4 and dr <= 1e-4
 
 
+def test_vgicp_sharded_with_a_far_outlier_in_the_map(gpu, vg_w):
+    """One stray point 20 km away lands in an edge rank's cloud (the outer tiles are open) and makes THAT rank's voxel lattice too large
+    for dense tables; the reference's hash map does not care (fast_vgicp_voxel.hpp:129-156).  The rank indexes the bulk of its own cloud,
+    as an unsharded handle does (test_vgicp_gpu.py::test_far_outlier_in_the_target): the stray point is in nobody's 20-neighbourhood and
+    in no voxel the scan visits, so every rank returns the unsharded pose.  A scan placed AT the stray point reaches the part that was
+    left out: the count travels with the ranks' fitness sums and ALL ranks fail the call together (none is left in a collective)."""
+    w = vg_w
+    kw = dict(vgicp_resolution=0.5)
+    m = w["map"].copy()
+    m[0, :3] = [2.0e4, -1.0e4, 2857.0]
+    poses, convs, regs, errs, tiles = run_ranks("vgicp", 2, w["scan"], w["init"], m, resolution=0.5, **kw)
+    assert errs == [None] * 2, errs
+    assert max(t.points[:, 0].max() for t in tiles) >= 2.0e4      # the stray point did go to a rank
+    _all_equal(poses)
+    r0 = VgicpRegister(**kw)
+    ref = w["init"].copy()
+    c_ref = r0.scan2Map(w["scan"], m, ref)
+    assert convs == [c_ref] * 2
+    assert [r.stats()["iterations"] for r in regs] == [r0.stats()["iterations"]] * 2
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 2e-6 and dr <= 2e-7, (dt, dr)
+    po, co, _ = oracle.vgicp_scan2map(w["scan"], m, w["init"], oracle.vgicp_params(resolution=0.5, threads=16))
+    dt, dr = synth.pose_error(poses[0], po)
+    assert co == convs[0] and dt <= 1e-4 and dr <= 1e-4
+    # the scan moved onto the stray point
+    there = w["init"].copy()
+    there[:3, 3] += m[0, :3].astype(np.float64) - w["truth"][:3, 3]
+    poses, convs, regs, errs, _ = run_ranks("vgicp", 2, w["scan"], there, m, resolution=0.5, **kw)
+    assert all(isinstance(e, pcr.PcrError) for e in errs), errs
+    assert all("left out" in str(e) for e in errs), errs
+
+
 def test_vgicp_halo_too_small_fails_on_every_rank(gpu, vg_w):
     """A halo that does not hold the 20 nearest neighbours of the tile's points would change their covariances
     (fast_gicp_impl.hpp:253): the device check finds them, and ALL ranks fail the call together (none is left in a collective)."""
