@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start, uint32_t* __restrict__ lay_next,
                                                        const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
-                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift, const TilePlan plan) {
+                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift) {
     // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
     // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
@@ -401,15 +401,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     DEV_STAMP(0, 0);
     const GridHeader h = *hdr;
     if (h.overflow || h.empty) return;
-    // plan (kPlace only; pcr_internal.h: TilePlan): the tile of a point comes from the table the previous build left -- tiles of about equal
-    // point count -- instead of key >> shift
-    const bool planned = kPlace && plan.n_tiles != nullptr;
-    uint32_t nbins_h = (uint32_t)(h.n_cells >> shift) + 1u;
-    if (planned) {
-        nbins_h = *plan.n_tiles;
-        // (a plan that could not be made, or more tiles than this launch has counters for: neither happens by construction; build afresh)
-        if (nbins_h == 0u || nbins_h > max_bins) { if (threadIdx.x == 0) hdr->stale = 1; return; }
-    }
+    const uint32_t nbins_h = (uint32_t)(h.n_cells >> shift) + 1u;
     for (uint32_t b = threadIdx.x; b < max_bins; b += 256) hist[b] = 0u;
     if (kPlace) { for (uint32_t b = threadIdx.x; b <= max_bins; b += 256) sh_lay[b] = b <= nbins_h ? lay_cur[b] : 0u; }
     __syncthreads();
@@ -428,19 +420,11 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         for (int u = 0; u < kBinPer; ++u) {
             const uint32_t i = c0 + u * 256 + threadIdx.x;
             uint32_t key;
-            bin[u] = 0xffffffffu;
+            bin[u] = 0xffffffffu; loc[u] = 0u;
             bool outside = false;
             if (i < n && point_key(h, px[u], py[u], pz[u], &key, &outside) && (!kPlace || !keep_mask || roi_mask_holds_cell(h, keep_mask, keep_mshift, key)))
-                bin[u] = planned ? key >> kPlanSlabShift : key >> shift;
+                bin[u] = key >> shift;
             if (outside && !h.clamped) hdr->stale = 1;      // (only a box reused from the previous build can be too small)
-        }
-        if (planned) {      // slab -> tile: the chunk's lookups in flight together (a 16-bit table of a few thousand entries, L2-resident)
-#pragma unroll
-            for (int u = 0; u < kBinPer; ++u) if (bin[u] != 0xffffffffu) bin[u] = plan.slab_tile[bin[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < kBinPer; ++u) {
-            loc[u] = 0u;
             // one LDS atomic per RUN of equal tiles in consecutive lanes (a cloud stored in a spatially coherent order puts
             // whole waves into one tile: 64 same-address atomics would serialise)
             const uint32_t prev = __shfl_up(bin[u], 1, 64);
@@ -505,7 +489,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     __syncthreads();
     DEV_STAMP(0, 5);
     if (!sh_last) return;
-    const uint32_t nbins = nbins_h;
+    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
     const uint32_t per = (nbins + 255u) / 256u;      // <= kMaxBins / 256 = 32
     const uint32_t b0 = threadIdx.x * per;
     uint32_t c[kMaxBins / 256];
@@ -597,8 +581,7 @@ template <int kTilePer, int kMode, int kThreads, bool kTail = false>
 __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
                                                         float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
-                                                        const uint32_t* __restrict__ src_start, const TileTail tail, const TilePlan plan,
-                                                        uint32_t* __restrict__ slab_count) {
+                                                        const uint32_t* __restrict__ src_start, const TileTail tail) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;                    // 1 << shift
     __shared__ uint32_t sh4[kThreads / 64];
@@ -610,10 +593,8 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
     if (kTail && h.empty && !h.overflow)      // nothing indexed: no cell carries a voxel
         for (uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x; t < h.n_cells; t += (uint64_t)gridDim.x * kThreads) tail.vox_slot[t] = 0u;
     if (h.overflow || h.empty) return;
-    // plan (pcr_internal.h: TilePlan): tile t = the cells [tile_cell0[t], tile_cell0[t + 1]) -- whole slabs of 256, at most kPlanMaxCells;
-    // slab_count (optional; tiles start on slab boundaries): the points of every slab, for grid_plan_kernel
-    uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
-    if (plan.n_tiles) nbins = *plan.n_tiles;      // (0 = no plan could be made: the bin pass has raised header.stale)
+    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
+    const uint32_t S = 1u << shift;
     if (h.stale) {
         // a hint did not hold (points outside the box, or a tile without room: not every point was stored): nothing here can be
         // trusted and the caller rebuilds.  Only the counters are put back to zero, the state every build expects.
@@ -625,12 +606,9 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
         //  tile's own 24 us wherever it starts, and the extra scan cost the bin kernel's serial tail 3 us; profiles/r04_notes.md)
         const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
         const uint32_t q0 = src_start[tile];      // first point of the tile in `tiled`
-        uint64_t cell0 = (uint64_t)tile << shift;
-        uint32_t S = 1u << shift;
-        if (plan.n_tiles) { cell0 = plan.tile_cell0[tile]; S = plan.tile_cell0[tile + 1] - (uint32_t)cell0; }
+        const uint64_t cell0 = (uint64_t)tile << shift;
         if (kMode == 1 && np > 256u) continue;          // (block-uniform: the other instantiation's tile)
         if (kMode == 2 && np <= 256u) continue;
-        if (S == 0u) { if (threadIdx.x == 0) tile_sq[tile] = 0ull; continue; }      // (a tile number the plan skipped: no cells, no points)
         const bool small = np <= (uint32_t)kThreads * kTilePer;      // block-uniform
         float4 p[kTilePer];
         uint32_t cr[kTilePer];
@@ -704,9 +682,6 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
             sq += (unsigned long long)v.x * v.x + (unsigned long long)v.y * v.y + (unsigned long long)v.z * v.z + (unsigned long long)v.w * v.w;
             uint32_t tot;
             const uint32_t o = block_exclusive_scan<kThreads>(v.x + v.y + v.z + v.w, &tot, sh4) + carry;
-            // (a wave's four cells per lane are one slab of 256: its points, left in sh4 by the scan)
-            if (slab_count && (threadIdx.x & 63) == 0 && cb + (threadIdx.x >> 6) * 256u < S)
-                slab_count[(((uint32_t)cell0 + cb) >> kPlanSlabShift) + (threadIdx.x >> 6)] = sh4[threadIdx.x >> 6];
             __syncthreads();      // sh4 is reused by the next round
             if (c < S) {
                 const uint4 st = make_uint4(o, o + v.x, o + v.x + v.y, o + v.x + v.y + v.z);
@@ -772,85 +747,11 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
     DEV_STAMP(1, 4);
 }
 
-// The plan of the NEXT build's tiles, from the points per slab this build has counted (one block).  A tile ends where the running sum of
-// points / P + cells / C passes an integer (32.32 fixed point: w_point = 2^32 / P per point, w_slab = 2^32 * 256 / C per slab): no tile
-// holds more than P points + one slab's, none more than C + 256 cells, tiles are runs of whole slabs in cell order -- so the sorted cloud
-// and the cell table come out exactly as with uniform tiles -- and the crowded ground of a lidar map no longer puts 5 600 points (10 M-point
-// map: 23 000) into ONE block's tile while most blocks hold a few hundred.  Written with it: the layout of the next build (where each of THESE
-// tiles' points go, an eighth more room than they hold now + 32), which replaces the one the bin pass derived for the tiles of this build.
-// plan_words: [0] number of tiles (0: could not be made -- more than max_tiles), [8 ..] first cell of every tile (+ the end), then slab -> tile.
-template <class T>
-__device__ inline T block_exclusive_scan_1024(T v, T* total, T* sh /* >= 16 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const T t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    if (lane == 63) sh[wave] = inc;
-    __syncthreads();
-    T off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const T x = sh[w]; if (w < wave) off += x; tot += x; }
-    *total = tot;
-    __syncthreads();
-    return off + inc - v;
-}
-__global__ __launch_bounds__(1024) void grid_plan_kernel(const GridHeader* __restrict__ hdr, const uint32_t* __restrict__ slab_count, uint32_t* __restrict__ plan_words,
-                                                         uint32_t* __restrict__ lay_next, unsigned long long w_point, unsigned long long w_slab, uint32_t max_tiles) {
-    __shared__ unsigned long long sh_w[16];
-    __shared__ uint32_t sh_c[16];
-    __shared__ uint32_t sh_pstart[kMaxBins + 8];      // points before every tile
-    __shared__ uint32_t sh_ntiles, sh_bad;
-    uint32_t* const tile_cell0 = plan_words + kPlanHeaderWords;
-    uint16_t* const slab_tile = reinterpret_cast<uint16_t*>(plan_words + kPlanHeaderWords + kMaxBins + 8);
-    const GridHeader h = *hdr;
-    const uint32_t t = threadIdx.x;
-    const uint32_t n_slabs = (uint32_t)(h.n_cells >> kPlanSlabShift) + 1u;
-    if (h.overflow || h.empty || h.stale || n_slabs > kPlanMaxSlabs || max_tiles > (uint32_t)kMaxBins) { if (t == 0) plan_words[0] = 0u; return; }
-    if (t == 0) { sh_ntiles = 0u; sh_bad = 0u; }
-    const uint32_t per = (n_slabs + 1023u) / 1024u;      // <= 128
-    const uint32_t s0 = min(t * per, n_slabs), s1 = min(s0 + per, n_slabs);
-    unsigned long long wsum = 0;
-    uint32_t csum = 0;
-    for (uint32_t s = s0; s < s1; ++s) { const uint32_t c = slab_count[s]; wsum += (unsigned long long)c * w_point + w_slab; csum += c; }
-    unsigned long long wtot;
-    uint32_t ctot;
-    unsigned long long E = block_exclusive_scan_1024<unsigned long long>(wsum, &wtot, sh_w);
-    uint32_t C = block_exclusive_scan_1024<uint32_t>(csum, &ctot, sh_c);
-    if (s0 < s1) {
-        // the tile of the slab before this thread's first (0xffffffff: there is none)
-        uint32_t prev = s0 == 0u ? 0xffffffffu : (uint32_t)((E - ((unsigned long long)slab_count[s0 - 1] * w_point + w_slab)) >> 32);
-        if (prev != 0xffffffffu && prev >= max_tiles) prev = max_tiles - 1u;
-        for (uint32_t s = s0; s < s1; ++s) {
-            const uint32_t c = slab_count[s];
-            uint32_t tile = (uint32_t)(E >> 32);
-            if (tile >= max_tiles) { tile = max_tiles - 1u; sh_bad = 1u; }
-            slab_tile[s] = (uint16_t)tile;
-            if (tile != prev)      // tile numbers the sum jumped over get no cells and no points
-                for (uint32_t u = prev + 1u; u <= tile; ++u) { tile_cell0[u] = s << kPlanSlabShift; sh_pstart[u] = C; }
-            prev = tile;
-            E += (unsigned long long)c * w_point + w_slab; C += c;
-        }
-        if (s1 == n_slabs) { sh_ntiles = prev + 1u; tile_cell0[prev + 1u] = n_slabs << kPlanSlabShift; sh_pstart[prev + 1u] = C; }
-    }
-    __syncthreads();
-    const uint32_t n_tiles = sh_ntiles;
-    // the layout: tile u gets room for an eighth more points than it holds now, + 32
-    const uint32_t per2 = (n_tiles + 1023u) / 1024u;      // <= 8
-    const uint32_t u0 = min(t * per2, n_tiles), u1 = min(u0 + per2, n_tiles);
-    uint32_t room = 0;
-    for (uint32_t u = u0; u < u1; ++u) { const uint32_t c = sh_pstart[u + 1u] - sh_pstart[u]; room += c + (c >> 3) + 32u; }
-    uint32_t room_total;
-    uint32_t lo = block_exclusive_scan_1024<uint32_t>(room, &room_total, sh_c);
-    for (uint32_t u = u0; u < u1; ++u) { const uint32_t c = sh_pstart[u + 1u] - sh_pstart[u]; lay_next[u] = lo; lo += c + (c >> 3) + 32u; }
-    if (t == 0) { lay_next[n_tiles] = room_total; plan_words[0] = sh_bad ? 0u : n_tiles; }
-}
-
 // sum of count^2 over the cells = sum of the tiles' sums -> header (only VGICP's choice of a search cell reads it)
-__global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restrict__ hdr, const unsigned long long* __restrict__ tile_sq, int shift,
-                                                           const uint32_t* __restrict__ plan_n_tiles) {
+__global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restrict__ hdr, const unsigned long long* __restrict__ tile_sq, int shift) {
     __shared__ unsigned long long sh[4];
     if (hdr->overflow || hdr->empty) return;
-    const uint32_t nbins = plan_n_tiles ? *plan_n_tiles : (uint32_t)(hdr->n_cells >> shift) + 1u;
+    const uint32_t nbins = (uint32_t)(hdr->n_cells >> shift) + 1u;
     unsigned long long s = 0;
     for (uint32_t b = threadIdx.x; b < nbins; b += 256) s += tile_sq[b];
 #pragma unroll
@@ -957,9 +858,7 @@ hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src
 // ---- host side ----------------------------------------------------------------------
 hipError_t GridIndex::enqueue_density(hipStream_t s) {
     if (tiled_shift < 0) return hipSuccess;      // the atomic build path leaves its estimate in header.sum_sq
-    // (the plan the LAST build used goes with the other layout buffer: build() has flipped lay_idx since, unless that build was one of a region)
-    const uint32_t* plan_tiles = used_plan ? plan[filtered ? lay_idx : lay_idx ^ 1].as<uint32_t>() : nullptr;
-    hipLaunchKernelGGL(grid_density_kernel, dim3(1), dim3(256), 0, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), tiled_shift, plan_tiles);
+    hipLaunchKernelGGL(grid_density_kernel, dim3(1), dim3(256), 0, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), tiled_shift);
     return hipGetLastError();
 }
 
@@ -981,7 +880,6 @@ void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
     bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
     tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); layout[0].release(); layout[1].release(); lay_ok = false;
-    plan[0].release(); plan[1].release(); slab_count.release(); lay_has_plan = false; plan_max_tiles = 0;
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -1095,14 +993,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     // ~2048 tiles when the table allows it -- 8 KB of LDS counters per block in the bin kernel, tiles of a few hundred to a few
     // thousand points -- never more than kMaxBins.
     if (tiled_path) {
-        // Layout hint (see grid_bin_kernel<.., kPlace>): the previous build of this index left, next to its header, where each tile's
-        // points may go; a build that reuses the header places by it and skips the placing pass.  PCR_INDEX_NO_LAYOUT=1 switches it off.
-        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && dev_env("PCR_INDEX_NO_LAYOUT") == nullptr;
-        // Tile plan (grid_plan_kernel): made by every full build whose grid it fits, used by the next build that places by the layout made with it
-        const bool plan_possible = tshift >= kPlanSlabShift && ((uint64_t)cap_eff >> kPlanSlabShift) + 2 <= kPlanMaxSlabs && !no_hints && dev_env("PCR_NO_PLAN") == nullptr;
-        const bool use_plan = use_layout && lay_has_plan && plan_possible && plan_max_tiles > 0;
-        used_plan = use_plan;
-        const uint32_t max_bins = use_plan ? plan_max_tiles + 2u : (uint32_t)(((uint64_t)cap_eff >> tshift) + 2);
+        const uint32_t max_bins = (uint32_t)(((uint64_t)cap_eff >> tshift) + 2);
         PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
         PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));
@@ -1118,17 +1009,11 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const int bin_blocks = (int)std::min<size_t>(4096, (n + bin_chunk - 1) / bin_chunk ? (n + bin_chunk - 1) / bin_chunk : 1);
         const int place_blocks = (int)std::min<size_t>(2048, (n + 1023) / 1024 ? (n + 1023) / 1024 : 1);
         const int tile_blocks = (int)max_bins;
+        // Layout hint (see grid_bin_kernel<.., kPlace>): the previous build of this index left, next to its header, where each tile's
+        // points may go; a build that reuses the header places by it and skips the placing pass.  PCR_INDEX_NO_LAYOUT=1 switches it off.
+        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && dev_env("PCR_INDEX_NO_LAYOUT") == nullptr;
         PCR_TRY(layout[0].reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(layout[1].reserve((kMaxBins + 8) * sizeof(uint32_t)));
-        if (plan_possible) {
-            const size_t plan_bytes = (size_t)(kPlanHeaderWords + kMaxBins + 8) * sizeof(uint32_t) + (size_t)kPlanMaxSlabs * sizeof(uint16_t);
-            PCR_TRY(plan[0].reserve(plan_bytes));
-            PCR_TRY(plan[1].reserve(plan_bytes));
-            PCR_TRY(slab_count.reserve((size_t)kPlanMaxSlabs * sizeof(uint32_t)));
-        }
-        TilePlan plan_cur;
-        memset(&plan_cur, 0, sizeof plan_cur);
-        if (use_plan) plan_cur = plan_view(lay_idx);
         if (use_layout) {      // room for every tile's slack (the device also checks every store against the capacity it is told)
             const size_t need = lay_n + lay_n / 8 + (size_t)32 * (max_bins + 1) + 16;
             if (need > n + 16) PCR_TRY(tiled.reserve(need * sizeof(float4)));
@@ -1144,11 +1029,10 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
             keep_mask = filter->mask; keep_mshift = filter->mshift;
             filter->applied = filtered = keep_mask != nullptr;
         }
-        const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4,
-                     tile_lds = (size_t)std::max<uint32_t>(1u << tshift, use_plan ? kPlanMaxCells : 0u) * 4;
+        const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
 #define PCR_LAUNCH_BIN(VEC, PER, PLACE) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
                                                     bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
-                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift, plan_cur)
+                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
         if (use_layout) {
             if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, true); else PCR_LAUNCH_BIN(true, 16, true); }
             else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, true); else PCR_LAUNCH_BIN(false, 16, true); }
@@ -1169,10 +1053,9 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
         TileTail tail;
         memset(&tail, 0, sizeof tail);
-        const bool make_plan = plan_possible && !filtered;      // (a build of a region counts the region's points only: the plan and the layout it came with stay)
 #define PCR_LAUNCH_TILE_T(PER, MODE, THREADS, TAIL) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS, TAIL>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
                            bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
-                           use_layout ? lay_cur : bin_start.as<uint32_t>(), tail, plan_cur, make_plan ? slab_count.as<uint32_t>() : nullptr)
+                           use_layout ? lay_cur : bin_start.as<uint32_t>(), tail)
 #define PCR_LAUNCH_TILE(PER, MODE, THREADS) PCR_LAUNCH_TILE_T(PER, MODE, THREADS, false)
         // dense grids: eight points per thread (135 VGPRs, three waves per SIMD) while a tile holds ~1 000 points or fewer on average, sixteen
         // beyond (A/B: 1 M points in 1 464 tiles 48.4 -> 46.8 us with eight; 5 M and 10 M points are faster with sixteen)
@@ -1185,27 +1068,14 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const bool with_tail = filtered && filter->want_tail && !sparse && tshift <= 13 && dev_env("PCR_NDT_NO_TAIL") == nullptr;
         if (with_tail) { tail = filter->tail; tail.mask = keep_mask; tail.mshift = keep_mshift; filter->tail_applied = true; }
         if (sparse) { PCR_LAUNCH_TILE(1, 1, 256); PCR_LAUNCH_TILE(16, 2, 256); }
-        else if (with_tail) { if (use_plan ? plan_points <= 1024 : (tiles_est && n / tiles_est <= 1024)) PCR_LAUNCH_TILE_T(8, 0, 256, true); else PCR_LAUNCH_TILE_T(16, 0, 256, true); }
-        else if (use_plan ? plan_points <= 1024 : (tiles_est && n / tiles_est <= 1024)) PCR_LAUNCH_TILE(8, 0, 256);
+        else if (with_tail) { if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE_T(8, 0, 256, true); else PCR_LAUNCH_TILE_T(16, 0, 256, true); }
+        else if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE(8, 0, 256);
         else if (wide > 0 && tiles_est && n / tiles_est >= (uint64_t)wide) PCR_LAUNCH_TILE(4, 0, 1024);
         else PCR_LAUNCH_TILE(16, 0, 256);
 #undef PCR_LAUNCH_TILE
 #undef PCR_LAUNCH_TILE_T
-        if (make_plan) {
-            // P points per tile at most (+ a slab's): ~1 000 for scan- to map-sized clouds, more when that would take more than ~4 000 tiles;
-            // cells per tile at most 31 slabs + 1.  The bound on the tile count sizes the next build's launches.
-            const uint64_t P = std::max<uint64_t>(1024, (n + 3999) / 4000);
-            const unsigned long long w_point = (1ull << 32) / P, w_slab = ((1ull << 32) << kPlanSlabShift) / (kPlanMaxCells - (1u << kPlanSlabShift));
-            const uint64_t slabs_cap = ((uint64_t)cap_eff >> kPlanSlabShift) + 2;
-            const uint64_t bound = (((unsigned __int128)n * w_point + (unsigned __int128)slabs_cap * w_slab) >> 32) + 2;
-            if (bound + 2 <= (uint64_t)kMaxBins) {
-                hipLaunchKernelGGL(grid_plan_kernel, dim3(1), dim3(1024), 0, s, header.as<GridHeader>(), slab_count.as<uint32_t>(), plan[lay_idx ^ 1].as<uint32_t>(), lay_next,
-                                   w_point, w_slab, (uint32_t)bound);
-                lay_has_plan = true; plan_max_tiles = (uint32_t)bound; plan_points = P;
-            } else { lay_has_plan = false; plan_max_tiles = 0; }
-        } else if (!filtered) { lay_has_plan = false; plan_max_tiles = 0; }
-        if (!filtered) { lay_idx ^= 1; lay_n = n; }      // (what this build left serves the next one; a build of a region hands layout and plan on as they are)
-        lay_ok = true; lay_shift = tshift;
+        lay_idx ^= 1; lay_ok = true; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
+        if (!filtered) lay_n = n;
         PCR_TRY(hipGetLastError());
         n_points = n;
         valid = true;

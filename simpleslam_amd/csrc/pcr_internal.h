@@ -162,15 +162,6 @@ struct DeviceBuf {
 
 static constexpr int kMaxBins = 8192;    // tiles of the tiled build path (grid_index.hip): one 32 KB LDS histogram
 static constexpr int kMaxTileShift = 13; // a tile's cells are histogrammed in LDS too
-// Tile plan (grid_index.hip: grid_plan_kernel): tiles of about equal POINT count -- runs of whole slabs of 2^kPlanSlabShift consecutive cells -- laid
-// out by one build for the next from the occupancy it has just counted.  A tile of a plan never holds more than kPlanMaxCells cells.
-static constexpr int kPlanSlabShift = 8;
-static constexpr uint32_t kPlanMaxSlabs = 131072;      // grids of up to 2^25 cells
-static constexpr uint32_t kPlanMaxCells = 8192;
-static constexpr uint32_t kPlanHeaderWords = 8;        // [0] number of tiles (0: the plan could not be made), then the tiles' first cells, then the slabs' tiles (16 bit)
-struct TilePlan {      // by value to the build kernels; n_tiles == nullptr: uniform tiles of 2^shift cells
-    const uint32_t* n_tiles; const uint32_t* tile_cell0; const uint16_t* slab_tile;
-};
 
 // A build that indexes only the points inside a region (pcr_scan2map of NDT: voxel Gaussians depend on a voxel's own points alone, so
 // a lattice that holds nothing outside the region the scan can reach serves that scan as the full one would).  Possible only when the
@@ -219,15 +210,6 @@ struct GridIndex {
     int lay_idx = 0, lay_shift = -1;
     size_t lay_n = 0;
     bool lay_ok = false, used_layout = false;
-    // Tile plan: tiles of equal point count for the next build, made with the layout (plan[k] goes with layout[k]; grid_plan_kernel)
-    DeviceBuf plan[2], slab_count;
-    bool lay_has_plan = false, used_plan = false;
-    uint64_t plan_points = 0;                   // points per tile the plan that goes with layout[lay_idx] aimed at
-    uint32_t plan_max_tiles = 0;                // bound on the tile count of the plan that goes with layout[lay_idx] (sizes the LDS of the build that uses it)
-    TilePlan plan_view(int k) const {
-        const uint32_t* w = plan[k].as<uint32_t>();
-        return TilePlan{w, w + kPlanHeaderWords, reinterpret_cast<const uint16_t*>(w + kPlanHeaderWords + kMaxBins + 8)};
-    }
     bool filtered = false;                      // the last build() indexed the points of a region only (BuildFilter)
     // A build WITHOUT hints computes the bounding box itself; then (grid_bbox_header_kernel)
     GridHeader* header_mirror = nullptr;        //   the header is also written to this host-mapped address (no copy queued behind the build): `mirrored` says so
