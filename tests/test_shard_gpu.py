@@ -256,9 +256,10 @@ def test_vgicp_halo_too_small_fails_on_every_rank(gpu, vg_w):
 
 
 def test_a_rank_without_a_usable_target_stops_all_ranks(gpu, w1m):
-    """One rank's tile cannot be indexed (a stray point 1e7 m away: its box needs more cells than the dense table of the
-    VGICP voxel lattice can hold).  The others learn it from the status exchange before the first linearisation and return an
-    error instead of waiting for a peer that has left.  (LOAM, which can cut such a box, succeeds on every rank.)"""
+    """One rank's target cannot be prepared (its cloud is so thin that the 20 nearest neighbours of its tile's points reach past the halo:
+    the covariances would not be the whole map's).  The others learn it from the status exchange before the first linearisation and
+    return an error instead of waiting for a peer that has left.  A stray point 1e7 m away in one rank's cloud -- a box no dense table can
+    hold -- is no such case: LOAM and VGICP index the part of the cloud that matters and succeed on every rank."""
     w = w1m
     n = 3
     stray = np.array([[1.0e7, -1.0e7, 3.0e6, 0.0]], np.float32)
@@ -269,10 +270,20 @@ def test_a_rank_without_a_usable_target_stops_all_ranks(gpu, w1m):
             pts = shard.tile_for_method(w["map"], r, n, method, res).points
             out.append(np.ascontiguousarray(np.vstack([pts, stray]) if r == 1 else pts))
         return out
-    poses, convs, regs, errs, _ = run_ranks("vgicp", n, w["scan"], w["init"], w["map"], resolution=0.5, maps=maps_for("vgicp", 0.5), vgicp_resolution=0.5)
+    thin = [shard.tile_for_method(w["map"], r, n, "vgicp", 0.5).points for r in range(n)]
+    thin[1] = np.ascontiguousarray(thin[1][::400])
+    poses, convs, regs, errs, _ = run_ranks("vgicp", n, w["scan"], w["init"], w["map"], resolution=0.5, maps=thin, vgicp_resolution=0.5)
     assert all(isinstance(e, pcr.PcrError) for e in errs), errs
     assert "another rank" in str(errs[0]) and "another rank" in str(errs[2])
     assert "another rank" not in str(errs[1])
+    # VGICP: the rank indexes the bulk of its cloud (the stray point is in nobody's neighbourhood and in no voxel the scan visits)
+    poses, convs, regs, errs, _ = run_ranks("vgicp", n, w["scan"], w["init"], w["map"], resolution=0.5, maps=maps_for("vgicp", 0.5), vgicp_resolution=0.5)
+    assert errs == [None] * n, errs
+    _all_equal(poses)
+    ref = w["init"].copy()
+    VgicpRegister(vgicp_resolution=0.5).scan2Map(w["scan"], w["map"], ref)
+    dt, dr = synth.pose_error(poses[0], ref)
+    assert dt <= 2e-6 and dr <= 2e-7, (dt, dr)
     # LOAM indexes a part of such a tile instead -- scan2Map the region around the scan, the prepared-target path (pcr_set_target has no
     # scan to go by) the bulk of the tile -- and succeeds on every rank, with the pose of the unsharded call
     ref = w["init"].copy()
