@@ -475,7 +475,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         }
         for (int k = 0; k < iters; ++k) {
             if (per_kernel) H_TRY(loam_launch_iteration(a, k, h->stream, h->ev_kernel[2 * k], h->ev_kernel[2 * k + 1]));
-            else H_TRY(loam_launch_iteration(a, k, h->stream));
+            else H_TRY(loam_launch_iteration(a, k, h->stream, nullptr, nullptr, !shard));
             if (h->host_ar) {
                 // the caller's collective: sums to the host, through fn, back (one host round trip per linearisation)
                 H_TRY(loam_launch_reduce(a, k, h->red_dev, h->stream));

@@ -884,13 +884,14 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     // Request this thread's share of the previous launch's partial sums together with the state it guards
     // (one memory round trip instead of two); they are simply unused when the loop has already finished.
     const int comp = t & 31, slice = t >> 5;
+    const uint32_t n_rows = a.n_prev ? a.n_prev : a.n_partials;      // rows of launch k - 1
     // the state first: loads complete in issue order, so testing `done` then waits for nothing younger
     const int prev_done = prev->done;
     const double prev_pose_t = t < 16 ? prev->pose[t] : 0.0;
     double pv[32];
     {
         const double* part = a.partials + (size_t)((k + 1) & 1) * kMaxPartials * kAccum + comp;
-        const uint32_t last = a.n_partials ? a.n_partials - 1u : 0u;
+        const uint32_t last = n_rows ? n_rows - 1u : 0u;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             const uint32_t b = (uint32_t)slice + 8u * u;
@@ -903,16 +904,16 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     const double red = *(a.reduced ? a.reduced + comp : part0);       // sharded mode: sums already all-reduced
     double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) acc += ((uint32_t)slice + 8u * u < a.n_partials) ? pv[u] : 0.0;
+    for (int u = 0; u < 32; ++u) acc += ((uint32_t)slice + 8u * u < n_rows) ? pv[u] : 0.0;
     // more than 256 blocks (scans beyond 65 536 points): sixteen loads in flight per step, added in the same order as a plain
     // loop (one load per step cost 11 us of every launch on a 131 072-point scan)
-    for (uint32_t b0 = (uint32_t)slice + 256u; b0 < a.n_partials; b0 += 128u) {
-        const uint32_t last = a.n_partials - 1u;
+    for (uint32_t b0 = (uint32_t)slice + 256u; b0 < n_rows; b0 += 128u) {
+        const uint32_t last = n_rows - 1u;
         double w[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) { const uint32_t b = b0 + 8u * u; w[u] = part0[(size_t)(b < last ? b : last) * kAccum]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += (b0 + 8u * u < a.n_partials) ? w[u] : 0.0;
+        for (int u = 0; u < 16; ++u) acc += (b0 + 8u * u < n_rows) ? w[u] : 0.0;
     }
     if (a.reduced) acc = slice == 0 ? red : 0.0;
     sh_sum[slice * 32 + comp] = acc;
@@ -1072,13 +1073,17 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
     float pre_x = 0.f, pre_y = 0.f, pre_z = 0.f;
     const bool use_cache = k > 0 && a.nn_cache != nullptr;
     const float4* pre_src = nullptr;
+    // half blocks (LoamArgs::half): 128 queries per block, owned by the lower half of its threads; the upper half has none of its own and
+    // only takes its slice of the searches (loam_point: a block with 128 posted queries searches each with two lanes, in different waves)
+    const uint32_t qpb = a.half ? 128u : 256u;
+    const bool owner_lane = (uint32_t)tid < qpb;
     {
-        const uint32_t q = blk * 256 + tid;
+        const uint32_t q = blk * qpb + (uint32_t)tid;
         // unconditional load of a clamped index: a conditional one makes the wave wait for it at the join
         const float* sp = a.n_src ? a.src + (size_t)(q < a.n_src ? q : a.n_src - 1u) * a.src_stride
                                   : reinterpret_cast<const float*>(a.partials);      // empty scan: any readable address
         pre_x = sp[0]; pre_y = sp[1]; pre_z = sp[2];
-        pre_src = (use_cache && q < a.n_src) ? reinterpret_cast<const float4*>(a.nn_cache + q) : nullptr;
+        pre_src = (use_cache && owner_lane && q < a.n_src) ? reinterpret_cast<const float4*>(a.nn_cache + q) : nullptr;
     }
     if (loam_prologue(a, k, sh_sum, &sh_pro, tl, pre_src, use_cache ? sh_pre + (tid & ~63) : nullptr)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // never leave with an LDS-DMA in flight
@@ -1104,9 +1109,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
     }
     double acc = 0.0;
     uint32_t n_hit = 0, n_search = 0, n_esc = 0;
-    for (uint32_t base = blk * 256; base < a.n_src; base += gridDim.x * 256) {
+    for (uint32_t base = blk * qpb; base < a.n_src; base += gridDim.x * qpb) {
         const uint32_t q = base + tid;
-        const bool valid = q < a.n_src;
+        const bool valid = owner_lane && q < a.n_src;
         double row[7] = {0, 0, 0, 0, 0, 0, 0};
         uint32_t nn[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         int how = 0;
@@ -1114,7 +1119,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
         float sx = pre_x, sy = pre_y, sz = pre_z;
         union { NnCacheEntry e; float4 v[kEntryVec]; } ce;
         ce.e.flags = 0;
-        if (base == blk * 256) {
+        if (base == blk * qpb) {
             // EVERY wave waits for its own LDS-DMA, also one without a single valid query (its lanes fetched a dummy address):
             // the staging area is reused right after the barrier, and a transfer still in flight would land in the search
             // scratch of the other waves.
@@ -1132,9 +1137,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void loam_iterate_kernel(const 
                 if (use_cache) ce.e = a.nn_cache[q];
             }
         }
-        const bool all_search = sh_pro.big_step != 0 && base == blk * 256;      // (later rounds of a grid-stride launch go the ordinary way)
+        const bool all_search = sh_pro.big_step != 0 && base == blk * qpb && !a.half;      // (later rounds of a grid-stride launch go the ordinary way)
         const int st = loam_point<kGroup>(a, h, pose, sx, sy, sz, valid, ce.e, use_cache && valid && !all_search, sh_knn, sh_ex, row, nn, q, &how, &esc,
-                                          base == blk * 256 ? tl : nullptr, all_search);
+                                          base == blk * qpb ? tl : nullptr, all_search);
         if (valid && (a.dbg_status || a.dbg_nn || a.dbg_rows)) {
             const size_t oi = (size_t)q;
             if (a.dbg_status) a.dbg_status[oi] = (int8_t)st;
@@ -1320,7 +1325,19 @@ uint32_t loam_grid_blocks(uint32_t n_src) {
 // start/stop (optional): events that the packet processor stamps at the kernel's own begin and end (hipExtLaunchKernelGGL),
 // i.e. what a profiler reports as the kernel's duration -- events recorded around an ordinary launch also contain the
 // dispatch latency (~2 us here).
-hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+hipError_t loam_launch_iteration(const LoamArgs& a_in, int k, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool allow_half) {
+    LoamArgs a = a_in;
+    a.half = 0; a.n_prev = 0;
+    // (development: launch 0 -- every query searches -- as twice the blocks of 128 queries, two lanes per query, two waves per SIMD)
+    static const int half0 = dev_env("PCR_LOAM_HALF0") ? atoi(dev_env("PCR_LOAM_HALF0")) : 0;
+    const bool can_half = allow_half && half0 > 0 && !a.reduced && !a.coresident && 2u * a.n_partials <= (uint32_t)kMaxPartials && !(start && stop);
+    if (can_half && k == 1) a.n_prev = 2u * a.n_partials;
+    if (can_half && k == 0) {
+        a.half = 1;
+        if (half0 == 1) hipLaunchKernelGGL((loam_iterate_kernel<8, 2>), dim3(2u * a.n_partials), dim3(256), 0, s, a, k);
+        else hipLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(2u * a.n_partials), dim3(256), 0, s, a, k);
+        return hipGetLastError();
+    }
     if (start && stop) {
         if (a.coresident) hipExtLaunchKernelGGL((loam_iterate_kernel<4, 2>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);
         else hipExtLaunchKernelGGL((loam_iterate_kernel<8, 1>), dim3(a.n_partials), dim3(256), 0, s, start, stop, 0, a, k);

@@ -132,6 +132,8 @@ struct LoamArgs {
     double* partials;        // [2][kMaxPartials][kAccum]
     const double* reduced;   // non-null: partial sums already reduced (and all-reduced) into kAccum doubles
     uint32_t n_partials;     // blocks of the linearisation grid
+    uint32_t n_prev;         // rows the PREVIOUS launch wrote (0: n_partials) -- a launch of half blocks writes twice as many
+    uint32_t half;           // this launch: 128 queries per block (the upper half of its threads only helps searching), twice the blocks
     LoamTrace* trace;        // [iters] or null
     LoamResult* result;      // final pose (after T2SE3) and flags
     // optional per-point outputs (tests): null in production
@@ -398,7 +400,7 @@ static constexpr unsigned long long kPeerTimeoutTicks = 200000000ull;      // 2 
 struct PeerComm { double* buf[kMaxPeers]; int32_t rank, nranks; };
 hipError_t loam_launch_peer_exchange(const LoamArgs& a, int k, const PeerComm& pc, double seq, double* d_out, hipStream_t s);
 hipError_t peer_launch_allreduce(double* d_inout, int n, int op, const PeerComm& pc, double seq, hipStream_t s);
-hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr, bool allow_half = false);
 hipError_t loam_launch_finalize(const LoamArgs& a, int k, hipStream_t s);
 hipError_t loam_launch_reduce(const LoamArgs& a, int k, double* d_out, hipStream_t s);
 uint32_t loam_grid_blocks(uint32_t n_src);
