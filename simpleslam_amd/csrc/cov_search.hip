@@ -533,7 +533,16 @@ hipError_t CovScratch::reserve(size_t n) {
     if ((e = seed.reserve((n + 64) * sizeof(unsigned long long))) != hipSuccess) return e;
     return count.reserve(64);
 }
-void CovScratch::release() { nbr.release(); queue.release(); seed.release(); count.release(); }
+hipError_t CovScratch::reserve_region(size_t n, hipStream_t s) {
+    hipError_t e;
+    if ((e = region_list.reserve((n + 64) * sizeof(uint32_t))) != hipSuccess) return e;
+    if (!region_count.p) {
+        if ((e = region_count.reserve(256)) != hipSuccess) return e;
+        return hipMemsetAsync(region_count.p, 0, 256, s);
+    }
+    return hipSuccess;
+}
+void CovScratch::release() { nbr.release(); queue.release(); seed.release(); count.release(); region_list.release(); region_count.release(); }
 
 // The three kernels over one cloud (scratch reserved for >= n points by the caller, before anything was queued).
 hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, const GridIndex* coarse2, const float* d_orig, size_t stride_floats,

@@ -318,7 +318,12 @@ struct CovCheck { double chk_lo[3], chk_hi[3], ext_lo[3], ext_hi[3]; uint32_t* v
 // the lane-per-query kernel hands to the wave-per-query one (+ the bound each brings along), its counter.  One per stream that runs it.
 struct CovScratch {
     DeviceBuf nbr, queue, seed, count;
+    // a map-sized target prepared for one scan (vgicp.hip: vgicp_region_list_kernel): the sorted positions of the region's points, and two counters
+    // used alternately (each call leaves the other one cleared for the next)
+    DeviceBuf region_list, region_count;
+    int region_idx = 0;
     hipError_t reserve(size_t n);
+    hipError_t reserve_region(size_t n, hipStream_t s);
     void release();
 };
 // ev (optional, profiling passes): 6 events = begin / end of the three kernels

@@ -210,10 +210,52 @@ __device__ __forceinline__ GridLevels one_level(const GridView& g) {
 // of dependent round trips at one wave per SIMD: A/B on one box, the scan's 65 k covariances no longer hold the optimiser up (align 0.19 ->
 // 0.11 ms).  A map-sized cloud runs the same kernel at four waves per SIMD and is bound by instruction issue: there the batched form
 // costs 0.83 -> 1.28 ms per million points, so it keeps the row-by-row walk.
+// A map-sized target prepared for one scan: the sorted positions of the points whose voxel the scan can reach, compacted (in blocks of 1 024
+// positions, each block's share in order; one atomic per block).  The covariance kernel below then runs FULL waves over the region's ~100 k points
+// instead of 16 000 thin ones over the million, most of whose lanes left at the region test while the others searched.
+__global__ __launch_bounds__(256) void vgicp_region_list_kernel(GridView g, uint32_t n_sorted_max, const RoiView roi, uint32_t* __restrict__ list,
+                                                                uint32_t* __restrict__ count, uint32_t* __restrict__ count_next) {
+    __shared__ uint32_t sh_cnt[16], sh_base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0u;      // (the other of two counters, for the next call: before anything can return)
+    const GridHeader h = *g.hdr;
+    if (h.empty || h.overflow || h.stale) return;
+    const GridHeader lat = *roi.lat;
+    if (lat.stale || lat.overflow) return;
+    const uint32_t n = min(g.cell_start[h.n_cells], n_sorted_max);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t c0 = blockIdx.x * 1024u; c0 < n; c0 += gridDim.x * 1024u) {
+        unsigned long long m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = c0 + (uint32_t)u * 256u + threadIdx.x;
+            bool in = false;
+            if (j < n) { const float4 q = g.pts[j]; in = roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z); }
+            m[u] = __ballot(in);
+            if (lane == 0) sh_cnt[u * 4 + wave] = (uint32_t)__popcll(m[u]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int k = 0; k < 16; ++k) tot += sh_cnt[k];
+            sh_base = tot ? atomicAdd(count, tot) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t off = sh_base;
+            for (int k = 0; k < u * 4 + wave; ++k) off += sh_cnt[k];
+            if ((m[u] >> lane) & 1ull) list[off + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull))] = c0 + (uint32_t)u * 256u + threadIdx.x;
+        }
+        __syncthreads();      // sh_cnt is rewritten by the next chunk
+    }
+}
+
+// list / list_count (optional): the sorted positions to process (vgicp_region_list_kernel) instead of every position with the region test
 template <bool kBatch>
 __global__ __launch_bounds__(256, kBatch ? 1 : 4) void vgicp_cov_kernel(GridView g, GridView g1, GridView g2, int n_levels, const float* __restrict__ orig,
                                                         uint32_t stride, uint32_t n_sorted_max, double* __restrict__ cov6, const int use_check,
-                                                        const CovCheck chk, const RoiView roi) {
+                                                        const CovCheck chk, const RoiView roi, const uint32_t* __restrict__ list,
+                                                        const uint32_t* __restrict__ list_count) {
     __shared__ uint2 sh_rows[kBatch ? 9 * 256 : 1];      // row ranges of ring 1 (ring_level)
     const GridHeader h = *g.hdr;
     if (h.empty || h.overflow || h.stale) return;      // (stale: queued ahead of the host's look at the header, capi.hip: settle_cov_levels; the caller builds afresh)
@@ -227,11 +269,12 @@ __global__ __launch_bounds__(256, kBatch ? 1 : 4) void vgicp_cov_kernel(GridView
     lv.n = n_levels;
     if (n_levels > 1 && (g1.hdr->overflow || g1.hdr->empty)) lv.n = 1;
     if (n_levels > 2 && (g2.hdr->overflow || g2.hdr->empty)) lv.n = min(lv.n, 2);
-    const uint32_t n = g.cell_start[h.n_cells];   // points actually indexed (finite ones)
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n && j < n_sorted_max; j += gridDim.x * 256) {
+    const uint32_t n = list ? *list_count : min(g.cell_start[h.n_cells], n_sorted_max);   // points actually indexed (finite ones), or the listed ones
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t j = list ? list[i] : i;
         const float4 q = g.pts[j];
         // a target prepared for one scan: only the points whose voxel the scan can reach (the search itself always sees the whole cloud)
-        if (roi.mask && !roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z)) continue;
+        if (!list && roi.mask && !roi_holds_point(roi, lat, (double)q.x, (double)q.y, (double)q.z)) continue;
         if (roi.count) atomicAdd(roi.count, 1u);      // (profiling passes only)
         KeyList<kCovK> L;
         ring_knn<kCovK>(lv, q.x, q.y, q.z, 3.0e38f, L, kBatch ? sh_rows : nullptr);
@@ -702,13 +745,29 @@ hipError_t vgicp_launch_cov(const GridIndex& grid, const GridIndex* coarse1, con
     memset(&rv, 0, sizeof rv);
     if (roi) rv = *roi;
     // (ev: events stamped at the kernel's own begin and end -- profiling passes)
-#define PCR_COV_ARGS grid.view(), coarse1 ? coarse1->view() : grid.view(), coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv
+    // a map-sized target prepared for one scan: the region's points are listed first, and the search runs over the list
+    const uint32_t* d_list = nullptr;
+    const uint32_t* d_list_count = nullptr;
+    int cov_blocks = blocks;
+    static const bool no_list = dev_env("PCR_COV_NO_LIST") != nullptr;      // (development builds: A/B)
+    if (n > 300000 && roi && roi->mask && scratch && !check && !no_list) {
+        const hipError_t e = scratch->reserve_region(n, s);
+        if (e != hipSuccess) return e;
+        scratch->region_idx ^= 1;
+        uint32_t* const cnt = scratch->region_count.as<uint32_t>() + 32 * scratch->region_idx;
+        uint32_t* const cnt_next = scratch->region_count.as<uint32_t>() + 32 * (scratch->region_idx ^ 1);
+        const int lb = (int)std::min<size_t>(2048, (n + 1023) / 1024);
+        hipLaunchKernelGGL(vgicp_region_list_kernel, dim3(lb), dim3(256), 0, s, grid.view(), (uint32_t)n, rv, scratch->region_list.as<uint32_t>(), cnt, cnt_next);
+        d_list = scratch->region_list.as<uint32_t>(); d_list_count = cnt;
+        cov_blocks = std::min(blocks, 1024);      // (four blocks per CU resident at once; the kernel strides over the list)
+    }
+#define PCR_COV_ARGS grid.view(), coarse1 ? coarse1->view() : grid.view(), coarse2 ? coarse2->view() : grid.view(), levels, d_orig, (uint32_t)stride_floats, (uint32_t)n, d_cov6, check ? 1 : 0, chk, rv, d_list, d_list_count
     if (n <= 300000) {      // scan-sized (the same threshold as the choice of search levels, capi.hip: cov_levels)
         if (ev) hipExtLaunchKernelGGL(vgicp_cov_kernel<true>, dim3(blocks), dim3(256), 0, s, ev[0], ev[1], 0, PCR_COV_ARGS);
         else hipLaunchKernelGGL(vgicp_cov_kernel<true>, dim3(blocks), dim3(256), 0, s, PCR_COV_ARGS);
     } else {
-        if (ev) hipExtLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(blocks), dim3(256), 0, s, ev[0], ev[1], 0, PCR_COV_ARGS);
-        else hipLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(blocks), dim3(256), 0, s, PCR_COV_ARGS);
+        if (ev) hipExtLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(cov_blocks), dim3(256), 0, s, ev[0], ev[1], 0, PCR_COV_ARGS);
+        else hipLaunchKernelGGL(vgicp_cov_kernel<false>, dim3(cov_blocks), dim3(256), 0, s, PCR_COV_ARGS);
     }
 #undef PCR_COV_ARGS
     return hipGetLastError();
