@@ -835,8 +835,15 @@ __global__ __launch_bounds__(256) void roi_spread_axis_kernel(const GridHeader* 
         const size_t step = axis == 1 ? (size_t)m0 : (size_t)m0 * m1;
         const int k0 = max(pos - R, 0), k1 = min(pos + R, len - 1);
         const uint8_t* p = in + ((size_t)m - (size_t)(pos - k0) * step);
+        // (every load of the span in flight at once -- positions past the span repeat its last one: taken one by one they are a chain of up to 25
+        //  round trips, and that chain was the kernel's duration)
+        const int span = k1 - k0;
+        uint8_t w[2 * kRoiMaxRadius + 3];
+#pragma unroll
+        for (int k = 0; k < 2 * kRoiMaxRadius + 3; ++k) w[k] = p[(size_t)min(k, span) * step];
         uint8_t any = 0;
-        for (int k = k0; k <= k1; ++k, p += step) any |= *p;
+#pragma unroll
+        for (int k = 0; k < 2 * kRoiMaxRadius + 3; ++k) any |= w[k];
         out[m] = any ? 1 : 0;
     }
 }
