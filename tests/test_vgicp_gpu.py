@@ -348,6 +348,28 @@ def test_target_prepared_for_the_scans_region_only(gpu, vg_world, off):
     assert lin["n"] == lin_k["n"] and lin["err"] == lin_k["err"]
 
 
+def test_region_list_of_a_map_sized_target_matches_the_whole_target(gpu):
+    """A map-sized target (more than 300 000 points: one search level, the lane-per-query kernel) prepared for one scan: the sorted positions of the
+    region's points are compacted first (vgicp_region_list_kernel) and the covariance kernel runs over that list.  Poses, verdicts and
+    iteration counts are those of the full preparation (pcr_params.full_target = 1), bit for bit -- on every call of a handle (the list's
+    two counters alternate) and from a start that leaves the region (repeat on the whole target)."""
+    world, m = synth.make_map(400_000, seed=77)
+    scan, T = synth.make_scan(world, 1, seed=77)
+    full = VgicpRegister(full_target=1)
+    reg = VgicpRegister()
+    repeats = 0
+    for k, off in enumerate([0.2, -0.3, 0.1, 5.0, 0.25]):
+        T0 = T.copy()
+        T0[:3, 3] += np.array([off, -0.5 * off, 0.03 * off])
+        pf = T0.copy(); cf = full.scan2Map(scan, m, pf)
+        p = T0.copy(); c = reg.scan2Map(scan, m, p)
+        assert c == cf, (k, off)
+        np.testing.assert_array_equal(p, pf)
+        assert reg.stats()["iterations"] == full.stats()["iterations"], (k, off)
+        repeats += reg.stats()["region_repeats"]
+    assert full.stats()["region_repeats"] == 0
+
+
 @pytest.mark.parametrize("method", ["vgicp", "ndt"])
 def test_align_after_scan2map_of_a_device_target_says_what_to_do(gpu, vg_world, method):
     """a DEVICE target is the caller's buffer and may be gone after the call: the region-only preparation is not passed on to pcr_align, the
