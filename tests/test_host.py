@@ -109,6 +109,23 @@ def test_synth_is_deterministic_and_sized():
     assert np.median(np.sqrt(d2[:, 0])) < 0.45
 
 
+def test_a_far_outlier_goes_to_an_edge_rank_and_leaves_the_cuts_alone():
+    """The cuts are point-count quantiles, so one stray point kilometres off moves no cut by more than a lattice step; the outer tiles are open, so the
+    stray point belongs to exactly one (edge) rank -- whose library then indexes the bulk of its cloud (tests/test_shard_gpu.py)."""
+    _, m = synth.make_map(30000, seed=11)
+    far = m.copy()
+    far[0, :3] = [2.0e4, -1.0e4, 2857.0]
+    for method, res in (("loam", 1.0), ("ndt", 1.0), ("vgicp", 0.5)):
+        plain = [shard.tile_for_method(m, r, 4, method, res) for r in range(4)]
+        tiles = [shard.tile_for_method(far, r, 4, method, res) for r in range(4)]
+        assert sum(t.n_core for t in tiles) == far.shape[0]
+        holders = [r for r, t in enumerate(tiles) if (t.points[:, 0] >= 1.0e4).any()]
+        assert len(holders) == 1 and holders[0] in (0, 3), (method, holders)
+        if plain[0].axis == tiles[0].axis:      # (the stray point may make another axis the longest: then the cuts are another axis's)
+            for a, b in zip(plain[:-1], tiles[:-1]):
+                assert abs(a.hi[a.axis] - b.hi[b.axis]) <= 2 * res, (method, a.hi, b.hi)
+
+
 def test_tiles_partition_queries_exactly_once():
     _, m = synth.make_map(30000, seed=9)
     for ws in (2, 3, 8):
