@@ -753,7 +753,14 @@ __global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restric
     if (hdr->overflow || hdr->empty) return;
     const uint32_t nbins = (uint32_t)(hdr->n_cells >> shift) + 1u;
     unsigned long long s = 0;
-    for (uint32_t b = threadIdx.x; b < nbins; b += 256) s += tile_sq[b];
+    // (sixteen loads in flight per step: one by one the ~13 loads of a thread were a chain of round trips -- 7.8 us for a kernel that adds up 27 KB)
+    for (uint32_t b0 = threadIdx.x; b0 < nbins; b0 += 16u * 256u) {
+        unsigned long long w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const uint32_t b = b0 + (uint32_t)u * 256u; w[u] = b < nbins ? tile_sq[b] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += w[u];
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
