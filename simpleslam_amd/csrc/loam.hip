@@ -1199,17 +1199,29 @@ __global__ __launch_bounds__(256) void loam_finalize_kernel(const LoamArgs a, co
     }
 }
 
+// This thread's share (component comp, rows slice, slice + 8, ...) of the rows launch k wrote, added in row order.  The state word and the first 32
+// rows are requested together and unconditionally (rows past the end repeat the last one and are masked in the sum): a load per loop step behind the
+// test of `done` was a chain of up to 33 round trips in a kernel every linearisation of a sharded call waits for.
+__device__ __forceinline__ double loam_fold_own_rows(const LoamArgs& a, int k, int comp, int slice) {
+    const int done = a.state[k & 1].done;
+    const double* const part0 = a.partials + (size_t)(k & 1) * kMaxPartials * kAccum + comp;
+    const uint32_t last = a.n_partials ? a.n_partials - 1u : 0u;
+    double pv[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { const uint32_t b = (uint32_t)slice + 8u * u; pv[u] = part0[(size_t)(b < last ? b : last) * kAccum]; }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc += ((uint32_t)slice + 8u * u < a.n_partials) ? pv[u] : 0.0;
+    for (uint32_t b = (uint32_t)slice + 256u; b < a.n_partials; b += 8u) acc += part0[(size_t)b * kAccum];      // (scans beyond 65 536 points)
+    return done ? 0.0 : acc;
+}
+
 // sharded (multi-GPU) mode: fold this rank's partial sums into kAccum doubles so that
 // RCCL can all-reduce them before the next launch's prologue reads a.reduced
 __global__ __launch_bounds__(256) void loam_reduce_kernel(const LoamArgs a, const int k, double* __restrict__ out) {
     __shared__ double sh_sum[8 * 32];
     const int t = threadIdx.x, comp = t & 31, slice = t >> 5;
-    const LoamState* st = &a.state[k & 1];
-    double acc = 0.0;
-    if (!st->done) {
-        const double* part = a.partials + (size_t)(k & 1) * kMaxPartials * kAccum;
-        for (uint32_t b = slice; b < a.n_partials; b += 8) acc += part[(size_t)b * kAccum + comp];
-    }
+    const double acc = loam_fold_own_rows(a, k, comp, slice);
     sh_sum[slice * 32 + comp] = acc;
     __syncthreads();
     if (t < 32) {
@@ -1282,12 +1294,7 @@ __device__ __forceinline__ bool peer_exchange_block(const PeerComm& pc, double s
 __global__ __launch_bounds__(256) void loam_peer_exchange_kernel(const LoamArgs a, const int k, const PeerComm pc, const double seq, double* __restrict__ out) {
     __shared__ double sh_sum[8 * 32];
     const int t = threadIdx.x, comp = t & 31, slice = t >> 5;
-    const LoamState* st = &a.state[k & 1];
-    double acc = 0.0;
-    if (!st->done) {
-        const double* part = a.partials + (size_t)(k & 1) * kMaxPartials * kAccum;
-        for (uint32_t b = slice; b < a.n_partials; b += 8) acc += part[(size_t)b * kAccum + comp];
-    }
+    const double acc = loam_fold_own_rows(a, k, comp, slice);
     sh_sum[slice * 32 + comp] = acc;
     __syncthreads();
     double v = 0.0;
