@@ -1,5 +1,7 @@
+#!/bin/bash
+# Run on the GPU box with a DEV library (ab/libdev.so): the covariance search kernels alone, statistics and SQ counters.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cp $R/ab/libdev.so $R/simpleslam_amd/lib/libpcr_hip.so
+export PCR_LIB=$R/ab/libdev.so      # (the loader's override: the product library is not touched)
 cd /tmp && export TMPDIR=/tmp
 export PCR_COV_LPQ=4 PCR_COV_GROUP=4 PCR_COV_WAVE_BLOCKS=2048
 OUT=$R/gpurun_out/cov_alone; rm -rf $OUT; mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Run on the GPU box with a DEV library (ab/libdev.so): sweep of the covariance search's launch shape on the VGICP line.
 #   scripts/cov_sweep.sh "<lpq> <group> <wave_blocks>" ...      -> per configuration: parity (cov_debug), kernel averages (rocprofv3), scans/s
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cp $R/ab/libdev.so $R/simpleslam_amd/lib/libpcr_hip.so
+export PCR_LIB=$R/ab/libdev.so      # (the loader's override: the product library is not touched)
 cd /tmp && export TMPDIR=/tmp
 for cfg in "$@"; do
   set -- $cfg

@@ -21,7 +21,7 @@ buf = np.zeros(2 * 8192 * 8, np.uint64)
 L.pcr_dev_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
 st = buf.reshape(2, 8192, 8).astype(np.int64)
 for k, name, labels in ((0, "bin", ["start", "keys+lds done", "barrier", "claims back", "chunk loop done", "ticket", "last block done"]), (1, "tile", ["start", "loaded+hist", "scanned", "stored", "end"])):
-    a = st[k]; used = a[:, 0] > 0; a = a[used]
+    a = st[k][1:] if k == 1 else st[k]; used = a[:, 0] > 0; a = a[used][:, :5] if k == 1 else a[used]
     if not len(a): continue
     t0 = a[:, 0].min()
     print(f"{name} kernel: {len(a)} blocks, span {(a.max() - t0) / 100:.1f} us; block starts: min 0 median {np.median(a[:, 0] - t0) / 100:.1f} max {(a[:, 0].max() - t0) / 100:.1f} us")

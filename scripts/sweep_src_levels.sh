@@ -2,8 +2,7 @@
 # Development sweep (needs ab/libdev.so = a `make DEV=1` build): number, cell size and ratio of the scan's own search levels in VGICP.
 out=${1:-gpurun_out/sweep_src}
 mkdir -p $out
-cp simpleslam_amd/lib/libpcr_hip.so $out/lib_orig.so
-cp ab/libdev.so simpleslam_amd/lib/libpcr_hip.so
+export PCR_LIB=$(pwd)/ab/libdev.so      # (the loader's override: the product library is not touched)
 run() {      # cell0 ratio levels
   r=$(PCR_COV_CELL0=$1 PCR_COV_RATIO=$2 PCR_COV_LEVELS=$3 timeout -k 10 200 python bench.py --method vgicp --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],4), round(d['roofline']['target_prep_ms'],4), round(d['roofline']['align_ms'],4))")
   echo "cell0 $1 ratio $2 levels $3 -> $r"
@@ -17,4 +16,4 @@ run 1 4 2
 run 2 3 2
 run 2 3 3
 run 1 6 2
-cp $out/lib_orig.so simpleslam_amd/lib/libpcr_hip.so
+unset PCR_LIB

@@ -375,46 +375,102 @@ __device__ unsigned long long* g_dev_stamps = nullptr;
 static constexpr int kBinStride = 16;                  // counters 64 bytes apart: memory-side atomics on one line serialise
 static constexpr int kBinPerDefault = 8;              // points per thread and chunk of the bin kernel
 
+// ---- BINS: the units of the two passes.  A build without a layout hint bins by TILE (2^shift consecutive cells: bin b = tile b).  A ground tile of a
+// 1 m grid over a 0.5 m map holds eight times the points of the median tile, and the tile pass lasted as long as its heaviest tile's ONE block (24 us of
+// chunked two-pass work against a median block of 5 us at 1 M points; 151-165 us against 11.5 at 10 M: profiles/r04_notes.md).  So the LAYOUT a build
+// leaves for the next one (one block of its tile pass plans it beside the others: plan_next_layout) cuts the tiles that were heavy into 2^k equal
+// SLABS of cells -- k per tile, one step up or down per build -- and the bin pass of the next build, which places by that layout anyway, takes a
+// point's bin from a per-tile word in LDS: base + (key >> (shift - k)) & (2^k - 1).  A bin is a run of whole cells in cell order, so the sorted cloud
+// and the cell table are the same whatever the cut.  Layout buffer (uint32 words; two, alternating):
+//   [0 .. nb]              where bin b's points go in `tiled` (room: what the bin held + an eighth + 32; the children of a tile cut one step further
+//                          get their parent's room each, a tile merged one step its children's sum)   [nb] = total room
+//   [kLaySub + t]          tile t: first bin | k << 13
+//   [kLayMap + b]          bin b: tile | slab << 13 | k << 26
+//   [kLayMeta]             nb (0: no usable layout), [kLayMeta + 1] tiles of the header the layout was made for
+static constexpr uint32_t kLaySub = kMaxBins + 8, kLayMap = 2 * kMaxBins + 16, kLayMeta = 3 * kMaxBins + 24, kLayWords = 3 * kMaxBins + 32;
+static constexpr int kMaxSplit = 6;                    // at most 64 slabs per tile (and never fewer than 4 cells per slab)
+
+template <int kThreads>
+__device__ inline unsigned long long block_exclusive_scan_u64(unsigned long long v, unsigned long long* total, unsigned long long* sh /* >= kThreads / 64 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    unsigned long long off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) { const unsigned long long x = sh[w]; if (w < wave) off += x; tot += x; }
+    *total = tot;
+    return off + inc - v;
+}
+
 template <bool kVec>
 __device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i, uint32_t stride, float& x, float& y, float& z) {
     if (kVec) { const float4 v = *reinterpret_cast<const float4*>(pts + i * stride); x = v.x; y = v.y; z = v.z; }
     else { const float* p = pts + i * stride; x = p[0]; y = p[1]; z = p[2]; }
 }
 
-// dynamic LDS: max_bins counters (max_bins = tiles the cell table's capacity can make: host-known)
-// kPlace: the build has a LAYOUT HINT -- lay_cur[t] = where tile t's points go in `tiled`, with room for an eighth more than the tile
-// held in the previous build (+32), written by the previous build's last block -- and moves every point to its tile right here:
+// dynamic LDS: nb_max counters (nb_max = bins this build can have: host-known; without a layout = max_tiles, the tiles the cell table's
+// capacity can make) + (kPlace) as many + 1 places + (kSub) the tiles' words, 16 bits each
+// kPlace: the build has a LAYOUT HINT -- lay_cur[b] = where bin b's points go in `tiled`, with room for an eighth more than the bin held in the
+// previous build (+32), planned by the previous build's tile pass -- and moves every point to its bin right here:
 // the separate placing pass (a second read of the cloud, 15 us at 1 M points) disappears.  A sub-map changes by a key frame at a
-// time, so the room nearly always suffices; a tile that outgrows it raises header.stale, nothing is stored out of bounds, and the
-// caller rebuilds without hints (the same protocol as the bounding-box hint that this path requires anyway).
-template <bool kVec, int kBinPer, bool kPlace>
+// time, so the room nearly always suffices; a bin that outgrows it raises header.stale, nothing is stored out of bounds (every store is
+// checked against the room and the buffer), and the caller rebuilds without hints (the same protocol as the bounding-box hint that this path
+// requires anyway).  kSub: the layout may hold tiles that are cut (see BINS): a point's bin comes from its tile's word; without it bin = tile, the
+// kernel of round 4 (the words cost the 10 M-point map's bin pass its third block per CU, and clouds of that size are never cut).
+template <bool kVec, int kBinPer, bool kPlace, bool kSub>
 __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
-                                                       uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_bins,
-                                                       uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start, uint32_t* __restrict__ lay_next,
+                                                       uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_tiles, uint32_t nb_max,
+                                                       uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start,
                                                        const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
                                                        const uint8_t* __restrict__ keep_mask, int keep_mshift) {
     // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
     // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
+    static_assert(kPlace || !kSub, "tiles are cut by a layout only");
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     uint32_t* const hist = dyn_lds;
-    uint32_t* const sh_lay = dyn_lds + max_bins;      // kPlace: max_bins + 1 entries
+    uint32_t* const sh_lay = dyn_lds + nb_max;      // kPlace: nb_max + 1 entries
+    uint16_t* const sh_sub = reinterpret_cast<uint16_t*>(dyn_lds + 2 * (size_t)nb_max + 2);      // kSub: max_tiles entries (first bin | k << 13)
     DEV_STAMP(0, 0);
+    constexpr uint32_t kBinChunk = 256u * kBinPer;      // points a block histograms at a time
+    float px[kBinPer], py[kBinPer], pz[kBinPer];
+    const uint32_t c_first = blockIdx.x * kBinChunk;
+    if (c_first < n) {      // the first chunk's points are requested before the header has arrived: two independent round trips overlap
+#pragma unroll
+        for (int u = 0; u < kBinPer; ++u) {
+            const uint32_t i = c_first + u * 256 + threadIdx.x;
+            load_xyz<kVec>(pts, i < n ? i : c_first, stride, px[u], py[u], pz[u]);
+        }
+    }
+    uint32_t nb_lay = 0, nt_lay = 0;
+    if (kPlace) { nb_lay = lay_cur[kLayMeta]; nt_lay = lay_cur[kLayMeta + 1]; }      // (requested beside the header)
     const GridHeader h = *hdr;
     if (h.overflow || h.empty) return;
-    const uint32_t nbins_h = (uint32_t)(h.n_cells >> shift) + 1u;
-    for (uint32_t b = threadIdx.x; b < max_bins; b += 256) hist[b] = 0u;
-    if (kPlace) { for (uint32_t b = threadIdx.x; b <= max_bins; b += 256) sh_lay[b] = b <= nbins_h ? lay_cur[b] : 0u; }
+    const uint32_t ntiles = (uint32_t)(h.n_cells >> shift) + 1u;
+    const uint32_t nb = kPlace ? nb_lay : ntiles;
+    if (kPlace) {
+        // (a layout made for another lattice, one that holds cuts this kernel does not read, or none: nothing is binned, the caller rebuilds without hints)
+        if (nb == 0u || nb > nb_max || nt_lay != ntiles || ntiles > max_tiles || (!kSub && nb != ntiles)) { if (threadIdx.x == 0) hdr->stale = 1; return; }
+        for (uint32_t b = threadIdx.x; b <= nb; b += 256) sh_lay[b] = lay_cur[b];
+        if (kSub) for (uint32_t t = threadIdx.x; t < ntiles; t += 256) sh_sub[t] = (uint16_t)lay_cur[kLaySub + t];
+    }
+    for (uint32_t b = threadIdx.x; b < nb_max; b += 256) hist[b] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    constexpr uint32_t kBinChunk = 256u * kBinPer;      // points a block histograms at a time
-    for (uint32_t c0 = blockIdx.x * kBinChunk; c0 < n; c0 += gridDim.x * kBinChunk) {
+    for (uint32_t c0 = c_first; c0 < n; c0 += gridDim.x * kBinChunk) {
         uint32_t bin[kBinPer], loc[kBinPer];
         bool first[kBinPer];
-        float px[kBinPer], py[kBinPer], pz[kBinPer];
+        if (c0 != c_first) {
 #pragma unroll
-        for (int u = 0; u < kBinPer; ++u) {      // all loads of the chunk in flight
-            const uint32_t i = c0 + u * 256 + threadIdx.x;
-            load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
+            for (int u = 0; u < kBinPer; ++u) {      // all loads of the chunk in flight
+                const uint32_t i = c0 + u * 256 + threadIdx.x;
+                load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) {
@@ -422,11 +478,16 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
             uint32_t key;
             bin[u] = 0xffffffffu; loc[u] = 0u;
             bool outside = false;
-            if (i < n && point_key(h, px[u], py[u], pz[u], &key, &outside) && (!kPlace || !keep_mask || roi_mask_holds_cell(h, keep_mask, keep_mshift, key)))
+            if (i < n && point_key(h, px[u], py[u], pz[u], &key, &outside) && (!kPlace || !keep_mask || roi_mask_holds_cell(h, keep_mask, keep_mshift, key))) {
                 bin[u] = key >> shift;
+                if (kSub) {      // the tile's slabs (see BINS above)
+                    const uint32_t e = sh_sub[bin[u]], k = e >> 13;
+                    bin[u] = (e & 0x1fffu) + ((key >> (shift - (int)k)) & ((1u << k) - 1u));
+                }
+            }
             if (outside && !h.clamped) hdr->stale = 1;      // (only a box reused from the previous build can be too small)
-            // one LDS atomic per RUN of equal tiles in consecutive lanes (a cloud stored in a spatially coherent order puts
-            // whole waves into one tile: 64 same-address atomics would serialise)
+            // one LDS atomic per RUN of equal bins in consecutive lanes (a cloud stored in a spatially coherent order puts
+            // whole waves into one bin: 64 same-address atomics would serialise)
             const uint32_t prev = __shfl_up(bin[u], 1, 64);
             const bool leader = lane == 0 || prev != bin[u];
             const unsigned long long lead = __ballot(leader);
@@ -436,14 +497,14 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
             const int end = above ? __ffsll((long long)above) - 1 : 64;
             uint32_t base = 0;
             if (leader && bin[u] != 0xffffffffu) base = atomicAdd(&hist[bin[u]], (uint32_t)(end - start));
-            first[u] = leader && bin[u] != 0xffffffffu && base == 0u;      // this lane opened the tile in this chunk
+            first[u] = leader && bin[u] != 0xffffffffu && base == 0u;      // this lane opened the bin in this chunk
             base = __shfl(base, start, 64);
             loc[u] = base + (uint32_t)(lane - start);
         }
         DEV_STAMP(0, 1);
         __syncthreads();
         DEV_STAMP(0, 2);
-        // the lane that opened a tile claims room for all the chunk's points of that tile: one global atomic per (chunk, tile)
+        // the lane that opened a bin claims room for all the chunk's points of that bin: one global atomic per (chunk, bin)
         uint32_t cnt[kBinPer], got[kBinPer];
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) cnt[u] = first[u] ? hist[bin[u]] : 0u;
@@ -465,7 +526,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                     else over = true;
                 }
             }
-            if (over) hdr->stale = 1;      // the tile has outgrown the room the previous build left it
+            if (over) hdr->stale = 1;      // the bin has outgrown the room the previous build left it
         } else {
 #pragma unroll
             for (int u = 0; u < kBinPer; ++u) {
@@ -478,9 +539,14 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         for (int u = 0; u < kBinPer; ++u) if (first[u]) hist[bin[u]] = 0u;      // ready for the next chunk
         __syncthreads();
     }
-    // ---- the last block to finish turns the tile counters (64 bytes apart, written by device-scope atomics) into the compact
-    //      exclusive scan the next two kernels read: bin_start[0 .. nbins] ----
     DEV_STAMP(0, 4);
+    // ---- the last block to finish turns the bin counters (64 bytes apart, written by device-scope atomics) into the compact
+    //      exclusive scan the next two kernels read: bin_start[0 .. nb]  (the layout of the NEXT build is planned by a block of the tile
+    //      pass, beside the others: tile_block0 -- here it was another block scan on the one chain every block of the next kernel waits for).
+    //      Measured and not kept, round 5 (profiles/r05_notes.md): the scan by block 0 of the tile pass, published to the other blocks as tagged words
+    //      they poll (its 8 K counter loads queue behind the 16 MB the other blocks ask for at the same moment: published after 12 us); a second, compact
+    //      set of counters added up by atomics nobody waits for, summed by every block of the tile pass for itself (sixteen counters to a line: the
+    //      claims beside them came back after 25 us instead of 16) ----
     __shared__ uint32_t sh_last, sh4[4];
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's claims have been acknowledged (they returned values)
@@ -489,38 +555,32 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     __syncthreads();
     DEV_STAMP(0, 5);
     if (!sh_last) return;
-    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
-    const uint32_t per = (nbins + 255u) / 256u;      // <= kMaxBins / 256 = 32
+    const uint32_t per = (nb + 255u) / 256u;      // <= kMaxBins / 256 = 32
     const uint32_t b0 = threadIdx.x * per;
     uint32_t c[kMaxBins / 256];
+    // all of a thread's counters requested before the first is used: UNCONDITIONAL loads of clamped indices, 8 / 16 / 32 of them by the (block-uniform)
+    // length of a thread's run (a load under a per-element condition waits for the one before it: 0.7 us apiece, measured in round 5)
 #pragma unroll
-    for (uint32_t j = 0; j < kMaxBins / 256; ++j)      // all of a thread's counters requested before the first is used
-        c[j] = (j < per && b0 + j < nbins) ? __hip_atomic_load(&bin_count[(size_t)(b0 + j) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j) c[j] = 0u;
+    if (per <= 8u) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (per <= 16u) {
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < kMaxBins / 256; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < kMaxBins / 256; ++j) sum += c[j];
+    for (uint32_t j = 0; j < kMaxBins / 256; ++j) { if (!(j < per && b0 + j < nb)) c[j] = 0u; sum += c[j]; }
     uint32_t total;
     uint32_t off = block_exclusive_scan_256(sum, &total, sh4);
 #pragma unroll
     for (uint32_t j = 0; j < kMaxBins / 256; ++j)
-        if (j < per && b0 + j < nbins) { bin_start[b0 + j] = off; off += c[j]; }
-    if (threadIdx.x == 255) bin_start[nbins] = total;
-    // ... and into the layout the NEXT build may place its points by: every tile gets an eighth more room than it holds now
-    if (kPlace && keep_mask) {      // (a build of a region: the counts are not the cloud's; the layout it came with stays)
-        for (uint32_t b = threadIdx.x; b <= nbins; b += 256) lay_next[b] = lay_cur[b];
-        if (threadIdx.x == 0) *ticket = 0u;
-        return;
-    }
-    __syncthreads();      // sh4 is reused
-    uint32_t room = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kMaxBins / 256; ++j) if (j < per && b0 + j < nbins) room += c[j] + (c[j] >> 3) + 32u;
-    uint32_t room_total;
-    uint32_t lo = block_exclusive_scan_256(room, &room_total, sh4);
-#pragma unroll
-    for (uint32_t j = 0; j < kMaxBins / 256; ++j)
-        if (j < per && b0 + j < nbins) { lay_next[b0 + j] = lo; lo += c[j] + (c[j] >> 3) + 32u; }
-    if (threadIdx.x == 255) lay_next[nbins] = room_total;
+        if (j < per && b0 + j < nb) { bin_start[b0 + j] = off; off += c[j]; }
+    if (threadIdx.x == 255) bin_start[nb] = total;
     if (threadIdx.x == 0) *ticket = 0u;                        // ready for the next build
     DEV_STAMP(0, 6);
 }
@@ -566,8 +626,135 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
     }
 }
 
-// One block per tile.  Dynamic LDS: the tile's cell histogram (2^shift counters).  A tile of up to 256 * kTilePer points
-// is held in registers between the two passes (all its loads in flight at once); a larger one goes through the generic loop
+// ---- block 0 of the tile pass: the layout of the NEXT build, planned beside the blocks that sort ----
+// In: this build's bin_start (points per bin) and the layout the cloud was binned by (lay_cur; nullptr: by tile).  Out: lay_next.  Per tile, with k the
+// current number of cuts: one more when its fullest slab holds more than `hs` points (and a slab would keep >= 4 cells), one fewer when every pair of
+// sibling slabs together holds <= hs / 2 (hysteresis: a tile does not flap), else unchanged -- never more than nb_max bins in all (then nothing is
+// cut further).  A thread owns a run of consecutive tiles, hence of consecutive bins: one block scan of (bins, room) gives every thread its first bin
+// and its first position in `tiled`.  copy_only (a build of a region: its counts are not the cloud's): the layout is handed on as it came.
+// (Measured and not kept, round 5: the scan of the bin counters here too, its results published to the other blocks of the launch as tagged 64-bit
+//  words they polled -- it takes the ticket and the last block's scan off the bin pass, but block 0's 8 K counter loads queue behind the 16 MB the
+//  other blocks ask for at the same moment: published after 12 us at 1 M points, 28 us at 10 M, every block waiting; profiles/r05_notes.md.)
+struct TilePlan { uint32_t* lay_next; uint32_t hs; uint32_t nb_max; int32_t enabled; int32_t copy_only; int32_t cuts; int32_t pad_; };      // cuts: tiles may be cut (hs finite) -- else bin = tile, always
+
+template <int kThreads>
+__device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const uint32_t* __restrict__ bin_start,
+                            const uint32_t* __restrict__ lay_cur, const TilePlan plan, uint32_t* lds) {
+    __shared__ unsigned long long sh_scan[kThreads / 64];
+    uint32_t nb_lay = 0;
+    if (lay_cur) nb_lay = lay_cur[kLayMeta];
+    const GridHeader h = *hdr;
+    uint32_t* const out = plan.lay_next;
+    const uint32_t ntiles = (uint32_t)(h.n_cells >> shift) + 1u;
+    const uint32_t nb = lay_cur ? nb_lay : ntiles;
+    const bool unusable = h.overflow || h.empty || h.stale || nb == 0u || nb > plan.nb_max || ntiles > (uint32_t)kMaxBins;
+    if (unusable) {      // nothing to go by: no layout for the next build (the other blocks leave before they poll)
+        if (threadIdx.x == 0) { out[kLayMeta] = 0u; out[kLayMeta + 1] = 0u; }
+        return;
+    }
+    if (!plan.cuts && nb == ntiles && !plan.copy_only) {
+        // bin = tile now and next time (the layouts of clouds that are never cut: NDT's and VGICP's lattices, maps of millions of points): a thread's run
+        // of tiles straight from bin_start -- UNCONDITIONAL loads of clamped indices, 9 / 17 / 33 by the block-uniform length of the run -- and one block
+        // scan of the rooms; no LDS beyond the scan's (this launch's other blocks keep the occupancy their histogram allows)
+        __shared__ uint32_t sh_scan32[kThreads / 64];
+        const uint32_t per = (nb + kThreads - 1) / kThreads, b0 = threadIdx.x * per;      // <= kMaxBins / 256 = 32
+        // (eight tiles at a time -- nine loads in flight -- so that this block's registers stay below what the sorting blocks of the same kernel need)
+        uint32_t room = 0;
+        for (uint32_t j0 = 0; j0 < per; j0 += 8u) {
+            uint32_t c[9];
+#pragma unroll
+            for (uint32_t j = 0; j <= 8; ++j) c[j] = bin_start[min(b0 + j0 + j, nb)];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) if (j0 + j < per && b0 + j0 + j < nb) { const uint32_t e = c[j + 1] - c[j]; room += e + (e >> 3) + 32u; }
+        }
+        uint32_t room_total;
+        uint32_t lo = block_exclusive_scan<kThreads>(room, &room_total, sh_scan32);
+        for (uint32_t j0 = 0; j0 < per; j0 += 8u) {
+            uint32_t c[9];
+#pragma unroll
+            for (uint32_t j = 0; j <= 8; ++j) c[j] = bin_start[min(b0 + j0 + j, nb)];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j)
+                if (j0 + j < per && b0 + j0 + j < nb) {
+                    const uint32_t e = c[j + 1] - c[j], b = b0 + j0 + j;
+                    out[b] = lo; out[kLaySub + b] = b; out[kLayMap + b] = b;
+                    lo += e + (e >> 3) + 32u;
+                }
+        }
+        if (threadIdx.x == 0) { out[nb] = room_total; out[kLayMeta] = nb; out[kLayMeta + 1] = ntiles; }
+        return;
+    }
+    uint32_t* const start = lds;                                                            // nb + 1 (<= nb_max + 1)
+    uint16_t* const sub = reinterpret_cast<uint16_t*>(lds + plan.nb_max + 2);              // ntiles: first bin | k << 13
+    for (uint32_t i = threadIdx.x; i <= nb; i += kThreads) start[i] = bin_start[i];
+    if (plan.copy_only) {
+        if (!lay_cur) { if (threadIdx.x == 0) { out[kLayMeta] = 0u; out[kLayMeta + 1] = 0u; } return; }
+        for (uint32_t i = threadIdx.x; i <= nb; i += kThreads) out[i] = lay_cur[i];
+        for (uint32_t i = threadIdx.x; i < ntiles; i += kThreads) out[kLaySub + i] = lay_cur[kLaySub + i];
+        for (uint32_t i = threadIdx.x; i < nb; i += kThreads) out[kLayMap + i] = lay_cur[kLayMap + i];
+        if (threadIdx.x == 0) { out[kLayMeta] = nb; out[kLayMeta + 1] = ntiles; }
+        return;
+    }
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kThreads) sub[t] = lay_cur ? (uint16_t)lay_cur[kLaySub + t] : (uint16_t)t;
+    __syncthreads();
+    const int kmax = plan.cuts ? min(kMaxSplit, shift - 2) : 0;      // (no cuts: a layout that holds some -- planned when the cloud was smaller -- is merged back step by step)
+    const uint32_t per = (ntiles + kThreads - 1) / kThreads, t0 = min(threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
+    // what becomes of tile t: new k in the low bits of the result, its room << 8
+    auto decide = [&](uint32_t t, bool may_cut) -> unsigned long long {
+        const uint32_t e = sub[t], base = e & 0x1fffu;
+        const int k = (int)(e >> 13);
+        const uint32_t nc = 1u << k;
+        uint32_t maxc = 0, maxpair = 0, prev = 0;
+        unsigned long long same = 0, merged = 0;
+        for (uint32_t i = 0; i < nc; ++i) {
+            const uint32_t c = start[base + i + 1] - start[base + i];
+            maxc = max(maxc, c);
+            same += (unsigned long long)c + (c >> 3) + 32u;
+            if (i & 1u) { const uint32_t s2 = prev + c; maxpair = max(maxpair, s2); merged += (unsigned long long)s2 + (s2 >> 3) + 32u; }
+            prev = c;
+        }
+        if (may_cut && maxc > plan.hs && k < kmax) return (unsigned long long)(k + 1) | ((2ull * same) << 8);      // (both children get their parent's room)
+        if (k > 0 && maxpair <= plan.hs / 2u) return (unsigned long long)(k - 1) | (merged << 8);
+        return (unsigned long long)k | (same << 8);
+    };
+    bool may_cut = true;
+    unsigned long long mine = 0, total = 0, off = 0;      // bins << 40 | room
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        mine = 0;
+        for (uint32_t t = t0; t < t1; ++t) { const unsigned long long d = decide(t, may_cut); mine += (1ull << (40 + (d & 0xffu))) + (d >> 8); }
+        off = block_exclusive_scan_u64<kThreads>(mine, &total, sh_scan);
+        __syncthreads();      // sh_scan is reused
+        if ((total >> 40) <= (unsigned long long)plan.nb_max) break;      // (block-uniform)
+        may_cut = false;      // too many bins: nothing is cut further (merges only: never more bins than now)
+    }
+    if ((total >> 40) > (unsigned long long)plan.nb_max || (total & 0xffffffffffull) > 0xfffffff0ull) {      // (cannot happen with nb <= nb_max; a layout nobody can use says so)
+        if (threadIdx.x == 0) { out[kLayMeta] = 0u; out[kLayMeta + 1] = 0u; }
+        return;
+    }
+    uint32_t nbin = (uint32_t)(off >> 40), pos = (uint32_t)(off & 0xffffffffffull);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t e = sub[t], base = e & 0x1fffu;
+        const int k = (int)(e >> 13), kn = (int)(decide(t, may_cut) & 0xffu);
+        out[kLaySub + t] = nbin | ((uint32_t)kn << 13);
+        for (uint32_t i = 0; i < (1u << kn); ++i) {
+            uint32_t est;
+            if (kn == k) est = start[base + i + 1] - start[base + i];
+            else if (kn > k) est = start[base + (i >> 1) + 1] - start[base + (i >> 1)];
+            else est = start[base + 2 * i + 2] - start[base + 2 * i];
+            out[kLayMap + nbin] = t | (i << 13) | ((uint32_t)kn << 26);
+            out[nbin] = pos;
+            pos += est + (est >> 3) + 32u;
+            ++nbin;
+        }
+    }
+    if (threadIdx.x == kThreads - 1) { out[nbin] = pos; out[kLayMeta] = nbin; out[kLayMeta + 1] = ntiles; }      // (the last thread ends at the totals)
+}
+
+// The other blocks: a bin each (a tile, or one of the slabs a heavy tile was cut into: see BINS above), bin after bin -- the grid is sized to what the
+// device holds at once, and what a block needs to know of its NEXT bin (points, place, cells) is requested while it works on the current one: a block
+// launched per bin paid that round trip, and the header's, in front of every bin (round 5: median block 5.5 us, of which 2 before its points were asked for).
+// Dynamic LDS: the bin's cell histogram (<= 2^shift counters; block 0 keeps the bins' positions and the tiles' words there).  A bin of up to
+// 256 * kTilePer points is held in registers between the two passes (all its loads in flight at once); a larger one goes through the generic loop
 // (ranks parked in global scratch).
 // kTilePer = 16 (64 VGPRs of points; the kernel then needs 223 VGPRs: TWO waves per SIMD, 512 blocks in flight).  That is right for a
 // grid whose tiles all hold several hundred points (LOAM's 1 m cells over a 0.5 m map), and wrong for a fine lattice over the same map:
@@ -576,51 +763,74 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
 // points with one point per thread (few VGPRs, many blocks in flight), kMode 2 the others with sixteen; kMode 0 = every tile (dense grids).
 // kTail (NDT's region-only targets, pcr_internal.h: TileTail): while a tile's cell counts are in registers the cells that will carry a voxel
 // are listed and every cell's slot is written -- ndt_candidates_kernel's work without its launch and without reading the table again.
-template <int kTilePer, int kMode, int kThreads, bool kTail = false>
-// src_start: where tile t's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
+template <int kTilePer, int kMode, int kThreads, bool kTail, bool kPlan>
+// kPlan: the launch that carries block 0 (tile_block0; plan.enabled says whether it does).  src_start: where bin b's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
+// lay_cur: the layout the points were binned by (nullptr: by tile).  plan.enabled: block 0 is tile_block0 and sorts nothing.
 __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
                                                         float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
-                                                        const uint32_t* __restrict__ src_start, const TileTail tail) {
+                                                        const uint32_t* __restrict__ src_start, const uint32_t* __restrict__ lay_cur, const TilePlan plan, const TileTail tail) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-    uint32_t* const hist = dyn_lds;                    // 1 << shift
+    uint32_t* const hist = dyn_lds;                    // <= 1 << shift
     __shared__ uint32_t sh4[kThreads / 64];
     __shared__ unsigned long long sh_sq[kThreads / 64];
     __shared__ uint32_t sh_tail_base;
     DEV_STAMP(1, 0);
-    if (kTail && blockIdx.x == 0 && threadIdx.x == 0) *tail.count_next = 0u;      // (the other of two counters, for the next call: before anything can return)
+    const uint32_t first_blk = kPlan && plan.enabled ? 1u : 0u;
+    const uint32_t blk = blockIdx.x - first_blk, nblk = gridDim.x - first_blk;      // (block 0 of a planning launch never uses them)
+    // what this block needs to know of its first bin, requested beside the header (the indices are in bounds for every block of the grid: <= kMaxBins blocks)
+    const bool worker = !(kPlan && plan.enabled && blockIdx.x == 0);
+    uint32_t i_p0 = 0, i_p1 = 0, i_q0 = 0, i_map = 0;
+    auto fetch = [&](uint32_t b) {
+        i_p0 = bin_start[b]; i_p1 = bin_start[b + 1];
+        i_q0 = src_start[b];
+        if (lay_cur) i_map = lay_cur[kLayMap + b];
+    };
+    if (worker) fetch(min(blk, (uint32_t)kMaxBins));
+    uint32_t nb_lay = 0;
+    if (lay_cur) nb_lay = lay_cur[kLayMeta];
+    if (kTail && blockIdx.x == first_blk && threadIdx.x == 0) *tail.count_next = 0u;      // (the other of two counters, for the next call: before anything can return)
+    if (kPlan && !worker) { tile_block0<kThreads>(hdr_in, shift, bin_start, lay_cur, plan, dyn_lds); return; }
     const GridHeader h = *hdr_in;
     if (kTail && h.empty && !h.overflow)      // nothing indexed: no cell carries a voxel
-        for (uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x; t < h.n_cells; t += (uint64_t)gridDim.x * kThreads) tail.vox_slot[t] = 0u;
+        for (uint64_t t = (uint64_t)blk * kThreads + threadIdx.x; t < h.n_cells; t += (uint64_t)nblk * kThreads) tail.vox_slot[t] = 0u;
     if (h.overflow || h.empty) return;
-    const uint32_t nbins = (uint32_t)(h.n_cells >> shift) + 1u;
-    const uint32_t S = 1u << shift;
+    const uint32_t ntiles = (uint32_t)(h.n_cells >> shift) + 1u;
+    uint32_t nb = lay_cur ? nb_lay : ntiles;
     if (h.stale) {
-        // a hint did not hold (points outside the box, or a tile without room: not every point was stored): nothing here can be
+        // a hint did not hold (points outside the box, or a bin without room: not every point was stored): nothing here can be
         // trusted and the caller rebuilds.  Only the counters are put back to zero, the state every build expects.
-        for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;
+        if (nb == 0u || nb > (uint32_t)kMaxBins) nb = (uint32_t)kMaxBins;
+        for (uint32_t b = blk; b < nb; b += nblk) if (threadIdx.x == 0) bin_count[(size_t)b * kBinStride] = 0u;
         return;
     }
-    for (uint32_t tile = blockIdx.x; tile < nbins; tile += gridDim.x) {
+    if (nb > plan.nb_max || ntiles > (uint32_t)kMaxBins) return;      // (block 0 has left too: see tile_block0)
+    for (uint32_t bin = blk; bin < nb; bin += nblk) {
         // (taking the heavy tiles first -- an order written by the bin kernel's last block -- was measured: the kernel's span is its heaviest
         //  tile's own 24 us wherever it starts, and the extra scan cost the bin kernel's serial tail 3 us; profiles/r04_notes.md)
-        const uint32_t p0 = bin_start[tile], p1 = bin_start[tile + 1], np = p1 - p0;
-        const uint32_t q0 = src_start[tile];      // first point of the tile in `tiled`
-        const uint64_t cell0 = (uint64_t)tile << shift;
-        if (kMode == 1 && np > 256u) continue;          // (block-uniform: the other instantiation's tile)
-        if (kMode == 2 && np <= 256u) continue;
+        if (bin != blk) fetch(bin);
+        const uint32_t p0 = i_p0, np = i_p1 - i_p0;
+        const uint32_t q0 = i_q0;      // first point of the bin in `tiled`
+        uint64_t cell0 = (uint64_t)bin << shift;
+        uint32_t S = 1u << shift;
+        if (lay_cur) {
+            const uint32_t m = i_map, k = m >> 26;
+            S = 1u << (shift - (int)k);
+            cell0 = ((uint64_t)(m & 0x1fffu) << shift) + (uint64_t)((m >> 13) & 0x1fffu) * S;
+        }
+        const bool mine = !(kMode == 1 && np > 256u) && !(kMode == 2 && np <= 256u);      // (block-uniform: else the other instantiation's bin)
         const bool small = np <= (uint32_t)kThreads * kTilePer;      // block-uniform
         float4 p[kTilePer];
         uint32_t cr[kTilePer];
-        if (small) {
+        if (mine && small) {
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {      // all loads in flight, issued before anything waits
                 const uint32_t j = u * (uint32_t)kThreads + threadIdx.x;
                 if (u * (uint32_t)kThreads < np) p[u] = tiled[q0 + (j < np ? j : 0u)];
             }
         }
+        if (!mine) continue;
         for (uint32_t c = threadIdx.x * 4u; c < S; c += 4u * kThreads) *reinterpret_cast<uint4*>(hist + c) = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x == 0) bin_count[(size_t)tile * kBinStride] = 0u;      // the counters are left zeroed: the state the next build expects
         __syncthreads();
         if (small) {
 #pragma unroll
@@ -634,7 +844,8 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
                     cr[u] = (c << 18) | atomicAdd(&hist[c], 1u);          // c < 2^13, rank < 4096 <= 2^18
                 }
             }
-        } else {
+        }
+        if (!small) {
             for (uint32_t j0 = 0; j0 < np; j0 += (uint32_t)kThreads * kTilePer) {      // chunks of 4096 points, their loads in flight together
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) { const uint32_t j = j0 + u * (uint32_t)kThreads + threadIdx.x; p[u] = tiled[q0 + (j < np ? j : 0u)]; }
@@ -649,9 +860,10 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
                 }
             }
         }
+        if (threadIdx.x == 0) bin_count[(size_t)bin * kBinStride] = 0u;      // the counters are left zeroed: the state the next build expects
         __syncthreads();
-        if (tile == blockIdx.x) DEV_STAMP(1, 1);
-        // exclusive scan of the tile's counters -> cell_start (+ sum of count^2, the density estimate of the header)
+        if (bin == blk) DEV_STAMP(1, 1);
+        // exclusive scan of the bin's counters -> cell_start (+ sum of count^2, the density estimate of the header)
         unsigned long long sq = 0;
         uint32_t carry = 0;
         uint32_t listed = 0;      // kTail: bit (4 * round + k) = cell k of this thread's four in that round goes on the list (<= 8 rounds: 2^13 cells per tile)
@@ -685,11 +897,12 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
             __syncthreads();      // sh4 is reused by the next round
             if (c < S) {
                 const uint4 st = make_uint4(o, o + v.x, o + v.x + v.y, o + v.x + v.y + v.z);
-                *reinterpret_cast<uint4*>(hist + c) = st;                                     // hist now holds the offsets inside the tile
+                *reinterpret_cast<uint4*>(hist + c) = st;                                     // hist now holds the offsets inside the bin
                 const uint64_t g = cell0 + c;
                 if (g + 3 <= h.n_cells) *reinterpret_cast<uint4*>(cell_start + g) = make_uint4(p0 + st.x, p0 + st.y, p0 + st.z, p0 + st.w);
                 else {
                     const uint32_t e[4] = {p0 + st.x, p0 + st.y, p0 + st.z, p0 + st.w};
+#pragma unroll
                     for (int k = 0; k < 4; ++k) if (g + k <= h.n_cells) cell_start[g + k] = e[k];      // (entry n_cells = number of indexed points)
                 }
             }
@@ -699,23 +912,23 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
         for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
         if ((threadIdx.x & 63) == 0) sh_sq[threadIdx.x >> 6] = sq;
         __syncthreads();
-        // (one 8-byte store per tile; thousands of blocks adding into one header word serialise at the memory side for ~45 us)
-        if (threadIdx.x == 0) { unsigned long long t_ = 0; for (int w = 0; w < kThreads / 64; ++w) t_ += sh_sq[w]; tile_sq[tile] = t_; }
+        // (one 8-byte store per bin; thousands of blocks adding into one header word serialise at the memory side for ~45 us)
+        if (threadIdx.x == 0) { unsigned long long t_ = 0; for (int w = 0; w < kThreads / 64; ++w) t_ += sh_sq[w]; tile_sq[bin] = t_; }
         if (kTail) {
-            // room on the list for all of the tile's cells with ONE atomic (the order of the list is immaterial: ndt_voxel_kernel takes a cell per thread)
+            // room on the list for all of the bin's cells with ONE atomic (the order of the list is immaterial: ndt_voxel_kernel takes a cell per thread)
             uint32_t tot;
             uint32_t pos = block_exclusive_scan<kThreads>((uint32_t)__popc(listed), &tot, sh4);
             if (threadIdx.x == 0) sh_tail_base = tot ? atomicAdd(tail.count, tot) : 0u;
             __syncthreads();
             pos += sh_tail_base;
             while (listed) {
-                const uint32_t b = (uint32_t)__ffs((int)listed) - 1u;
+                const uint32_t bit = (uint32_t)__ffs((int)listed) - 1u;
                 listed &= listed - 1u;
-                if (pos < tail.capacity) tail.list[pos] = (uint32_t)cell0 + (b >> 2) * 4u * kThreads + threadIdx.x * 4u + (b & 3u);      // (capacity = points / min_points: never short)
+                if (pos < tail.capacity) tail.list[pos] = (uint32_t)cell0 + (bit >> 2) * 4u * kThreads + threadIdx.x * 4u + (bit & 3u);      // (capacity = points / min_points: never short)
                 ++pos;
             }
         }
-        if (tile == blockIdx.x) DEV_STAMP(1, 2);
+        if (bin == blk) DEV_STAMP(1, 2);
         if (small) {
 #pragma unroll
             for (int u = 0; u < kTilePer; ++u) {
@@ -742,16 +955,16 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
             }
         }
         __syncthreads();
-        if (tile == blockIdx.x) DEV_STAMP(1, 3);
+        if (bin == blk) DEV_STAMP(1, 3);
     }
     DEV_STAMP(1, 4);
 }
 
 // sum of count^2 over the cells = sum of the tiles' sums -> header (only VGICP's choice of a search cell reads it)
-__global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restrict__ hdr, const unsigned long long* __restrict__ tile_sq, int shift) {
+__global__ __launch_bounds__(256) void grid_density_kernel(GridHeader* __restrict__ hdr, const unsigned long long* __restrict__ tile_sq, int shift, const uint32_t* __restrict__ lay_cur) {
     __shared__ unsigned long long sh[4];
     if (hdr->overflow || hdr->empty) return;
-    const uint32_t nbins = (uint32_t)(hdr->n_cells >> shift) + 1u;
+    const uint32_t nbins = lay_cur ? min(lay_cur[kLayMeta], (uint32_t)kMaxBins) : (uint32_t)(hdr->n_cells >> shift) + 1u;      // (one sum per bin: see BINS)
     unsigned long long s = 0;
     // (sixteen loads in flight per step: one by one the ~13 loads of a thread were a chain of round trips -- 7.8 us for a kernel that adds up 27 KB)
     for (uint32_t b0 = threadIdx.x; b0 < nbins; b0 += 16u * 256u) {
@@ -872,7 +1085,8 @@ hipError_t roi_launch(const GridIndex& lattice, const float* d_src, size_t n_src
 // ---- host side ----------------------------------------------------------------------
 hipError_t GridIndex::enqueue_density(hipStream_t s) {
     if (tiled_shift < 0) return hipSuccess;      // the atomic build path leaves its estimate in header.sum_sq
-    hipLaunchKernelGGL(grid_density_kernel, dim3(1), dim3(256), 0, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), tiled_shift);
+    hipLaunchKernelGGL(grid_density_kernel, dim3(1), dim3(256), 0, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), tiled_shift,
+                       used_layout ? (const uint32_t*)layout[lay_idx ^ 1].as<uint32_t>() : (const uint32_t*)nullptr);      // (the layout the last build was binned by: build() has flipped lay_idx since)
     return hipGetLastError();
 }
 
@@ -1009,7 +1223,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     // ~2048 tiles when the table allows it -- 8 KB of LDS counters per block in the bin kernel, tiles of a few hundred to a few
     // thousand points -- never more than kMaxBins.
     if (tiled_path) {
-        const uint32_t max_bins = (uint32_t)(((uint64_t)cap_eff >> tshift) + 2);
+        const uint32_t max_bins = (uint32_t)(((uint64_t)cap_eff >> tshift) + 2);      // tiles the (bounded) cell table can make
         PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
         PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));
@@ -1024,18 +1238,39 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const size_t bin_chunk = (size_t)256 * bin_per;
         const int bin_blocks = (int)std::min<size_t>(4096, (n + bin_chunk - 1) / bin_chunk ? (n + bin_chunk - 1) / bin_chunk : 1);
         const int place_blocks = (int)std::min<size_t>(2048, (n + 1023) / 1024 ? (n + 1023) / 1024 : 1);
-        const int tile_blocks = (int)max_bins;
-        // Layout hint (see grid_bin_kernel<.., kPlace>): the previous build of this index left, next to its header, where each tile's
+        // (a grid with many more cells than points: light tiles and heavy tiles by an instantiation each, see grid_tile_kernel)
+        const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
+        const uint64_t tiles_est = cells_hint ? (cells_hint >> tshift) + 1 : 0;
+        // dense grids: eight points per thread (135 VGPRs, three waves per SIMD) while a tile holds ~1 000 points or fewer on average, sixteen
+        // beyond (A/B: 1 M points in 1 464 tiles 48.4 -> 46.8 us with eight; 5 M and 10 M points are faster with sixteen)
+        const bool per8 = !sparse && tiles_est && n / tiles_est <= 1024;
+        // BINS (see the top of the tiled path): a tile whose fullest slab holds more than `hs` points is cut one step further in the layout this build
+        // leaves -- three quarters of what a block of the tile pass holds in registers -- while the bins stay within nb_max.  pcr_params.index_no_hints:
+        // no layout is ever used, so nothing is cut.
+        // Measured (round 5, A/B on one box, profiles/r05_notes.md): at 1 M points hs = 2 048 or 3 072 takes the tile pass from 26.0 to 18.6 us and costs the bin pass
+        // 1.5 us (more bins: more claims); 1 024 costs it 4 us.  At 10 M points (tiles of 8 192 cells, sixteen points per thread) cutting does NOT pay: the bin
+        // pass's stores scatter over twice the bins (151 -> 186-235 us) and the tile pass, whose length there is blocks x latency / occupancy and not its heaviest
+        // block, stays at 153-169 us: clouds whose tiles hold more than ~1 000 points on average are never cut.
+        uint32_t hs = per8 ? 2048u : 0u;
+        if (const char* e = dev_env("PCR_BIN_SPLIT")) hs = (uint32_t)std::max(0, atoi(e));      // (development: 0 = tiles are never cut)
+        if (hs == 0u) hs = 0xffffffffu;
+        // bins a layout may hold: the tiles + two bins per `hs` points (a slab that was cut holds between hs / 2 and hs), never fewer than the tiles the table
+        // can make, and never fewer than the layout in hand was planned for (the bin pass sizes its LDS by it)
+        uint32_t nb_max = (uint32_t)std::min<uint64_t>((uint64_t)kMaxBins, std::max<uint64_t>((uint64_t)max_bins, (tiles_est ? tiles_est + 2 : (uint64_t)max_bins) + (hs != 0xffffffffu ? 2 * (uint64_t)n / hs : 0)));
+        if (hs == 0xffffffffu && !(lay_ok && lay_cuts)) nb_max = max_bins;
+        if (lay_ok && lay_shift == tshift) nb_max = std::max(nb_max, lay_nb_max);
+        // Layout hint (see grid_bin_kernel<.., kPlace>): the previous build of this index left, next to its header, where each bin's
         // points may go; a build that reuses the header places by it and skips the placing pass.  PCR_INDEX_NO_LAYOUT=1 switches it off.
-        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && dev_env("PCR_INDEX_NO_LAYOUT") == nullptr;
-        PCR_TRY(layout[0].reserve((kMaxBins + 8) * sizeof(uint32_t)));
-        PCR_TRY(layout[1].reserve((kMaxBins + 8) * sizeof(uint32_t)));
-        if (use_layout) {      // room for every tile's slack (the device also checks every store against the capacity it is told)
-            const size_t need = lay_n + lay_n / 8 + (size_t)32 * (max_bins + 1) + 16;
+        const bool use_layout = reuse_header && lay_ok && lay_shift == tshift && lay_nb_max <= nb_max && dev_env("PCR_INDEX_NO_LAYOUT") == nullptr;
+        for (int i = 0; i < 2; ++i)
+            if (!layout[i].p) { PCR_TRY(layout[i].reserve(kLayWords * sizeof(uint32_t))); PCR_TRY(hipMemsetAsync(layout[i].p, 0, kLayWords * sizeof(uint32_t), s)); }      // (meta word 0: no layout)
+        if (use_layout) {      // room for every bin's slack, the children of a tile that is cut one step further get their parent's room each:
+                               // at most twice the cloud's (the device also checks every store against the capacity it is told)
+            const size_t need = 2 * (lay_n + lay_n / 8) + (size_t)32 * (nb_max + 1) + 16;
             if (need > n + 16) PCR_TRY(tiled.reserve(need * sizeof(float4)));
         }
         const uint32_t tiled_cap = (uint32_t)std::min<size_t>(tiled.cap / sizeof(float4), 0xfffffff0u);
-        uint32_t* const lay_cur = layout[lay_idx].as<uint32_t>();
+        const uint32_t* const lay_cur = layout[lay_idx].as<uint32_t>();
         uint32_t* const lay_next = layout[lay_idx ^ 1].as<uint32_t>();
         used_layout = use_layout;
         const uint8_t* keep_mask = nullptr;
@@ -1045,17 +1280,20 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
             keep_mask = filter->mask; keep_mshift = filter->mshift;
             filter->applied = filtered = keep_mask != nullptr;
         }
-        const size_t bin_lds = (size_t)max_bins * 4 + (use_layout ? ((size_t)max_bins + 4) * 4 : 0), place_lds = ((size_t)max_bins + 4) * 4, tile_lds = (size_t)(1u << tshift) * 4;
-#define PCR_LAUNCH_BIN(VEC, PER, PLACE) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
-                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
-                                                    lay_next, lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
-        if (use_layout) {
-            if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, true); else PCR_LAUNCH_BIN(true, 16, true); }
-            else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, true); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, true); else PCR_LAUNCH_BIN(false, 16, true); }
-        } else {
-            if (vec) { if (bin_per == 4) PCR_LAUNCH_BIN(true, 4, false); else if (bin_per == 8) PCR_LAUNCH_BIN(true, 8, false); else PCR_LAUNCH_BIN(true, 16, false); }
-            else { if (bin_per == 4) PCR_LAUNCH_BIN(false, 4, false); else if (bin_per == 8) PCR_LAUNCH_BIN(false, 8, false); else PCR_LAUNCH_BIN(false, 16, false); }
-        }
+        const bool cuts_now = hs != 0xffffffffu;                      // the layout this build plans may cut tiles
+        const bool use_sub = use_layout && lay_cuts;                   // the layout in hand may hold tiles that are cut
+        const bool plan_lds = cuts_now || use_sub;                     // block 0 of the tile pass plans with cuts (or merges some back): it keeps the bins' positions + the tiles' words in LDS
+        const uint32_t nb_bin = use_layout ? nb_max : max_bins;      // bins the bin pass counts in LDS
+        const size_t bin_lds = (size_t)nb_bin * 4 + (use_layout ? ((size_t)nb_bin + 4) * 4 : 0) + (use_sub ? ((size_t)max_bins + 8) * 2 : 0), place_lds = ((size_t)max_bins + 4) * 4,
+                     tile_lds = std::max<size_t>((size_t)(1u << tshift) * 4, plan_lds ? ((size_t)nb_max + 4) * 4 + ((size_t)max_bins + 8) * 2 : 0);
+#define PCR_LAUNCH_BIN(VEC, PER, PLACE, SUB) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE, SUB>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
+                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, nb_bin, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
+                                                    lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
+#define PCR_LAUNCH_BIN_P(VEC, PLACE, SUB) do { if (bin_per == 4) PCR_LAUNCH_BIN(VEC, 4, PLACE, SUB); else if (bin_per == 8) PCR_LAUNCH_BIN(VEC, 8, PLACE, SUB); else PCR_LAUNCH_BIN(VEC, 16, PLACE, SUB); } while (0)
+        if (use_layout && use_sub) { if (vec) PCR_LAUNCH_BIN_P(true, true, true); else PCR_LAUNCH_BIN_P(false, true, true); }
+        else if (use_layout) { if (vec) PCR_LAUNCH_BIN_P(true, true, false); else PCR_LAUNCH_BIN_P(false, true, false); }
+        else { if (vec) PCR_LAUNCH_BIN_P(true, false, false); else PCR_LAUNCH_BIN_P(false, false, false); }
+#undef PCR_LAUNCH_BIN_P
 #undef PCR_LAUNCH_BIN
         if (!use_layout) {
             if (vec)
@@ -1065,31 +1303,41 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
                 hipLaunchKernelGGL(grid_place_kernel<false>, dim3(place_blocks), dim3(256), place_lds, s, d_pts, n32, st, header.as<GridHeader>(), bin_count.as<uint32_t>(),
                                    ranks.as<uint32_t>(), bin_start.as<uint32_t>(), tiled.as<float4>(), tshift);
         }
-        // (a grid with many more cells than points: light tiles and heavy tiles by an instantiation each, see grid_tile_kernel)
-        const bool sparse = split_sparse_tiles && cells_hint > 4 * (uint64_t)n + 65536;
         TileTail tail;
         memset(&tail, 0, sizeof tail);
-#define PCR_LAUNCH_TILE_T(PER, MODE, THREADS, TAIL) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS, TAIL>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
+        // block 0 of the (first) tile launch plans the layout of the next build; the others take a bin each
+        TilePlan plan;
+        plan.lay_next = lay_next; plan.hs = hs; plan.nb_max = nb_max; plan.enabled = 1; plan.copy_only = filtered ? 1 : 0; plan.cuts = cuts_now ? 1 : 0; plan.pad_ = 0;
+        // the tile pass: as many blocks as the device holds at once (a block takes bin after bin), + block 0
+        static const int n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+        int per_cu = 0;      // (0 = a block per bin: persistent blocks -- 6 / 4 / 2 per CU by their registers -- measured no better at 1 M points and 6 % worse at 10 M, round 5)      // (blocks of 256 threads by their registers: 77 / 128 (130 with the tail) / 216 VGPRs)
+        if (const char* e = dev_env("PCR_TILE_PER_CU")) per_cu = std::max(0, atoi(e));      // (development: 0 = a block per bin, as before round 5)
+        // (a block per bin the host EXPECTS -- the tiles of the header it has seen + a bin per hs points when tiles are cut -- not per bin the table could
+        //  make: a block that finds no bin still waits for the header, ~2 us of a slot each, and there were 3 000 of them at 10 M points; a block takes
+        //  bin after bin, so more bins than blocks are served all the same)
+        const uint32_t bins_bound = use_layout ? nb_max : max_bins;
+        const uint32_t bins_expected = tiles_est ? (uint32_t)std::min<uint64_t>(bins_bound, tiles_est + 16 + (use_layout && hs != 0xffffffffu ? (uint64_t)n / hs : 0)) : bins_bound;
+        const int tile_blocks = (int)std::min<uint32_t>(bins_expected, per_cu > 0 ? (uint32_t)(n_cu * per_cu) : bins_expected) + 1;
+#define PCR_LAUNCH_TILE_T(PER, MODE, THREADS, TAIL, PLAN) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS, TAIL, PLAN>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
                            bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
-                           use_layout ? lay_cur : bin_start.as<uint32_t>(), tail)
-#define PCR_LAUNCH_TILE(PER, MODE, THREADS) PCR_LAUNCH_TILE_T(PER, MODE, THREADS, false)
-        // dense grids: eight points per thread (135 VGPRs, three waves per SIMD) while a tile holds ~1 000 points or fewer on average, sixteen
-        // beyond (A/B: 1 M points in 1 464 tiles 48.4 -> 46.8 us with eight; 5 M and 10 M points are faster with sixteen)
+                           use_layout ? lay_cur : (const uint32_t*)bin_start.as<uint32_t>(), use_layout ? lay_cur : (const uint32_t*)nullptr, plan, tail)
+#define PCR_LAUNCH_TILE(PER, MODE, THREADS) PCR_LAUNCH_TILE_T(PER, MODE, THREADS, false, true)
         // (blocks of 1 024 threads for the 5 M and 10 M-point maps -- grid_tile_kernel<4, 0, 1024>, PCR_TILE_WIDE in a development build -- cut the
         //  slowest tile of the 10 M-point map from 165 to 69 us and left the kernel at 165 us: one block per CU then, 19 rounds of ~8 us;
         //  profiles/r04_notes.md)
-        const uint64_t tiles_est = cells_hint ? (cells_hint >> tshift) + 1 : 0;
         static const int wide = dev_env("PCR_TILE_WIDE") ? atoi(dev_env("PCR_TILE_WIDE")) : 0;      // (development: average points per tile from which the wide blocks are used; 0 = never)
         // (the tile pass lists NDT's voxel cells beside its own work: dense grids, tiles of at most 2^13 cells -- 32 per thread)
         const bool with_tail = filtered && filter->want_tail && !sparse && tshift <= 13 && dev_env("PCR_NDT_NO_TAIL") == nullptr;
         if (with_tail) { tail = filter->tail; tail.mask = keep_mask; tail.mshift = keep_mshift; filter->tail_applied = true; }
-        if (sparse) { PCR_LAUNCH_TILE(1, 1, 256); PCR_LAUNCH_TILE(16, 2, 256); }
-        else if (with_tail) { if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE_T(8, 0, 256, true); else PCR_LAUNCH_TILE_T(16, 0, 256, true); }
-        else if (tiles_est && n / tiles_est <= 1024) PCR_LAUNCH_TILE(8, 0, 256);
+        // (sparse grids: the launch of the light tiles carries no planning block -- its 58 registers are what lets eight of its blocks share a CU)
+        if (sparse) { PCR_LAUNCH_TILE_T(1, 1, 256, false, false); PCR_LAUNCH_TILE(16, 2, 256); }
+        else if (with_tail) { if (per8) PCR_LAUNCH_TILE_T(8, 0, 256, true, true); else PCR_LAUNCH_TILE_T(16, 0, 256, true, true); }
+        else if (per8) PCR_LAUNCH_TILE(8, 0, 256);
         else if (wide > 0 && tiles_est && n / tiles_est >= (uint64_t)wide) PCR_LAUNCH_TILE(4, 0, 1024);
         else PCR_LAUNCH_TILE(16, 0, 256);
 #undef PCR_LAUNCH_TILE
 #undef PCR_LAUNCH_TILE_T
+        lay_nb_max = nb_max; lay_cuts = cuts_now || use_sub;
         lay_idx ^= 1; lay_ok = true; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
         if (!filtered) lay_n = n;
         PCR_TRY(hipGetLastError());

@@ -206,10 +206,13 @@ struct GridIndex {
     bool split_sparse_tiles = true;             // sparse grids: light and heavy tiles by an instantiation of the tile kernel each (grid_index.hip)
     bool prefer_one_level = false;              // build by the one-level path (histogram with ranks -> scan -> scatter): a small cloud on a COARSE grid puts
                                                 // a third of its points into one tile, which one block of the tiled path then sorts alone
-    // Layout hint: where each tile's points may go in `tiled` (an eighth more room than the tile held + 32), written by the last block
-    // of every tiled build for the next one; two buffers, alternating.  Used only together with a reused header.
+    // Layout hint: where each BIN's points may go in `tiled` (an eighth more room than the bin held + 32) and which bins the tiles are cut into
+    // (grid_index.hip: BINS), planned by one block of every tiled build's tile pass for the next one; two buffers, alternating.  Used only
+    // together with a reused header.
     DeviceBuf layout[2];
     int lay_idx = 0, lay_shift = -1;
+    uint32_t lay_nb_max = 0;                    // bins the layout in hand was planned for (the next build must have room for as many)
+    bool lay_cuts = false;                      // ... and it may hold tiles that are cut (the bin pass then reads the tiles' words)
     size_t lay_n = 0;
     bool lay_ok = false, used_layout = false;
     bool filtered = false;                      // the last build() indexed the points of a region only (BuildFilter)

@@ -19,7 +19,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
+# PCR_LIB (read HERE, by the Python loader -- the library itself reads no environment variable): another build of the library to load instead of the
+# product, e.g. the development build ab/libdev.so of scripts/build_dev.sh.  The A/B and sweep scripts set it; nothing overwrites lib/libpcr_hip.so.
+LIB_PATH = os.environ.get("PCR_LIB") or os.path.join(_HERE, "lib", "libpcr_hip.so")
 
 
 class PcrParams(C.Structure):
