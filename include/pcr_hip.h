@@ -120,6 +120,9 @@ typedef struct pcr_stats {
      *          (point, voxel) pairs evaluated by the gradient-only passes / by the passes that also accumulate the float Hessian */
     double aux_kernel_ms;
     int64_t region_points, region_voxels, pairs_grad, pairs_hess;
+    /* the handle's last build of its target index: did it reuse the previous target's bounding box (header), and did it place its points by the
+     * previous build's tile layout (both are hints that are checked on the device; a hint that failed shows as 0: the build was redone without it) */
+    int32_t index_box_hint, index_layout_hint;
 } pcr_stats;
 
 void pcr_default_params(pcr_params* p);

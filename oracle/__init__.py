@@ -551,6 +551,43 @@ def submap_assemble(clouds, poses, position, radius, grid):
     return out[:nout.value].copy(), sel[:nsel.value].copy()
 
 
+class SequenceFront:
+    """The CPU side of simpleslam_amd.sequence.drive(): the four steps of the front end's loop by the restatements in this package
+    (voxel_filter, submap_assemble, {loam,ndt,vgicp}_scan2map) -- the checker of the GPU front, and bench.py's cpu_baseline for it."""
+
+    def __init__(self, method, params=None):
+        self.method, self.params = method, params
+        self.clouds, self.kf_poses, self.submap = [], [], np.zeros((0, 4), np.float32)
+
+    def voxel(self, scan, grid):
+        return voxel_filter(scan, grid)[0]
+
+    def scan2map(self, ds, pose):
+        if self.method == "loam":
+            out, conv, info = loam_scan2map(ds, self.submap, pose, self.params)
+            it = info["iters_run"]
+        elif self.method == "ndt":
+            out, conv, info = ndt_scan2map(ds, self.submap, pose, self.params)
+            it = info["iterations"]
+        else:
+            out, conv, info = vgicp_scan2map(ds, self.submap, pose, self.params)
+            it = info["outer"]
+        pose[...] = out
+        return conv, it
+
+    def add_keyframe(self, scan, pose):
+        self.clouds.append(_f32(scan)); self.kf_poses.append(np.array(pose, float))
+
+    def update_map(self, position, radius, grid):
+        self.submap = submap_assemble(self.clouds, self.kf_poses, position, radius, grid)[0]
+
+    def submap_points(self):
+        return self.submap.shape[0]
+
+    def finish(self):
+        pass
+
+
 # ---------------------------------------------------------------------------
 # ScanContext loop-closure descriptor (oracle/scancontext_oracle.c); query's state machine restated here
 # ---------------------------------------------------------------------------

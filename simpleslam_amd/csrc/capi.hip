@@ -151,6 +151,10 @@ struct pcr_handle {
     // peer exchange (pcr_comm_init_peer): this rank's receive buffer (fine-grained HBM, exported over IPC), every rank's as mapped here
     double* peer_own = nullptr;
     bool peer_on = false;
+    bool peer_exported = false;      // pcr_comm_peer_export has cleared the receive buffer for a session that pcr_comm_init_peer has not opened yet
+    bool peer_broken = false;        // an exchange of the session timed out: the ranks' sequence numbers no longer agree, every further exchange is refused
+    int32_t* peer_status_host = nullptr;      // host-mapped: set by a kernel whose exchange timed out
+    int32_t* peer_status_dev = nullptr;
     PeerComm peer{};
     double peer_seq = 0.0;
     pcr_allreduce_fn host_ar = nullptr;     // or the caller's collective (pcr_comm_init_host)
@@ -195,6 +199,21 @@ namespace {
 int fail(pcr_handle* h, const std::string& msg) { h->err = msg; return 1; }
 
 bool sharded(const pcr_handle* h) { return h->comm != nullptr || h->host_ar != nullptr || h->peer_on; }
+// the peer session, if one is open: the peers' buffers unmapped, the transport off (pcr_comm_init / pcr_comm_init_host / a new pcr_comm_init_peer / pcr_destroy)
+void peer_close(pcr_handle* h) {
+    if (h->peer_on) for (int p = 0; p < h->peer.nranks; ++p) if (p != h->peer.rank && h->peer.buf[p]) (void)hipIpcCloseMemHandle(h->peer.buf[p]);
+    memset(&h->peer, 0, sizeof h->peer);
+    h->peer_on = false; h->peer_broken = false; h->peer_seq = 0.0;
+}
+// before an exchange is queued / after its results have arrived: a session in which an exchange timed out is over
+int peer_check(pcr_handle* h) {
+    if (!h->peer_on) return 0;
+    if (h->peer_status_host && __atomic_load_n(h->peer_status_host, __ATOMIC_ACQUIRE) != 0) h->peer_broken = true;
+    if (h->peer_broken)
+        return fail(h, "peer exchange: a rank did not arrive within 2 s; the session is over (the ranks' sequence numbers no longer agree): "
+                       "pcr_comm_peer_export + pcr_comm_init_peer on every rank start a new one");
+    return 0;
+}
 
 // profiling passes: the counters cleared (on the handle's stream, ahead of everything the call queues), the covariance events made
 uint32_t* prof_counters(const pcr_handle* h) { return (h->profile >= 2 && h->prof_count.p) ? h->prof_count.as<uint32_t>() : nullptr; }
@@ -238,14 +257,14 @@ int ranks_allreduce(pcr_handle* h, double* v, int n, int op = 0) {
         return 0;
     }
     if (h->peer_on) {
+        if (peer_check(h)) return 1;
         H_TRY(h->ar_stage.reserve(64 * sizeof(double)));
         H_TRY(hipMemcpyAsync(h->ar_stage.p, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         h->peer_seq += 1.0;
         H_TRY(peer_launch_allreduce(h->ar_stage.as<double>(), n, op, h->peer, h->peer_seq, h->stream));
         H_TRY(hipMemcpyAsync(v, h->ar_stage.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
-        for (int i = 0; i < n; ++i) if (v[i] != v[i]) return fail(h, "peer exchange: a rank did not arrive within 2 s");
-        return 0;
+        return peer_check(h);      // (the status word, not the values: a sum may be NaN in its own right)
     }
     if (h->comm) {
         H_TRY(h->ar_stage.reserve(64 * sizeof(double)));
@@ -432,6 +451,7 @@ int settle_loam_index(pcr_handle* h, const float* d_src, size_t n_src, size_t st
 int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floats, double pose[16], int* converged,
              bool index_timed) {
     if (n_src > 0xfffffff0ull) return fail(h, "source cloud too large");
+    if (peer_check(h)) return 1;
     if (ensure_loam_buffers(h)) return 1;
     const int iters = std::max(0, h->prm.loam_iters);
     const bool shard = sharded(h);
@@ -506,6 +526,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         }
         const LoamResult r = *h->result_host;
         if (r.pad != 1) return fail(h, "LOAM finalize kernel did not complete");
+        if (peer_check(h)) return 1;      // (an exchange of this call timed out: the ranks that waited stopped their loops -- slot 30 -- and the session is over)
         if (r.fail == 2 || rank_fail)      // (every rank sees the flag in the sums of the first linearisation: all return here together)
             return fail(h, rank_fail ? "this rank could not index its map tile: " + rank_err : "sharded scan2map: another rank could not index its map tile");
         if (r.fail == 3) {
@@ -562,6 +583,36 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
     return fail(h, "target index could not be sized");
 }
 
+// ---- host ranges page-locked by pcr_host_pin, and who copies out of them ----
+// pcr_host_unpin must not unregister a range while a copy out of it is in flight.  Every upload that reads a pinned range notes (device, stream)
+// with the range; unpinning waits for exactly those streams -- not for every device of the node (which created a context on each of them, waited
+// for unrelated work, and switched the calling thread's device: ADVICE r4).  A handle that goes away, or is given another stream, takes its
+// entries with it (after waiting for its own stream).
+namespace {
+struct PinUse { int device; hipStream_t stream; };
+struct PinnedRange { const void* p; size_t bytes; std::vector<PinUse> uses; };
+std::mutex g_pin_mu;
+std::vector<PinnedRange> g_pinned;
+void pin_note_copy(const void* src, size_t bytes, int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pinned.empty()) return;
+    const char* a = (const char*)src;
+    for (PinnedRange& r : g_pinned) {
+        const char* b = (const char*)r.p;
+        if (a < b + r.bytes && b < a + bytes) {      // the copy reads from the range
+            bool known = false;
+            for (const PinUse& u : r.uses) known = known || (u.device == device && u.stream == stream);
+            if (!known) r.uses.push_back(PinUse{device, stream});
+        }
+    }
+}
+void pin_forget_stream(hipStream_t stream) {      // (the caller has waited for the stream)
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (PinnedRange& r : g_pinned)
+        for (size_t i = r.uses.size(); i-- > 0;) if (r.uses[i].stream == stream) r.uses.erase(r.uses.begin() + (long)i);
+}
+}  // namespace
+
 // Host clouds are uploaded verbatim.  pcr_params.host_copy_xyz = 1: of records wider than 16 bytes (pcl::PointXYZI is 32: basic.hpp:16 -- what
 // the plugin adapter hands over) only the first 16 bytes cross PCIe, by a pitched copy into a staging area of the SAME stride
 // (nothing downstream changes; whole_records: every field is needed -- pcr_voxel_filter).  Measured and NOT the default: the pitched copy of a
@@ -574,6 +625,7 @@ int stage_host(pcr_handle* h, DeviceBuf* buf, const void* src, size_t n, size_t 
             H_TRY(hipMemcpy2DAsync(buf->p, stride_bytes, src, stride_bytes, 16, n, hipMemcpyHostToDevice, h->stream));
         else
             H_TRY(hipMemcpyAsync(buf->p, src, bytes, hipMemcpyHostToDevice, h->stream));
+        pin_note_copy(src, bytes, h->device, h->stream);
     }
     *out = buf->as<float>();
     return 0;
@@ -1666,11 +1718,12 @@ pcr_handle* pcr_create(const char* method, const pcr_params* p) {
 void pcr_destroy(pcr_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); pin_forget_stream(h->stream); }
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
-    if (h->peer_on) { for (int p = 0; p < h->peer.nranks; ++p) if (p != h->peer.rank && h->peer.buf[p]) (void)hipIpcCloseMemHandle(h->peer.buf[p]); }
+    peer_close(h);
     if (h->peer_own) (void)hipFree(h->peer_own);
+    if (h->peer_status_host) (void)hipHostFree(h->peer_status_host);
     h->prof_count.release();
     for (hipEvent_t e : h->ev_cov) if (e) (void)hipEventDestroy(e);
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
@@ -2197,6 +2250,7 @@ int pcr_get_stats(pcr_handle* h, pcr_stats* out) {
     *out = h->stats;
     out->target_builds = (int32_t)h->target_builds;
     out->region_repeats = (int32_t)h->roi_repeats; out->region_index = (h->roi_on && h->grid.filtered) ? 1 : 0;
+    out->index_box_hint = h->grid.used_hint ? 1 : 0; out->index_layout_hint = h->grid.used_layout ? 1 : 0;
     return 0;
 }
 
@@ -2208,7 +2262,8 @@ int pcr_set_profile(pcr_handle* h, int level) {
 
 int pcr_set_stream(pcr_handle* h, void* hip_stream) {
     if (!h) return 1;
-    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); pin_forget_stream(h->stream); }      // (copies out of pinned ranges are noted per stream)
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
     return 0;
@@ -2266,6 +2321,8 @@ int pcr_comm_init_host(pcr_handle* h, pcr_allreduce_fn fn, void* user, int rank,
     if (!fn) { h->host_ar = nullptr; h->host_ar_user = nullptr; if (!h->comm) { h->nranks = 1; h->rank = 0; } return 0; }
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, "bad communicator arguments");
     if (h->comm) return fail(h, "an RCCL communicator is already set on this handle");
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    peer_close(h);      // (one transport at a time)
     h->host_ar = fn; h->host_ar_user = user; h->rank = rank; h->nranks = nranks;
     return 0;
 }
@@ -2339,12 +2396,6 @@ int pcr_fitness_gated(pcr_handle* h, const void* src, size_t n_src, size_t strid
 // caller's pages directly.  The registration is keyed on what the caller SAYS -- (pointer, size), pinned until pcr_host_unpin -- never on
 // what the library guesses from a pointer it has seen before: a buffer that was freed and allocated again at the same address would be
 // read through stale page mappings (the hazard of SURVEY F10, one level down).
-namespace {
-struct PinnedRange { const void* p; size_t bytes; };
-std::mutex g_pin_mu;
-std::vector<PinnedRange> g_pinned;
-}  // namespace
-
 int pcr_host_pin(const void* ptr, size_t bytes) {
     g_create_error.clear();
     if (!ptr || !bytes) { g_create_error = "pcr_host_pin: NULL or empty range"; return 1; }
@@ -2357,7 +2408,7 @@ int pcr_host_pin(const void* ptr, size_t bytes) {
         }
     const hipError_t e = hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault);
     if (e != hipSuccess) { (void)hipGetLastError(); g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e); return 1; }
-    g_pinned.push_back(PinnedRange{ptr, bytes});
+    g_pinned.push_back(PinnedRange{ptr, bytes, {}});
     return 0;
 }
 
@@ -2366,12 +2417,14 @@ int pcr_host_unpin(const void* ptr) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pinned.size(); ++i)
         if (g_pinned[i].p == ptr) {
-            {   // no copy out of the range may still be in flight -- on ANY device (a handle on another GPU may have staged from it)
-                int cur = 0, ndev = 0;
-                if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess) {
-                    for (int d = 0; d < ndev; ++d) if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
-                    (void)hipSetDevice(cur);
-                } else (void)hipDeviceSynchronize();
+            {   // no copy out of the range may still be in flight: the streams that have copied from it (stage_host notes them), and only those
+                int cur = -1;
+                const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+                for (const PinUse& u : g_pinned[i].uses) {
+                    if (hipSetDevice(u.device) != hipSuccess) { (void)hipGetLastError(); continue; }
+                    if (hipStreamSynchronize(u.stream) != hipSuccess) (void)hipGetLastError();
+                }
+                if (have_cur && !g_pinned[i].uses.empty()) (void)hipSetDevice(cur);
             }
             const hipError_t e = hipHostUnregister(const_cast<void*>(ptr));
             g_pinned.erase(g_pinned.begin() + (long)i);
@@ -2416,15 +2469,23 @@ int pcr_comm_peer_export(pcr_handle* h, void* ipc_handle64) {
     if (set_device(h)) return 1;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI says 64 bytes");
     const size_t bytes = (size_t)2 * kMaxPeers * kPeerSlot * sizeof(double);
+    if (h->stream) H_TRY(hipStreamSynchronize(h->stream));      // (nothing of an earlier session is in flight)
     if (!h->peer_own) {
-        // fine-grained: the peers' stores and this rank's polls meet in memory, not in a cache that nobody invalidates inside a kernel
-        if (hipExtMallocWithFlags((void**)&h->peer_own, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-            (void)hipGetLastError();
-            H_TRY(hipMalloc((void**)&h->peer_own, bytes));
-        }
-        H_TRY(hipMemset(h->peer_own, 0, bytes));
-        H_TRY(hipDeviceSynchronize());
+        // fine-grained: the peers' stores and this rank's polls meet in memory, not in a cache that nobody invalidates inside a kernel.  No
+        // fallback to ordinary (coarse-grained) memory: remote stores might never be seen there, and every exchange would run into its timeout.
+        const hipError_t e = hipExtMallocWithFlags((void**)&h->peer_own, bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); h->peer_own = nullptr; return fail(h, std::string("peer exchange: no fine-grained device memory for the receive buffer (") + hipGetErrorString(e) + ")"); }
     }
+    if (!h->peer_status_host) {
+        H_TRY(hipHostMalloc((void**)&h->peer_status_host, 64, hipHostMallocMapped));
+        H_TRY(hipHostGetDevicePointer((void**)&h->peer_status_dev, h->peer_status_host, 0));
+    }
+    // EVERY export starts a session from nothing: sequence words of an earlier session could otherwise match the new one's.  The ranks share their
+    // handles only after every rank has exported (that exchange is the barrier): no peer writes into this buffer before it has been cleared.
+    H_TRY(hipMemset(h->peer_own, 0, bytes));
+    H_TRY(hipDeviceSynchronize());
+    *h->peer_status_host = 0;
+    h->peer_exported = true;
     hipIpcMemHandle_t mh;
     H_TRY(hipIpcGetMemHandle(&mh, h->peer_own));
     memcpy(ipc_handle64, &mh, 64);
@@ -2436,22 +2497,30 @@ int pcr_comm_init_peer(pcr_handle* h, const void* ipc_handles, int rank, int nra
     h->err.clear();
     if (!ipc_handles || nranks < 1 || nranks > kMaxPeers || rank < 0 || rank >= nranks) return fail(h, "bad peer-exchange arguments (at most 8 ranks)");
     if (h->method != kLoam) return fail(h, "the peer exchange is a prototype for loam handles (ndt / vgicp: pcr_comm_init or pcr_comm_init_host)");
-    if (!h->peer_own) return fail(h, "call pcr_comm_peer_export first (every rank), then share the handles");
+    if (!h->peer_own || !h->peer_exported) return fail(h, "call pcr_comm_peer_export first (every rank, for every session), then share the handles");
+    if (h->comm) return fail(h, "an RCCL communicator is already set on this handle");
     if (set_device(h)) return 1;
-    memset(&h->peer, 0, sizeof h->peer);
+    if (h->stream) H_TRY(hipStreamSynchronize(h->stream));
+    peer_close(h);      // (the mappings of an earlier session)
+    h->peer_exported = false;
     for (int p = 0; p < nranks; ++p) {
         if (p == rank) { h->peer.buf[p] = h->peer_own; continue; }
         hipIpcMemHandle_t mh;
         memcpy(&mh, (const char*)ipc_handles + (size_t)p * 64, 64);
         void* mapped = nullptr;
-        H_TRY(hipIpcOpenMemHandle(&mapped, mh, hipIpcMemLazyEnablePeerAccess));
+        const hipError_t e = hipIpcOpenMemHandle(&mapped, mh, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (int q = 0; q < p; ++q) if (q != rank && h->peer.buf[q]) (void)hipIpcCloseMemHandle(h->peer.buf[q]);
+            memset(&h->peer, 0, sizeof h->peer);
+            return fail(h, std::string("hipIpcOpenMemHandle of rank ") + std::to_string(p) + "'s receive buffer: " + hipGetErrorString(e));
+        }
         h->peer.buf[p] = (double*)mapped;
     }
-    h->peer.rank = rank; h->peer.nranks = nranks;
+    h->peer.rank = rank; h->peer.nranks = nranks; h->peer.status = h->peer_status_dev;
     h->rank = rank; h->nranks = nranks;
     h->peer_seq = 0.0;
-    h->peer_on = true;
-    h->comm = nullptr; h->host_ar = nullptr;
+    h->peer_on = true; h->peer_broken = false;
+    h->host_ar = nullptr; h->host_ar_user = nullptr;
     return 0;
 }
 
@@ -2464,8 +2533,11 @@ int pcr_comm_init(pcr_handle* h, const void* unique_id128, int rank, int nranks)
     if (!g_rccl.load(&h->err)) return 1;
     NcclId id;
     memcpy(&id, unique_id128, sizeof(id));
+    if (h->comm) return fail(h, "an RCCL communicator is already set on this handle");
     int rc = g_rccl.init_rank(&h->comm, nranks, id, rank);
     if (rc != 0) { h->comm = nullptr; return fail(h, "ncclCommInitRank failed with code " + std::to_string(rc)); }
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    peer_close(h);      // (one transport at a time)
     h->nranks = nranks; h->rank = rank;
     h->host_ar = nullptr; h->host_ar_user = nullptr;
     return 0;

@@ -1240,7 +1240,9 @@ __global__ __launch_bounds__(256) void loam_reduce_kernel(const LoamArgs a, cons
 // (stores that go out over xGMI), release to system scope, write the sequence number behind them; wait until every writer's slot of my OWN
 // buffer carries this exchange's number (local polls), acquire, fold the slots IN RANK ORDER (so every rank gets the same bits).  Two parities:
 // a rank can be at most one exchange ahead of the slowest (it needs that rank's contribution to go on), so the slot it overwrites has been read.
-// The wait is bounded (kPeerTimeoutTicks of the 100 MHz clock): a peer that never arrives makes the exchange FAIL, it does not hang the device.
+// The wait is bounded (kPeerTimeoutTicks of the 100 MHz clock): a peer that never arrives makes the exchange FAIL -- a status word in host-mapped memory
+// (PeerComm::status), after which the host refuses every further exchange of the session: the ranks' sequence counters no longer agree -- it does not
+// hang the device.
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ bool peer_exchange_block(const PeerComm& pc, double seq, const double* vals /* LDS or regs by thread t < n */, double v_mine, int n, int op,
                                                     double* __restrict__ out) {
@@ -1284,8 +1286,9 @@ __device__ __forceinline__ bool peer_exchange_block(const PeerComm& pc, double s
             const double x = __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             acc = op == 1 ? fmax(acc, x) : acc + x;
         }
-        out[t] = ok ? acc : __longlong_as_double(0x7ff8000000000000ll);      // (a peer never arrived: NaN, the caller fails the call)
+        out[t] = acc;      // (a peer never arrived: the sum is of whatever the slots held -- the STATUS word says so, not a value: a sum may be NaN in its own right)
     }
+    if (!ok && t == 0 && pc.status) __hip_atomic_store(pc.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     (void)vals;
     return ok;
 }

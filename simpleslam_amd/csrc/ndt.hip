@@ -862,9 +862,12 @@ __global__ __launch_bounds__(kProBlock, 1) void ndt_pass_pro_kernel(const NdtArg
         }
         __syncthreads();
         unsigned long long t_a = 0;
+        // the pass's 36 Hessian entries are taken in by lanes 1..36 of the wave whose lane 0 decides (same wave: their LDS stores are queued before
+        // lane 0's loads of the Newton solve)
+        if (t >= 1 && t <= 36) c->hess[t - 1] = ndt_opt::ctl_hess_entry(c->kind, c->phase, sh_sums, t - 1);
         if (t == 0) {
             t_a = wall_clock64();
-            sh_need = ndt_opt::ctl_decide(c, sh_sums) ? 1 : 0;
+            sh_need = ndt_opt::ctl_decide(c, sh_sums, true) ? 1 : 0;
             c->ticks[2] += (uint32_t)(wall_clock64() - t_a);
         }
         __syncthreads();

@@ -452,21 +452,27 @@ NDT_HD_FLAT bool ctl_advance(NdtCtl* c) {
 // wants a longer step than step_size every further trial is that same clamped step: with the reference's constants a More-Thuente
 // search that runs to its cap evaluates ONE point nine times over.  The reference recomputes it each time; n_deriv counts what the
 // reference evaluates, `replayed` how many of those were answered from here.
-NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
+// What a pass's sums do to entry i of the Hessian the state machine keeps (kind / phase: of the request the pass answered).  Apart from ctl_decide so
+// that the device can let 36 lanes take the entries in while one lane decides (hess_taken below).
+NDT_HD_FLAT double ctl_hess_entry(int kind, int phase, const double sums[43], int i) {
+    if (kind == kNdtPassHessian || phase == kNdtPhaseLsFirstH || kind == kNdtPassDerivH) return sums[7 + i];
+    return 0.0;      // (computeDerivatives zeroes it either way, :183)
+}
+NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43], bool hess_taken = false) {
     if (c->done) return false;
     c->passes += 1;
     // ---- take the sums in ----
+    if (!hess_taken) { const int k0 = c->kind, p0 = c->phase; for (int i = 0; i < 36; ++i) c->hess[i] = ctl_hess_entry(k0, p0, sums, i); }
+    bool hess_zero = false;      // the kept Hessian holds zeros: a repeated evaluation, which zeroes it again, has nothing to store (36 stores per repeat, up to nine repeats)
     if (c->kind == kNdtPassHessian) {
         c->n_hess += 1;
-        for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
     } else if (c->phase == kNdtPhaseLsFirstH) {
         c->late_h += 1;      // (not an evaluation of the reference's: it computed this Hessian with the first trial)
-        for (int i = 0; i < 36; ++i) c->hess[i] = sums[7 + i];
     } else {
         c->n_deriv += 1;
         c->score = sums[0];
+        hess_zero = c->kind != kNdtPassDerivH;
         for (int i = 0; i < 6; ++i) c->grad[i] = sums[1 + i];
-        for (int i = 0; i < 36; ++i) c->hess[i] = c->kind == kNdtPassDerivH ? sums[7 + i] : 0.0;      // (computeDerivatives zeroes it either way, :183)
         for (int i = 0; i < 6; ++i) c->x_eval[i] = c->x_t[i];
         c->eval_valid = 1;
     }
@@ -479,7 +485,7 @@ NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43]) {
         if (!same) return moved;
         // (x_t == x_eval compares values: +0 / -0 would pass as equal and give the same pose; NaN never passes)
         c->n_deriv += 1; c->replayed += 1;
-        for (int i = 0; i < 36; ++i) c->hess[i] = 0.0;
+        if (!hess_zero) { for (int i = 0; i < 36; ++i) c->hess[i] = 0.0; hess_zero = true; }
     }
 }
 

@@ -405,7 +405,7 @@ static constexpr int kMaxPeers = 8;
 static constexpr int kPeerSlot = 72;                       // doubles per (parity, writer) slot: 64 values + the sequence word + padding
 static constexpr int kPeerFlag = 64;
 static constexpr unsigned long long kPeerTimeoutTicks = 200000000ull;      // 2 s of the 100 MHz clock
-struct PeerComm { double* buf[kMaxPeers]; int32_t rank, nranks; };
+struct PeerComm { double* buf[kMaxPeers]; int32_t rank, nranks; int32_t* status; };      // status: host-mapped word, set to 1 by an exchange that timed out (out of band: the sums may hold any value, NaN included)
 hipError_t loam_launch_peer_exchange(const LoamArgs& a, int k, const PeerComm& pc, double seq, double* d_out, hipStream_t s);
 hipError_t peer_launch_allreduce(double* d_inout, int n, int op, const PeerComm& pc, double seq, hipStream_t s);
 hipError_t loam_launch_iteration(const LoamArgs& a, int k, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr, bool allow_half = false);

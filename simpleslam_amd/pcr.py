@@ -47,7 +47,8 @@ class PcrStats(C.Structure):
         ("total_ms", C.c_double), ("index_ms", C.c_double), ("solve_ms", C.c_double), ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_int32), ("iterations", C.c_int32), ("n_src", C.c_int64), ("n_dst", C.c_int64),
         ("attempts", C.c_int32), ("target_builds", C.c_int32), ("region_repeats", C.c_int32), ("region_index", C.c_int32),
-                ("aux_kernel_ms", C.c_double), ("region_points", C.c_int64), ("region_voxels", C.c_int64), ("pairs_grad", C.c_int64), ("pairs_hess", C.c_int64),
+        ("aux_kernel_ms", C.c_double), ("region_points", C.c_int64), ("region_voxels", C.c_int64), ("pairs_grad", C.c_int64), ("pairs_hess", C.c_int64),
+        ("index_box_hint", C.c_int32), ("index_layout_hint", C.c_int32),
     ]
 
 

@@ -1,0 +1,109 @@
+"""The caller's workload: scan after scan along a trajectory, against a sub-map that grows by key frames.
+
+One pass of the reference's front end in "lo" mode, reduced to what touches the registration path
+(frontend/src/LidarOdometry.cpp:160-200, frontend/src/MapManager.cpp:109-201):
+
+    scan -> voxel filter (downSampleVoxelGridSize)                         LidarOdometry.cpp:170-171
+         -> scan2Map(filtered scan, sub-map, init = previous pose o commanded motion)   :179-181
+         -> setCurPose: the sub-map is assembled again once the pose has moved minKFGap since the last assembly   MapManager.cpp:109-119
+         -> putKeyFrame: the scan becomes a key frame when no key frame lies within minKFGap   :121-149
+         -> updateMap: key frames within 8 m, transformed, concatenated, voxel-filtered        :151-201
+
+`drive()` runs that loop over any front that offers the four steps -- `GpuFront` here (the C ABI: pcr_voxel_filter,
+pcr_scan2map_submap, pcr_map_*), the CPU oracle's in oracle/ (tests and bench.py only).  The reference notifies a map thread and goes on;
+here the assembly happens at the end of the step that asked for it, key frame of that step included: deterministic, and the same on
+both fronts."""
+import time
+
+import numpy as np
+
+from . import synth
+
+MIN_KF_GAP = 1.0          # MapManager.hpp:67
+SEARCH_RADIUS = 8.0       # MapManager.hpp:68
+
+
+def make_drive(n_scans, seed, map_points=200_000, beams=64, azimuths=1024, step=0.5, odo_trans=0.02, odo_rot_deg=0.2):
+    """-> (scans [n][N,4] float32 in the sensor frame, true poses, commanded motions).  commanded[k] = the motion from scan k-1 to scan k as an
+    odometer reports it: the true relative motion o a small error (|t| <= odo_trans, |r| <= odo_rot_deg); commanded[0] = identity."""
+    world, _ = synth.make_map(map_points, seed=seed)
+    truth = [synth.trajectory_pose(world, k, step) for k in range(n_scans)]
+    scans = [synth.make_scan(world, k, seed=seed, beams=beams, azimuths=azimuths, pose=truth[k])[0] for k in range(n_scans)]
+    cmds = [np.eye(4)]
+    for k in range(1, n_scans):
+        rel = np.linalg.inv(truth[k - 1]) @ truth[k]
+        cmds.append(synth.perturb(rel, seed * 1000 + k, trans=odo_trans, rot_deg=odo_rot_deg))
+    return scans, truth, cmds
+
+
+def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap=MIN_KF_GAP):
+    """Run the loop; -> dict(poses, converged, iterations, submap_points, keyframes, updates, seconds, scan2map_seconds)."""
+    pose = np.array(start_pose, float)
+    kf_pos, last_update = [], None
+    poses, conv, iters, sub_n = [], [], [], []
+    updates = 0
+    t_s2m = 0.0
+    t0 = time.perf_counter()
+    for k, scan in enumerate(scans):
+        ds = front.voxel(scan, grid)
+        pose = pose @ cmds[k]
+        if front.submap_points() > 0:
+            t1 = time.perf_counter()
+            c, it = front.scan2map(ds, pose)          # refines `pose` in place
+            t_s2m += time.perf_counter() - t1
+            conv.append(bool(c)); iters.append(int(it))
+        else:
+            conv.append(True); iters.append(0)
+        t = pose[:3, 3]
+        need_update = last_update is None or float(np.linalg.norm(last_update - t)) > kf_gap       # setCurPose
+        # putKeyFrame: nearestKSearch's squared distance against minKFGap (MapManager.cpp:141-143)
+        if not kf_pos or min(float(np.sum((q - t) ** 2)) for q in kf_pos) > kf_gap:
+            front.add_keyframe(scan, pose)
+            kf_pos.append(t.copy())
+        if need_update:
+            front.update_map(t, radius, grid)
+            last_update = t.copy()
+            updates += 1
+        poses.append(pose.copy()); sub_n.append(front.submap_points())
+    front.finish()
+    return dict(poses=poses, converged=conv, iterations=iters, submap_points=sub_n, keyframes=len(kf_pos), updates=updates,
+                seconds=time.perf_counter() - t0, scan2map_seconds=t_s2m)
+
+
+class GpuFront:
+    """The four steps through the C ABI; scans are CUDA tensors (uploaded once, outside the timed loop), the sub-map never leaves HBM."""
+
+    def __init__(self, register, submap=None, record=False):
+        """record: keep, per scan2map call, what went in and what came out -- (filtered scan, sub-map, initial pose, result), all on the host -- so that a
+        checker can repeat every call on exactly those inputs (tests, bench.py's parity figure; never in a timed pass)."""
+        from .pcr import SubMap
+        self.reg = register
+        self.map = submap or SubMap()
+        self._n = 0
+        self.calls = [] if record else None
+        self._sub_host = None
+
+    def voxel(self, scan, grid):
+        return self.reg.voxelDownSample(scan, grid)
+
+    def scan2map(self, ds, pose):
+        init = pose.copy() if self.calls is not None else None
+        c = self.reg.scan2MapSubmap(ds, self.map, pose)
+        if self.calls is not None:
+            self.calls.append((ds.cpu().numpy(), self._sub_host, init, pose.copy(), bool(c)))
+        return c, self.reg.stats()["iterations"]
+
+    def add_keyframe(self, scan, pose):
+        self.map.addKeyFrame(scan, pose)
+
+    def update_map(self, position, radius, grid):
+        self._n = self.map.updateMap(position, radius, grid)
+        if self.calls is not None:
+            self._sub_host = self.map.download()
+
+    def submap_points(self):
+        return self._n
+
+    def finish(self):
+        import torch
+        torch.cuda.synchronize()

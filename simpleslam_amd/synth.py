@@ -172,12 +172,33 @@ def scan_pose(world, k=0, seed=0):
     return T
 
 
-def make_scan(world, k=0, seed=0, beams=64, azimuths=1024, noise=0.02):
+def trajectory_pose(world, k, step=0.5):
+    """True sensor pose of scan k of a DRIVE: `step` metres per scan along the street through the middle of the world (x grows),
+    a gentle weave in y, a slowly changing heading -- what the reference's front end tracks scan after scan
+    (frontend/src/LidarOdometry.cpp:160-200), where scan_pose() above draws unrelated poses."""
+    mid = (world.blocks // 2) * PITCH
+    x = mid + 3.0 + step * k
+    y = mid - 2.0 + 0.8 * np.sin(0.11 * k)
+    if world.blocks == 1:
+        x, y = 5.0 + 0.25 * k, 5.0
+    yaw = 0.06 * np.sin(0.07 * k) + 0.02 * np.cos(0.23 * k)
+    pitch, roll = 0.004 * np.sin(0.31 * k), 0.003 * np.cos(0.19 * k)
+    cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = np.array([x, y, SENSOR_Z]) - map_origin(world.blocks)
+    return T
+
+
+def make_scan(world, k=0, seed=0, beams=64, azimuths=1024, noise=0.02, pose=None):
     """beams*azimuths returns of a spinning lidar (elevation -24.8..+2 deg), in the
     sensor frame.  Rays with no return within MAX_RANGE are re-drawn so the scan has
-    exactly beams*azimuths points (BASELINE fixes N_s = 65 536)."""
+    exactly beams*azimuths points (BASELINE fixes N_s = 65 536).  pose: the true sensor pose (default: scan_pose(world, k, seed))."""
     rng = np.random.default_rng([seed, k, 11])
-    T = scan_pose(world, k, seed)
+    T = scan_pose(world, k, seed) if pose is None else np.array(pose, float)
     n = beams * azimuths
     el = np.deg2rad(np.linspace(-24.8, 2.0, beams))
     az = np.arange(azimuths) * (2 * np.pi / azimuths)
