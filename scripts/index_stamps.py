@@ -6,12 +6,20 @@ import torch
 import simpleslam_amd
 from simpleslam_amd import LoamRegister, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+method = sys.argv[2] if len(sys.argv) > 2 else "loam"      # ndt: BASELINE configs[4]'s shapes (128 beams, 0.22 m map), region-only index from the second call on
 S = 20261003 + 2
-w, m = synth.make_map(n, seed=S)
-scan, T = synth.make_scan(w, 0, seed=S)
-T0 = synth.perturb(T, S)
+if method == "ndt":
+    from simpleslam_amd import NdtRegister
+    w, m = synth.make_map(n, seed=S, spacing=0.22)
+    scan, T = synth.make_scan(w, 0, seed=S, beams=128, azimuths=1024)
+    T0 = synth.perturb(T, S, trans=0.1, rot_deg=0.5)
+    reg = NdtRegister()
+else:
+    w, m = synth.make_map(n, seed=S)
+    scan, T = synth.make_scan(w, 0, seed=S)
+    T0 = synth.perturb(T, S)
+    reg = LoamRegister(loam_iters=1, loam_early_exit=0)
 ds, dm = torch.from_numpy(scan).cuda(), torch.from_numpy(m).cuda()
-reg = LoamRegister(loam_iters=1, loam_early_exit=0)
 L = simpleslam_amd.load_library()
 for i in range(6):
     pose = T0.copy(); reg.scan2Map(ds, dm, pose)

@@ -373,6 +373,10 @@ __device__ unsigned long long* g_dev_stamps = nullptr;
 #define DEV_STAMP(kernel, slot) do { } while (0)
 #endif
 static constexpr int kBinStride = 16;                  // counters 64 bytes apart: memory-side atomics on one line serialise
+// (Measured, round 5: the same counters 16 to a line -- bin b at word (b & 15) * 512 + (b >> 4), so that the last block reads them back in 16 coalesced
+//  rows instead of one line per counter at ~2.3 ns a line -- shorten that block's tail from 3.6 to 3 us at 1 M points and make the claims come back after
+//  41 us instead of 16: a chunk of a map in generator order touches every ground tile, ~300 claims per counter, and sixteen counters' claims then queue up
+//  on one line.  What bounds the claim phase is the serial handling of the claims on its hottest LINE.)
 static constexpr int kBinPerDefault = 8;              // points per thread and chunk of the bin kernel
 
 // ---- BINS: the units of the two passes.  A build without a layout hint bins by TILE (2^shift consecutive cells: bin b = tile b).  A ground tile of a
@@ -558,19 +562,19 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     const uint32_t per = (nb + 255u) / 256u;      // <= kMaxBins / 256 = 32
     const uint32_t b0 = threadIdx.x * per;
     uint32_t c[kMaxBins / 256];
-    // all of a thread's counters requested before the first is used: UNCONDITIONAL loads of clamped indices, 8 / 16 / 32 of them by the (block-uniform)
-    // length of a thread's run (a load under a per-element condition waits for the one before it: 0.7 us apiece, measured in round 5)
+    // all of a thread's counters requested before the first is used: UNCONDITIONAL loads of clamped indices, as many as the (block-uniform) length of a
+    // thread's run rounded up to four (a load under a per-element condition waits for the one before it: 0.7 us apiece, measured in round 5 -- and a
+    // counter too many is a line too many: they come back at ~2.3 ns a line)
 #pragma unroll
     for (uint32_t j = 0; j < kMaxBins / 256; ++j) c[j] = 0u;
-    if (per <= 8u) {
+    switch ((per + 3u) >> 2) {
+#define PCR_LOAD_COUNTERS(N) case (N) / 4: { _Pragma("unroll") for (uint32_t j = 0; j < (N); ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } break;
+        PCR_LOAD_COUNTERS(4) PCR_LOAD_COUNTERS(8) PCR_LOAD_COUNTERS(12) PCR_LOAD_COUNTERS(16) PCR_LOAD_COUNTERS(20) PCR_LOAD_COUNTERS(24) PCR_LOAD_COUNTERS(28)
+#undef PCR_LOAD_COUNTERS
+        default: {
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (per <= 16u) {
-#pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-#pragma unroll
-        for (uint32_t j = 0; j < kMaxBins / 256; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t j = 0; j < kMaxBins / 256; ++j) c[j] = __hip_atomic_load(&bin_count[(size_t)min(b0 + j, (uint32_t)kMaxBins) * kBinStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } break;
     }
     uint32_t sum = 0;
 #pragma unroll
@@ -766,6 +770,7 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
 template <int kTilePer, int kMode, int kThreads, bool kTail, bool kPlan>
 // kPlan: the launch that carries block 0 (tile_block0; plan.enabled says whether it does).  src_start: where bin b's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
 // lay_cur: the layout the points were binned by (nullptr: by tile).  plan.enabled: block 0 is tile_block0 and sorts nothing.
+// (forcing the 8-per-thread instantiation to 128 registers -- four blocks per CU instead of three -- changed nothing: 46.7 / 47.2 us either way, round 5)
 __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* __restrict__ hdr_in, unsigned long long* __restrict__ tile_sq, const uint32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ bin_count, const float4* __restrict__ tiled, uint32_t* __restrict__ cell_start,
                                                         float4* __restrict__ sorted, uint32_t* __restrict__ scratch_rank, int shift,
