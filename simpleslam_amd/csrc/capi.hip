@@ -725,7 +725,9 @@ int vgicp_side_init(pcr_handle* h) {
 int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2, const float* d_pts, size_t n, size_t stride_floats, double cell,
                       double shift0, GridHeader* hdr0_out, bool may_cut = false, double ahead_cell = 0.0, bool* ahead_ok = nullptr,
                       const std::function<int()>* after_ahead = nullptr, bool* after_clean = nullptr, const std::function<int()>* before_wait = nullptr,
-                      bool scan_levels = false) {
+                      bool scan_levels = false, BuildFilter* filter0 = nullptr) {
+    // filter0: the fine level may index the points of a region only (BuildFilter: possible when this build reuses the header and the tile layout of
+    // an earlier full build of the level -- build() decides and says so in filter0->applied)
     // scan_levels: the levels of a SCAN (the source of an alignment that did not come through vgicp_source_enqueue: pcr_set_target + pcr_align,
     // pcr_vgicp_covariances, the redo path): built like vgicp_source_enqueue builds them -- one-level path, no hints: one scan's box and tile
     // layout do not hold the next (walls at other distances; measured there: every hint failed and the redo cost 0.9 ms)
@@ -736,6 +738,7 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
     if (after_clean) *after_clean = false;
     if (after_ahead && vgicp_side_init(h)) return 1;
     for (int attempt = 0; attempt < 4; ++attempt) {
+        if (attempt > 0 && filter0) filter0->applied = filter0->tail_applied = false;      // (a repeat is a full build)
         GridHeader hdr_stack[4];
         GridHeader* hdr = after_ahead ? h->side_hdr + 3 : hdr_stack;      // (page-locked when the host is not to block in the copies)
         // (a one-level target's covariance grid at last call's cell size, enqueued with the fine level so that one round trip
@@ -764,7 +767,8 @@ int settle_cov_levels(pcr_handle* h, GridIndex& g, GridIndex& l1, GridIndex& l2,
             //  at a time, a scan's box in the sensor frame hardly at all; a cloud that does not fit raises header.stale and is built afresh)
             lv[l]->no_hints = h->prm.index_no_hints != 0 || scan_levels;
             if (scan_levels) { lv[l]->prefer_one_level = true; lv[l]->header_mirror = nullptr; lv[l]->twin = nullptr; }
-            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, !scan_levels) != hipSuccess) { if (aux) (void)hipStreamSynchronize(h->aux_stream); return 1; }
+            if (lv[l]->build(d_pts, n, stride_floats, cells[l], h->stream, &h->err, l == 0 ? shift0 : 0.0, 0, h->clamp.use && may_cut ? &h->clamp : nullptr, !scan_levels,
+                             l == 0 && attempt == 0 ? filter0 : nullptr) != hipSuccess) { if (aux) (void)hipStreamSynchronize(h->aux_stream); return 1; }
             if (l == 0 && hdr0_out) H_TRY_AUX(lv[l]->enqueue_density(h->stream));
             H_TRY_AUX(hipMemcpyAsync(&hdr[l], lv[l]->header.p, sizeof(GridHeader), hipMemcpyDeviceToHost, h->stream));
         }
@@ -968,9 +972,24 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     const bool want_roi = roi_scan && roi_scan->n_src > 0 && n_dst > 0 && !check;
     // region, covariances and voxels over (lattice, search grid): enqueued by settle_cov_levels behind the grid it builds ahead, before the
     // host has seen a header (the device used to idle ~45 us between the header read-back and the first of these launches), or below
+    // ... and, from a handle's second call on, the voxel LATTICE holds the region's points only (BuildFilter, as NDT's: the region is marked first, on
+    // the lattice of the previous full build, and the bin pass drops every point outside it -- a tenth of the map's points go through the two passes and
+    // the voxel kernel; A/B on one box, round 5: preparation 0.372 -> 0.344 ms).  Needs the covariance search on a grid of its own (the grid built
+    // ahead: it holds every point, and serves the fitness score), the previous full build's header and tile layout as hints (build() checks), and
+    // lookups that test the mask first (vgicp.hip: vgicp_lookup, RoiView::filtered).
+    static const bool no_filter = dev_env("PCR_VG_NO_FILTER") != nullptr;      // (A/B runs)
+    BuildFilter bf;
+    bf.enqueue_mask = [&]() -> hipError_t {
+        if (roi_enqueue(h, *roi_scan, res, 1.0, &roi)) return hipErrorUnknown;      // 1 m of translation + 0.05 rad
+        bf.mask = roi.mask; bf.mshift = roi.mshift;
+        return hipSuccess;
+    };
     auto enqueue_rest = [&](const GridIndex* cov_grid) -> int {
         h->roi_on = false;
-        if (want_roi && !h->clamp.use) {
+        if (bf.applied && !h->clamp.use) {      // (the region was marked inside the lattice's build)
+            roi.filtered = 1;
+            h->roi_on = true;
+        } else if (want_roi && !h->clamp.use) {
             if (roi_enqueue(h, *roi_scan, res, 1.0, &roi)) return 1;      // 1 m of translation + 0.05 rad
             h->roi_on = true;
         }
@@ -988,8 +1007,9 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     const bool try_early = want_roi && !no_early && ahead_cell > 0.0 && !h->clamp.use;
     // (may_cut: a cloud too spread out for dense tables -- a stray point kilometres off -- is indexed over its bulk.  A rank of a sharded call
     //  too: its cloud is its own, the cut is its own decision, and a scan that reaches the cut fails the call on EVERY rank, run_vgicp)
+    const bool try_filter = try_early && !no_filter && h->prm.index_no_hints == 0;
     if (settle_cov_levels(h, h->grid, h->cov_l1, h->cov_l2, d_dst, n_dst, stride_floats, res, 0.5, &h->cov_hdr0, true, ahead_cell, &ahead_ok,
-                          try_early ? &early : nullptr, &early_clean, before_wait)) return 1;
+                          try_early ? &early : nullptr, &early_clean, before_wait, false, try_filter ? &bf : nullptr)) return 1;
     if (h->clamp.use) { ahead_ok = false; early_clean = false; }      // (the target was cut to its bulk in there: the grid built ahead covers the uncut cloud)
     h->have_target = true;
     // A map-sized cloud is searched on ONE level whose cell is sized for the 20-neighbour radius, not for the voxel
@@ -998,7 +1018,10 @@ int vgicp_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t
     // map: cell 1.25 m, 0.74 -> 0.50 ms for 1 M points, the extra index build included.)
     const GridIndex* cov_grid = &h->grid;
     bool kept_ahead = false;
-    if (cov_levels(n_dst) == 1 && n_dst > 0 && grid_sum_sq(h->cov_hdr0) > 0.0) {
+    if (bf.applied) {      // (the density figure of a region-only lattice is the region's: the search cell of the previous call stays -- it decides how many candidates a search visits, never its result)
+        if (!ahead_ok && settle_grid(h, h->cov_l1, d_dst, n_dst, stride_floats, res * h->cov_scale_hint, 0, nullptr)) return 1;      // (the grid built ahead did not stand: built again, in full)
+        kept_ahead = ahead_ok; cov_grid = &h->cov_l1;
+    } else if (cov_levels(n_dst) == 1 && n_dst > 0 && grid_sum_sq(h->cov_hdr0) > 0.0) {
         const double occ = grid_sum_sq(h->cov_hdr0) / (double)n_dst;
         const double scale = std::min(8.0, sqrt(10.0 / std::max(occ, 1e-3)));
         if (scale >= 1.3) {
@@ -1943,7 +1966,9 @@ double pcr_fitness(pcr_handle* h) {
         if (h->vg_target_ready && h->fit_n > 0) {
             if (set_device(h) || ensure_out32(h)) return -1.0;
             h->seq += 1.0;
-            if (fitness_launch(h->grid, h->fit_src.as<float>(), h->fit_n, h->fit_stride, h->fit_pose, 1.7976931348623157e308, h->vg_partials.as<double>(),
+            // (a lattice that holds the scan's region only cannot answer a nearest-neighbour question; the grid its covariances were searched on holds every point)
+            const GridIndex& fit_grid = (h->grid.filtered && h->cov_l1.valid && !h->cov_l1.filtered) ? h->cov_l1 : h->grid;
+            if (fitness_launch(fit_grid, h->fit_src.as<float>(), h->fit_n, h->fit_stride, h->fit_pose, 1.7976931348623157e308, h->vg_partials.as<double>(),
                                h->out32_dev, h->stream, h->seq, nullptr) != hipSuccess) { h->err = "fitness_launch failed"; return -1.0; }
             if (wait_result(h, &h->out32_host[31], h->seq)) return -1.0;
             h->fitness = h->out32_host[1] > 0 ? h->out32_host[0] / h->out32_host[1] : 1.7976931348623157e308;

@@ -767,6 +767,12 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
 // points with one point per thread (few VGPRs, many blocks in flight), kMode 2 the others with sixteen; kMode 0 = every tile (dense grids).
 // kTail (NDT's region-only targets, pcr_internal.h: TileTail): while a tile's cell counts are in registers the cells that will carry a voxel
 // are listed and every cell's slot is written -- ndt_candidates_kernel's work without its launch and without reading the table again.
+// (Measured and not kept, round 5: for VGICP's region-only lattice -- a sparse grid, 16.7 M cells of 0.5 m of which the scan's region is a fraction -- a
+//  variant that stores nothing for the cells outside the region's mask: a bin none of whose cells lies in the mask left at once, of the others only the
+//  starts of the four-cell groups that touch the mask written, the lookups testing the mask first.  The table's 67.6 MB of writes went away and the two
+//  launches got SLOWER, 22.1 -> 30.8 us and 29.5 -> 41.9 us: a block of this pass is a chain of latencies, not a stream of stores, and the mask test put
+//  one more dependent round trip -- header, row decode, mask bytes, a block-wide OR -- in front of every one of its 3 350 blocks.  The region-only
+//  index itself (the bin pass drops the points outside the mask) is kept: profiles/r05_notes.md.)
 template <int kTilePer, int kMode, int kThreads, bool kTail, bool kPlan>
 // kPlan: the launch that carries block 0 (tile_block0; plan.enabled says whether it does).  src_start: where bin b's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
 // lay_cur: the layout the points were binned by (nullptr: by tile).  plan.enabled: block 0 is tile_block0 and sorts nothing.

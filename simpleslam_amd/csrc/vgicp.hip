@@ -388,8 +388,12 @@ __device__ __forceinline__ uint32_t vgicp_lookup(const GridHeader& h, const uint
     uint32_t key;
     double c[3];
     if (!lattice_key(h, tp[0], tp[1], tp[2], &key, c)) return 0;
+    // (an index of the region's points only -- roi.filtered -- holds nothing outside the mask, not even the cell table's entries: the mask is tested
+    //  FIRST, and a lookup outside it is an escape whether or not a voxel is there -- as NDT treats its region-only index)
+    const bool outside = roi.mask && roi.mask[roi_macro(h, roi.mshift, (int)(c[0] - h.org[0]), (int)(c[1] - h.org[1]), (int)(c[2] - h.org[2]))] == 0;
+    if (outside && roi.filtered) { atomicAdd(roi.escapes, 1u); return 0; }
     const uint32_t s = cell_start[key], e = cell_start[key + 1];
-    if (e > s && roi.mask && roi.mask[roi_macro(h, roi.mshift, (int)(c[0] - h.org[0]), (int)(c[1] - h.org[1]), (int)(c[2] - h.org[2]))] == 0) {
+    if (e > s && outside) {
         atomicAdd(roi.escapes, 1u);
         return 0;
     }

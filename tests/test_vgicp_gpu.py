@@ -357,7 +357,7 @@ def test_region_list_of_a_map_sized_target_matches_the_whole_target(gpu):
     scan, T = synth.make_scan(world, 1, seed=77)
     full = VgicpRegister(full_target=1)
     reg = VgicpRegister()
-    repeats = 0
+    repeats, region_index = 0, 0
     for k, off in enumerate([0.2, -0.3, 0.1, 5.0, 0.25]):
         T0 = T.copy()
         T0[:3, 3] += np.array([off, -0.5 * off, 0.03 * off])
@@ -367,7 +367,15 @@ def test_region_list_of_a_map_sized_target_matches_the_whole_target(gpu):
         np.testing.assert_array_equal(p, pf)
         assert reg.stats()["iterations"] == full.stats()["iterations"], (k, off)
         repeats += reg.stats()["region_repeats"]
-    assert full.stats()["region_repeats"] == 0
+        region_index += reg.stats()["region_index"]
+        # the fitness score is a nearest-neighbour question about the WHOLE target: a lattice that holds the region's points only hands it to the
+        # grid the covariances were searched on, which holds every point -- the same number as with the full preparation
+        assert reg.getFitnessScore() == full.getFitnessScore(), (k, off)
+        if k == 0:
+            assert reg.stats()["region_index"] == 0      # nothing to go by yet: the whole cloud is indexed
+    assert full.stats()["region_repeats"] == 0 and full.stats()["region_index"] == 0
+    # from the second call on the voxel lattice itself holds the region's points only (round 5: BuildFilter, as NDT's)
+    assert region_index >= 2
 
 
 @pytest.mark.parametrize("method", ["vgicp", "ndt"])
