@@ -99,6 +99,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (vgicp) and configs[4] (ndt) lines embedded as \"extra\"")
     ap.add_argument("--extra-steps", type=int, default=40)
     ap.add_argument("--secondary-map-points", type=int, default=0, help="--method vgicp|ndt: map size instead of the configuration's (rehearsals and tests)")
+    ap.add_argument("--no-twin", action="store_true", help="skip the stateless twins (pcr_params.index_no_hints = 1) and the host-buffer legs: counter passes "
+                                                        "(scripts/profile_round.sh) then see the dispatches of ONE leg, the one the line's figures are of")
     ap.add_argument("--sequence-scans", type=int, default=64, help="scans of the drive behind extra.sequence (the caller's workload: key frames, sub-map assembly, "
                                                                     "pcr_scan2map_submap with init = previous pose); 0 skips it")
     args = ap.parse_args()
@@ -291,6 +293,7 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
                     "from a handle's second call on the index holds the region's points only), inputs in HBM")
     if args.secondary_map_points and not embedded:
         n_map = int(args.secondary_map_points)
+        workload = workload.replace("1000000-pt submap", f"{n_map}-pt submap").replace("5000000-pt submap", f"{n_map}-pt submap")      # (the line names the map it ran on)
     world, map_np = synth.make_map(n_map, seed=SEED + cfg, **mk)
     scans, inits = [], []
     for j in range(args.scans):
@@ -301,7 +304,8 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
     d_scans = [torch.from_numpy(s).to(dev) for s in scans]
     d_map_full = d_map
     scaling = "weak"
-    parallelism = f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"
+    parallelism = (f"replicas x{world_size}: THE scaling mode of this path -- one process per GPU, every rank the whole map and its own scans, no data-path collective "
+                   "(weak scaling); --shard-map is the other mode, one call's map cut over the ranks, and is latency-bound (DESIGN.md 5)") if world_size > 1 else "single GPU"
     rank_info = {"rank": rank, "device": local_rank, "map_points": int(map_np.shape[0])}
     sharded = bool(args.shard_map) and not embedded
     if sharded:
@@ -313,7 +317,14 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         tile = shard.tile_for_method(map_np, rank, world_size, method, resolution=res)
         d_map = torch.from_numpy(tile.points).to(dev)
         reg.set_shard(tile.lo, tile.hi, tile.halo)
-        if rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
+        if args.transport == "peer":      # (the device-resident loops over the peer exchange: one more launch per pass, no host round trip; works in a rehearsal too)
+            handles = [None] * world_size
+            if world_size > 1:
+                dist.all_gather_object(handles, reg.comm_peer_export())
+            else:
+                handles = [reg.comm_peer_export()]
+            reg.comm_init_peer(handles, rank, world_size)
+        elif rehearse:      # all ranks on one card: RCCL refuses a communicator with one device twice -> the exchange goes through gloo
             reg.comm_init_host(shard.gloo_collective(), rank, world_size)
         else:
             uid = [shard.unique_id() if rank == 0 else None]
@@ -364,7 +375,7 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         rank_info.update(target_prep_ms=prep, align_ms=aln)
         all_ranks = gather_ranks(dist, world_size, rank_info)
         n1 = None
-        if world_size > 1:
+        if world_size >= 1:      # (one rank too: the same call with and without the exchange on one card is what the exchange costs)
             if rank == 0:
                 cls = VgicpRegister if method == "vgicp" else NdtRegister
                 reg1 = cls(device=local_rank, **(dict(vgicp_resolution=0.5) if method == "vgicp" else {}))
@@ -378,8 +389,23 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
                 e1 = float(np.median(w1))
                 n1 = {"value": steps / e1, "unit": "scans/s", "ms_per_step": 1e3 * e1 / steps,
                       "note": "same scans, whole map, one GPU, unsharded handle (the N = 1 point of this strong-scaling curve)"}
+                if world_size == 1:
+                    # what the exchange costs before any link is crossed: the ALIGNMENT of the sharded call against the alignment of the unsharded one (a sharded
+                    # target is always prepared in full, the unsharded one for the scan's region: the preparations are not comparable), per evaluation pass
+                    passes = max(1, int(reg.stats().get("attempts", 0)))
+                    reg1.set_profile(1)
+                    aln1 = 0.0
+                    for i in range(8):
+                        step1(i); aln1 += reg1.stats()["solve_ms"] / 8
+                    reg1.set_profile(0)
+                    n1["align_ms"] = aln1
+                    n1["exchange_us_per_pass"] = 1e3 * (aln - aln1) / passes
+                    n1["passes_last_call"] = passes
+                    n1["exchange_note"] = ("(alignment of the sharded call - alignment of the unsharded call) / evaluation passes of the last call, one rank on one card: "
+                                           "the sharded loop's extra launch per pass and its exchange")
                 del reg1
-            dist.barrier()
+            if world_size > 1:
+                dist.barrier()
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -418,13 +444,17 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
         for k in prof:
             prof[k] += st[k] / n_prof
     reg.set_profile(0)
-    pmc = {}
-    pj = os.path.join(ROOT, "profiles", f"r04_{method}_pmc.json")
-    if os.path.exists(pj):
-        try:
-            pmc = json.load(open(pj))
-        except Exception:
-            pmc = {}
+    # HBM traffic and SQ counters are NOT measured in this run (counters need passes of their own under rocprofv3): they are read from the summary the
+    # newest committed profile round left for this method -- the line says which file, and that file says which leg it profiled
+    pmc, pmc_src = {}, None
+    for rnd in ("r05", "r04"):
+        pj = os.path.join(ROOT, "profiles", f"{rnd}_{method}_pmc.json")
+        if os.path.exists(pj):
+            try:
+                pmc = json.load(open(pj)); pmc_src = f"profiles/{rnd}_{method}_pmc.json ({pmc.get('leg', 'hinted and stateless calls mixed: the pass ran both legs')}); not measured in this run"
+                break
+            except Exception:
+                pmc = {}
     n_s = scans[0].shape[0]
     if method == "vgicp":
         # covariance of one point 16 + 20 x 16 + 128 = 464 B, voxel map 16 + 128 = 144 B per point, an index build 32 B per point
@@ -463,10 +493,13 @@ def secondary(args, method=None, steps=None, warmup=None, embedded=False):
             "preparation": {"what": what, "algorithmic_bytes": prep_bytes, "achieved": prep_bytes / (idx_ms * 1e-3) / 1e9, "unit": "GB/s",
                             "frac": prep_bytes / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_scan_preparation")},
             "target_prep_ms": idx_ms, "align_ms": sol_ms}
+    out["roofline"]["traffic_source"] = pmc_src
+    if args.full_target and method == "vgicp":
+        out["roofline"]["note_full_target"] = "--full-target: no region exists, the kernels' counters of region points / voxels do not run; the covariance roofline above is not meaningful here"
     out["roofline"]["note"] = ("target_prep_ms / align_ms come from a separate 8-scan pass with phase events (pcr_set_profile 1); kernel durations and the "
                                "counts of what was processed from another with events at the kernels' own begin and end (pcr_set_profile 2)")
     # ---- the same scans with nothing carried across calls (pcr_params.index_no_hints = 1): the stateless twin of `value` ----
-    if world_size == 1:
+    if world_size == 1 and not args.no_twin:
         cls = VgicpRegister if method == "vgicp" else NdtRegister
         kw_nh = dict(vgicp_resolution=0.5) if method == "vgicp" else {}
         reg_nh = cls(device=local_rank, index_no_hints=1, full_target=int(args.full_target), **kw_nh)
@@ -714,7 +747,8 @@ def main():
     d_scans = [torch.from_numpy(s).to(dev) for s in scans]
     d_map = d_map_full
     scaling = "weak"
-    parallelism = f"replica x{world_size} (independent scans per GPU)" if world_size > 1 else "single GPU"
+    parallelism = (f"replicas x{world_size}: THE scaling mode of this path -- one process per GPU, every rank the whole map and its own scans, no data-path collective "
+                   "(weak scaling); --shard-map is the other mode, one call's map cut over the ranks, and is latency-bound (DESIGN.md 5)") if world_size > 1 else "single GPU"
     rank_info = {"rank": rank, "device": local_rank, "map_points": int(map_np.shape[0])}
     if args.shard_map:
         from simpleslam_amd import shard
@@ -847,15 +881,19 @@ def main():
             del reg1
         dist.barrier()
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "loam_iterate_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # (HBM traffic is NOT measured in this run -- counters need passes of their own under rocprofv3: it is read from the summary the newest committed
+        #  profile round left, and the line says which)
+        traffic, traffic_src = None, None
+        for name in ("r05_loam_iterate_pmc.json", "loam_iterate_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch"); traffic_src = f"profiles/{name} (FETCH_SIZE / WRITE_SIZE passes of the headline command); not measured in this run"
+                    break
+                except Exception:
+                    traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "kernel": "loam_iterate_kernel", "avg_launch_us": avg_s * 1e6,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "index_build_us": 1e3 * idx_ms / reps,
@@ -887,7 +925,7 @@ def main():
         #     same scans with pcr_params.index_no_hints = 1 -- fresh box, no layout, no state across calls -- are timed beside it.
         # (b) host_buffers: the drop-in adapter hands HOST clouds to pcr_scan2map; that path pays the PCIe copy of the
         #     map on every call.  Timed from pageable memory and from a range the caller page-locked with pcr_host_pin.  Never `value`.
-        if not args.shard_map:
+        if not args.shard_map and not args.no_twin:
             from simpleslam_amd import pcr as _pcr
             out["index_hints"] = True
             reg_nh = LoamRegister(device=local_rank, loam_iters=args.iters, loam_early_exit=0, index_no_hints=1)

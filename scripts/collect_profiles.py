@@ -4,7 +4,7 @@ corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in Ki
 import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -109,7 +109,8 @@ for m in ("vgicp", "ndt"):
         for k in rows:
             if "vgicp_cov_kernel<false>" in k["kernel"]:
                 extra["hbm_bytes_per_launch_cov_target"] = (2 * k["fetch_kib"] + k["write_kib"]) * 1024
-    json.dump({"method": m, "scans": scans, "hbm_bytes_per_scan_preparation": prep, "hbm_bytes_per_scan_total": total, **extra, "kernels": rows,
+    json.dump({"method": m, "scans": scans, "leg": "the hinted leg only: bench.py --no-twin, the stateless twin and its full builds do not run in the counter passes",
+               "hbm_bytes_per_scan_preparation": prep, "hbm_bytes_per_scan_total": total, **extra, "kernels": rows,
                "note": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, one counter per pass), FETCH doubled per the gfx950 correction; "
                        "preparation = every kernel but the optimiser's passes"}, open(os.path.join(dst, f"{tag}_{m}_pmc.json"), "w"), indent=1)
     print(m, "HBM bytes per scan: preparation", prep, "total", total)

@@ -128,6 +128,7 @@ struct pcr_handle {
     double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
     double* out48_dev = nullptr;
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
+    DeviceBuf vg_reduced;                // sharded VGICP over the peer exchange: a pass's 32 sums folded over the rows and the ranks
     DeviceBuf nd_sums;                   // sharded device loop: the 48 sums of a pass, all-reduced in place
     NdtOut* nd_out_host = nullptr;       // host-mapped: its result and progress word
     NdtOut* nd_out_dev = nullptr;
@@ -1103,8 +1104,12 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
     h->vg_outer = h->vg_lin = h->vg_err = 0;
     // ---- device-resident loop (vgicp_opt.h): launches are enqueued ahead of the device, the host watches a progress word.  Not for
     // sharded targets (every pass's sums cross the ranks) and not when pcr_params.host_optimiser asks for the host loop below ----
-    const bool on_device = n_src > 0 && !shard && h->prm.host_optimiser == 0 && h->prm.vgicp_max_iters > 0;
+    // Sharded over the peer exchange (pcr_comm_init_peer) the loop stays on the device too: an exchange launch in front of every pass
+    // (vgicp.hip: vgicp_peer_exchange_kernel), and the host queues launches by a rule that gives every rank the same number of them (see run_ndt).
+    const bool peer_loop = shard && h->peer_on && !h->host_ar && !h->comm;
+    const bool on_device = n_src > 0 && (!shard || peer_loop) && h->prm.host_optimiser == 0 && h->prm.vgicp_max_iters > 0;
     if (h->roi_on && !on_device) return fail(h, "internal: a target prepared for one scan needs the device-resident loop");
+    if (peer_loop && peer_check(h)) return 1;
     if (on_device) {
         if (!h->vg_out_host) {
             H_TRY(hipHostMalloc((void**)&h->vg_out_host, sizeof(VgOut), hipHostMallocMapped));
@@ -1124,12 +1129,39 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
         const long limit = (long)h->prm.vgicp_max_iters * std::max(1, h->prm.vgicp_lm_inner) + 3;
         if ((double)limit >= kProgressWindow) return fail(h, "vgicp_max_iters * vgicp_lm_inner exceeds the device loop's pass window (2^20)");
         long enq = 0;
-        // (a pass is ~14 us, and the word that says one has begun is written ~6 us into it: with fewer than three launches ahead of
-        // that word the queue runs dry while the host enqueues; a launch beyond the end costs ~5 us)
-        for (; enq < 4 && enq < limit; ++enq) H_TRY_DRAIN(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
         const volatile double* f_seq = &out->seq;
         const volatile double* f_prog = &out->progress;
         long spins = 0;
+        if (peer_loop) {
+            // never more than kAhead launches beyond the passes consumed, and exactly P + kAhead once the loop has finished after P passes: every
+            // rank queues the same number of exchanges whatever it happens to see when (the launches beyond the end exchange nothing)
+            const long kAhead = 3;
+            H_TRY(h->vg_reduced.reserve(64 * sizeof(double)));
+            auto launch = [&]() -> hipError_t {
+                if (enq > 0) h->peer_seq += 1.0;      // (the first launch of a call has nothing to exchange)
+                return vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq, &h->peer, h->peer_seq, h->vg_reduced.as<double>());
+            };
+            for (;;) {
+                if (*f_seq == seq) break;
+                const double pr = *f_prog;
+                const long consumed = (pr >= seq * kProgressWindow && pr < (seq + 1.0) * kProgressWindow) ? (long)(pr - seq * kProgressWindow) : 0;
+                if (enq - consumed < kAhead && enq < limit + kAhead) { H_TRY_DRAIN(launch()); ++enq; continue; }
+                __builtin_ia32_pause();
+                if (++spins > 400000) {
+                    H_TRY(hipStreamSynchronize(h->stream));
+                    if (*f_seq == seq) break;
+                    if (peer_check(h)) return 1;
+                    if (enq >= limit + kAhead) return fail(h, "vgicp: the optimiser did not finish within its pass budget");
+                    spins = 0;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (const long want = (long)out->passes + kAhead; enq < want; ++enq) H_TRY_DRAIN(launch());
+            if (peer_check(h)) return 1;
+        } else {
+        // (a pass is ~14 us, and the word that says one has begun is written ~6 us into it: with fewer than three launches ahead of
+        // that word the queue runs dry while the host enqueues; a launch beyond the end costs ~5 us)
+        for (; enq < 4 && enq < limit; ++enq) H_TRY_DRAIN(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
         for (;;) {
             if (*f_seq == seq) break;
             const double pr = *f_prog;
@@ -1147,12 +1179,14 @@ int run_vgicp(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_flo
                 for (int k = 0; k < 4 && enq < limit; ++k, ++enq) H_TRY_DRAIN(vgicp_launch_pass_pro(a, d_ctl, h->vg_partials.as<double>(), h->vg_out_dev, h->stream, seq, (int)enq));
             }
         }
+        }
         std::atomic_thread_fence(std::memory_order_acquire);
         // some pass looked up a voxel outside the region the target was prepared for: its sums lack that correspondence.  The caller
         // prepares the whole target and repeats the call (2).
         if (h->roi_on && out->roi_escapes > 0) { h->roi_repeats += 1; return 2; }
         x0 = out->x0; conv = out->conv != 0;
         h->vg_outer = out->outer; h->vg_lin = out->n_lin; h->vg_err = out->n_err;
+        h->stats.attempts = out->passes;      // (the passes the device loop evaluated)
     }
     // ---- host-driven loop: the same state machine (vgicp_opt.h), one host round trip per pass; sharded, every pass's sums cross
     // the ranks.  The LM trial pass (vgicp_launch_error) also linearises at the trial pose: once a trial is accepted that pose IS the
@@ -1411,7 +1445,9 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     // Sharded over RCCL the loop stays on the device as well: fold -> ncclAllReduce on the handle's stream -> controller step, in
     // batches of a fixed number of passes -- whether another batch is due is decided from the controller state the ranks share, so
     // every rank enqueues the same collectives.  (A host-supplied collective needs the host in every pass: the host loop below.)
-    const bool dev_sharded = sharded(h) && h->comm && !h->host_ar && n_src > 0 && h->prm.host_optimiser == 0;
+    // Sharded over the peer exchange (pcr_comm_init_peer) likewise, two launches per pass: the evaluation, then fold + exchange + controller step
+    // in one (ndt.hip: ndt_fold_exchange_ctl_kernel).
+    const bool dev_sharded = sharded(h) && (h->comm || h->peer_on) && !h->host_ar && n_src > 0 && h->prm.host_optimiser == 0;
     bool on_device = n_src > 0 && !sharded(h) && h->prm.host_optimiser == 0;
     if (h->roi_on && !on_device) return fail(h, "internal: a target prepared for one scan needs the device-resident loop");
     h->nd_grid_checked = false; h->nd_grid_bad = false;
@@ -1425,6 +1461,36 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
         H_TRY(ndt_launch_ctl_init(d_ctl, T0, p0, h->prm.ndt_step_size, h->prm.ndt_trans_eps, h->prm.ndt_max_iters, h->stream, h->prm.ndt_evaluate_repeats));
         const int limit = (h->prm.ndt_max_iters + 3) * 13 + 4, kBatch = 6;
         const volatile double* f_batch = &out->batch;
+        if (h->peer_on) {
+            // Peer exchange: passes are queued a FIXED number ahead of the progress word, one at a time, like the unsharded loop -- with a rule that
+            // makes every rank queue the same number of them whatever it happens to see when: never more than kAhead beyond the passes consumed,
+            // and, once the loop has finished after P passes, exactly P + kAhead (a rank that saw the end early tops its queue up; the launches
+            // beyond the end exchange nothing and leave).  The ranks' sequence numbers -- one per queued launch -- then agree in the next call too.
+            const int kAhead = 3;
+            const volatile double* f_seq = &out->seq;
+            const volatile double* f_prog = &out->progress;
+            if ((double)limit >= kProgressWindow) return fail(h, "ndt_max_iters exceeds the device loop's pass window (2^20 passes)");
+            auto launch = [&]() -> hipError_t { h->peer_seq += 1.0; return ndt_launch_pass_peer(r.a, d_ctl, h->peer, h->peer_seq, h->nd_out_dev, h->stream, seq, 0); };
+            int enq = 0;
+            long spins = 0;
+            for (;;) {
+                if (*f_seq == seq) break;
+                const double pr = *f_prog;
+                const int consumed = (pr >= seq * kProgressWindow && pr < (seq + 1.0) * kProgressWindow) ? (int)(pr - seq * kProgressWindow) : 0;
+                if (enq - consumed < kAhead && enq < limit + kAhead) { H_TRY(launch()); ++enq; continue; }
+                __builtin_ia32_pause();
+                if (++spins > 400000) {      // a slow device (or a profiler): wait for what is queued, then look again
+                    H_TRY(hipStreamSynchronize(h->stream));
+                    if (*f_seq == seq) break;
+                    if (peer_check(h)) return 1;
+                    if (enq >= limit + kAhead) return fail(h, "ndt: the optimiser did not finish within its pass budget");
+                    spins = 0;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (const int want = out->passes + kAhead; enq < want; ++enq) H_TRY(launch());      // (every rank ends the call with the same number of launches queued)
+            if (peer_check(h)) return 1;
+        } else
         for (int batch = 1, enq = 0;; ++batch) {
             for (int b = 0; b < kBatch; ++b, ++enq) {
                 H_TRY(ndt_launch_pass_fold(r.a, d_ctl, h->nd_sums.as<double>(), h->stream));      // (a rank with an empty scan still folds zeros and takes part)
@@ -1439,12 +1505,13 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
                 if (++spins > 400000 || h->profile != 0) { H_TRY(hipStreamSynchronize(h->stream)); if (!(*f_batch == want0 || *f_batch == want0 + 1.0)) return fail(h, "ndt: the sharded device loop lost its batch marker"); }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
+            if (peer_check(h)) return 1;      // (an exchange of this batch timed out: the loop has stopped on the ranks that waited, the session is over)
             if (*f_batch == want0 + 1.0) break;
             if (enq >= limit) return fail(h, "ndt: the optimiser did not finish within its pass budget");
         }
         if (!out->bail) {      // (a nearly singular Newton system: every rank saw the same pivots and goes to the host loop below, with the SVD)
             final_T = out->final_T; conv = out->conv; nr_it = out->nr_it; score = out->score;
-            h->nd_deriv = out->n_deriv; h->nd_hess = out->n_hess;
+            h->nd_deriv = out->n_deriv; h->nd_hess = out->n_hess; h->nd_last_passes = out->passes;
             sharded_done = true;
         }
     }
@@ -1529,7 +1596,7 @@ int run_ndt(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_float
     if (converged) *converged = conv ? 1 : 0;
     h->nd_iters = nr_it; h->nd_score = score;
     h->stats.iterations = nr_it; h->stats.kernel_launches = h->nd_deriv + h->nd_hess;
-    h->stats.attempts = on_device ? h->nd_last_passes : 0;      // (what the device loop actually launched; 0: not that loop)
+    h->stats.attempts = (on_device || sharded_done) ? h->nd_last_passes : 0;      // (the passes a device loop actually evaluated; 0: not such a loop)
     h->stats.n_src = (int64_t)n_src; h->stats.n_dst = (int64_t)h->tgt_n;
     return 0;
 }
@@ -1752,7 +1819,7 @@ void pcr_destroy(pcr_handle* h) {
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     h->src_grid.release(); h->cov_l1.release(); h->cov_l2.release(); h->src_l1.release(); h->src_l2.release(); h->tgt_cov6.release(); h->src_cov6.release(); h->vox.release(); h->src_scratch.release(); h->tgt_scratch.release();
-    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release(); h->vg_ctl.release(); h->fit_src.release();
+    h->corr_slot.release(); h->corr_M.release(); h->corr_slot2.release(); h->corr_M2.release(); h->vg_partials.release(); h->vg_ctl.release(); h->vg_reduced.release(); h->fit_src.release();
     if (h->vg_out_host) (void)hipHostFree(h->vg_out_host);
     if (h->out32_host) (void)hipHostFree(h->out32_host);
     h->nd_slot.release(); h->nd_vox.release(); h->nd_count.release(); h->nd_list.release(); h->nd_partials.release();
@@ -2521,7 +2588,6 @@ int pcr_comm_init_peer(pcr_handle* h, const void* ipc_handles, int rank, int nra
     if (!h) return 1;
     h->err.clear();
     if (!ipc_handles || nranks < 1 || nranks > kMaxPeers || rank < 0 || rank >= nranks) return fail(h, "bad peer-exchange arguments (at most 8 ranks)");
-    if (h->method != kLoam) return fail(h, "the peer exchange is a prototype for loam handles (ndt / vgicp: pcr_comm_init or pcr_comm_init_host)");
     if (!h->peer_own || !h->peer_exported) return fail(h, "call pcr_comm_peer_export first (every rank, for every session), then share the handles");
     if (h->comm) return fail(h, "an RCCL communicator is already set on this handle");
     if (set_device(h)) return 1;

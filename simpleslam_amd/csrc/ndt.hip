@@ -15,6 +15,7 @@
 
 #include "pcr_internal.h"
 #include "ndt_opt.h"
+#include "peer_exchange.h"
 #include "small_math.h"
 
 namespace pcr {
@@ -1009,6 +1010,93 @@ __global__ __launch_bounds__(64) void ndt_ctl_kernel(NdtCtl* __restrict__ ctl, c
     }
 }
 
+// Sharded targets over the PEER exchange (pcr_comm_init_peer): the three pieces above in ONE launch -- this rank's rows folded, the 48 sums pushed
+// into every peer's receive buffer and the ranks' contributions folded in rank order (peer_exchange.h), one step of the state machine on the result.
+// A pass is then two launches (ndt_pass_kernel + this one) and no collective call, where the RCCL loop needs three launches and an all-reduce and a
+// host-supplied collective a round trip through the host per pass.  Every rank holds the same controller state and gets the same bits out of the
+// exchange: the ranks decide alike.  A launch queued beyond the end of the optimisation exchanges nothing (every rank's `done` flips in the same
+// launch; sequence numbers are per enqueued launch, so the ones that follow still agree).
+__global__ __launch_bounds__(768) void ndt_fold_exchange_ctl_kernel(const double* __restrict__ partials, uint32_t nblocks, NdtCtl* __restrict__ ctl, const PeerComm pc,
+                                                                    const double xseq, const GridHeader* __restrict__ hdr, NdtOut* __restrict__ out, double seq,
+                                                                    int batch_mark, const uint32_t* __restrict__ roi_escapes) {
+    __shared__ double sh[16 * 48];
+    __shared__ double sh_sums[64];
+    __shared__ double sh_sc[12];
+    __shared__ int sh_need, sh_fail;
+    __shared__ __attribute__((aligned(16))) uint32_t sh_ctl[kCtlWords];
+    const int t = threadIdx.x, comp = t % 48, slice = t / 48;
+    const int done_in = ctl->done;
+    if (!done_in) {
+        const int kind = ctl->kind;
+        for (int w = t; w < kCtlWords; w += 768) sh_ctl[w] = reinterpret_cast<const uint32_t*>(ctl)[w];
+        double acc = 0.0;
+        if (kind != kNdtPassNone) {
+            for (uint32_t b0 = slice; b0 < nblocks; b0 += 16 * 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const uint32_t b = b0 + 16 * u; v[u] = b < nblocks ? partials[(size_t)b * 48 + comp] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+        }
+        sh[slice * 48 + comp] = acc;
+        __syncthreads();
+        double mine = 0.0;
+        if (t < 48) {
+            double v = sh[t];
+#pragma unroll
+            for (int s2 = 1; s2 < 16; ++s2) v += sh[s2 * 48 + t];
+            // a line-search pass fills 7 of the 48 slots of every block; the others hold what an earlier pass left there
+            mine = (kind == kNdtPassDeriv && t >= 7) || t >= kNdtComp ? 0.0 : v;
+        }
+        const bool ok = peer_exchange_block(pc, xseq, nullptr, mine, 48, 0, sh_sums);
+        if (t == 0) sh_fail = ok ? 0 : 1;
+        __syncthreads();
+        if (sh_fail) {      // a rank never arrived (the status word says so to the host): the loop ends here, on every rank that waited
+            if (t == 0) { NdtCtl* c = reinterpret_cast<NdtCtl*>(sh_ctl); c->done = 1; c->bail = 0; c->conv = 0; c->kind = kNdtPassNone; }
+        } else {
+            NdtCtl* const c = reinterpret_cast<NdtCtl*>(sh_ctl);
+            if (t >= 1 && t <= 36) c->hess[t - 1] = ndt_opt::ctl_hess_entry(c->kind, c->phase, sh_sums, t - 1);      // (lanes of the deciding lane's wave: see ndt_pass_pro_kernel)
+            if (t == 0) sh_need = ndt_opt::ctl_decide(c, sh_sums, true) ? 1 : 0;
+            __syncthreads();
+            if (sh_need) {
+                if (t < 6) {
+                    double sc[2];
+                    ndt_opt::trig_pair(c->x_t, t, sc);
+                    sh_sc[2 * t] = sc[0]; sh_sc[2 * t + 1] = sc[1];
+                }
+                __syncthreads();
+                // pose and the four parts of the angle tables: five waves, one lane each
+                if ((t & 63) == 0) {
+                    const int wave = t >> 6;
+                    if (wave == 0) ndt_opt::pose_from_trig(c->x_t, sh_sc, &c->T);
+                    else if (wave == 1) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 0);
+                    else if (wave == 2) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 1);
+                    else if (wave == 3) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 2);
+                    else if (wave == 4) ndt_opt::angle_tables_from_trig(sh_sc, &c->ang, 3);
+                }
+            }
+        }
+        __syncthreads();
+        for (int w = t; w < kCtlWords; w += 768) reinterpret_cast<uint32_t*>(ctl)[w] = sh_ctl[w];
+    }
+    if (t == 0) {
+        const NdtCtl* c = done_in ? ctl : reinterpret_cast<const NdtCtl*>(sh_ctl);
+        if (c->done && !done_in) {
+            out->final_T = c->final_T; out->score = c->score;
+            out->conv = c->conv; out->nr_it = c->nr_it; out->n_deriv = c->n_deriv; out->n_hess = c->n_hess; out->bail = c->bail; out->passes = c->passes;
+            out->grid_overflow = hdr->overflow; out->grid_empty = hdr->empty; out->grid_stale = hdr->stale; out->roi_escapes = roi_escapes ? (int32_t)min(*roi_escapes, 0x7fffffffu) : 0; out->grid_cells = hdr->n_cells;
+            __threadfence_system();
+            __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        else if (!c->done) __hip_atomic_store(&out->progress, seq * kProgressWindow + (double)c->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the host keeps its queue a fixed number of passes ahead of this)
+        if (batch_mark) {
+            __threadfence_system();
+            __hip_atomic_store(&out->batch, seq * 65536.0 + 2.0 * (double)batch_mark + (c->done ? 1.0 : 0.0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // fold per-block partials (48 doubles each) into 48 doubles, fixed order; 16 slices of 48 components, each
 // slice keeps 8 independent loads in flight
 // out lives in host-mapped memory: out[47] receives `seq` LAST (system-scope release), the word the host spins on
@@ -1116,6 +1204,13 @@ hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums4
     const uint32_t nb = ndt_blocks(a.n_src);
     hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
     hipLaunchKernelGGL(ndt_fold_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, d_sums48);
+    return hipGetLastError();
+}
+// one pass of the sharded loop over the peer exchange: the evaluation, then fold + exchange + controller step in one launch
+hipError_t ndt_launch_pass_peer(const NdtArgs& a, NdtCtl* d_ctl, const PeerComm& pc, double xseq, NdtOut* d_out, hipStream_t s, double seq, int batch_mark) {
+    const uint32_t nb = ndt_blocks(a.n_src);
+    hipLaunchKernelGGL(ndt_pass_kernel, dim3(nb), dim3(kNdtBlock), 0, s, a, d_ctl);
+    hipLaunchKernelGGL(ndt_fold_exchange_ctl_kernel, dim3(1), dim3(768), 0, s, a.partials, nb, d_ctl, pc, xseq, a.hdr, d_out, seq, batch_mark, (const uint32_t*)a.roi_escapes);
     return hipGetLastError();
 }
 hipError_t ndt_launch_ctl(const NdtArgs& a, NdtCtl* d_ctl, const double* d_sums48, NdtOut* d_out, hipStream_t s, double seq, int batch_mark) {

@@ -344,7 +344,9 @@ struct VgCtl;
 struct VgOut;
 hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_iters, int lm_inner, double lm_init_scale, double rot_eps, double trans_eps, hipStream_t s,
                                  uint32_t* d_roi_escapes = nullptr);
-hipError_t vgicp_launch_pass_pro(const VgicpArgs& a, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index);
+struct PeerComm;
+hipError_t vgicp_launch_pass_pro(const VgicpArgs& a, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index,
+                                 const PeerComm* pc = nullptr, double xseq = 0.0, double* d_reduced = nullptr);
 // out32[28] = compute_error(T); out32[0..27] = the linearisation at T (correspondences into a.corr_*_next)
 hipError_t vgicp_launch_error(const VgicpArgs& a, const Pose16& T, double* d_out32, hipStream_t s, double seq = 0.0);
 // out32[0] = sum of the squared 1-NN distances <= max_range, [1] = their number, [2] = (tile given) source points whose nearest
@@ -398,6 +400,8 @@ hipError_t ndt_launch_pass_pro(const NdtArgs& a, NdtCtl* d_ctl2, double* d_rows2
                                hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t ndt_launch_pass_fold(const NdtArgs& a, NdtCtl* d_ctl, double* d_sums48, hipStream_t s);
 hipError_t ndt_launch_ctl(const NdtArgs& a, NdtCtl* d_ctl, const double* d_sums48, NdtOut* d_out, hipStream_t s, double seq, int batch_mark);
+struct PeerComm;
+hipError_t ndt_launch_pass_peer(const NdtArgs& a, NdtCtl* d_ctl, const PeerComm& pc, double xseq, NdtOut* d_out, hipStream_t s, double seq, int batch_mark);
 uint32_t ndt_blocks(uint32_t n_src);
 
 // peer exchange (loam.hip): receive buffers of all ranks as THIS process maps them

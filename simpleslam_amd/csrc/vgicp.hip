@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "pcr_internal.h"
+#include "peer_exchange.h"
 #include "small_math.h"
 #include "vgicp_opt.h"
 #include "cov_math.h"
@@ -554,6 +555,7 @@ struct VgProArgs {
     double seq;
     uint32_t rows_prev_n;
     int32_t first;
+    const double* reduced;       // sharded over the peer exchange: the previous launch's 32 sums, already folded over the rows AND the ranks (vgicp_peer_exchange_kernel)
 };
 static constexpr int kVgCtlWords = (int)((sizeof(VgCtl) + 3) / 4);
 static_assert(sizeof(VgCtl) % 4 == 0, "VgCtl is copied word by word");
@@ -569,7 +571,10 @@ __global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_i
     // one round trip: the state and the rows of the previous launch ([8 slices][32 components], 32 rows a thread for <= 256 rows)
     const int comp = t & 31, slice = t >> 5;
     double acc = 0.0;
-    {
+    if (pa.reduced) {      // (block-uniform) the sums arrive folded: slice 0 carries them, the others zeros
+        if (!pa.first && slice == 0) acc = pa.reduced[comp];
+        for (int w = t; w < kVgCtlWords; w += 256) sh_ctl[w] = reinterpret_cast<const uint32_t*>(pa.ctl_prev)[w];
+    } else {
         double v[32];
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_i
 #pragma unroll
         for (int u = 0; u < 32; ++u) acc += v[u];
     }
-    if (!pa.first)
+    if (!pa.first && !pa.reduced)
         for (uint32_t r0 = 256; r0 < pa.rows_prev_n; r0 += 256) {      // (more than 65 536 source points: 512 rows)
             double v[32];
 #pragma unroll
@@ -645,6 +650,38 @@ __global__ __launch_bounds__(256) void vgicp_pass_pro_kernel(const VgicpArgs a_i
     __syncthreads();      // (sh_sum is reused by the body)
     if (kind == kVgPassLinearize) vgicp_lin_body<false>(a, T, sh, sh_sum);
     else vgicp_lin_body<true>(a, T, sh, sh_sum);
+}
+
+// Sharded targets over the peer exchange (pcr_comm_init_peer): between two passes ONE launch folds this rank's rows of the pass that has just run --
+// the order of vgicp_pass_pro_kernel's own fold -- pushes the 32 sums into every peer's receive buffer and folds what arrived in rank order
+// (peer_exchange.h); the next pass's prologue takes the result (VgProArgs::reduced) and the optimiser's step as ever, in every block, on every rank,
+// on the same bits.  Two launches per pass and no host round trip, where the host-driven loop of a sharded target has one per pass.  Once the loop
+// has finished (the state the pass before left says so, on every rank in the same launch) nothing is exchanged.
+__global__ __launch_bounds__(256) void vgicp_peer_exchange_kernel(const double* __restrict__ rows, uint32_t n_rows, const VgCtl* __restrict__ ctl, const PeerComm pc,
+                                                                  const double xseq, double* __restrict__ reduced) {
+    __shared__ double sh_sum[8 * 32];
+    const int t = threadIdx.x, comp = t & 31, slice = t >> 5;
+    if (ctl->done) return;
+    double acc = 0.0;
+    for (uint32_t r0 = 0; r0 < n_rows; r0 += 256) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const uint32_t row = r0 + (uint32_t)(slice + 8 * u);
+            v[u] = row < n_rows ? rows[(size_t)row * 32 + comp] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += v[u];
+    }
+    sh_sum[slice * 32 + comp] = acc;
+    __syncthreads();
+    double mine = 0.0;
+    if (t < 32) {
+        mine = sh_sum[t];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) mine += sh_sum[k * 32 + t];
+    }
+    peer_exchange_block(pc, xseq, nullptr, mine, 32, 0, reduced);      // (a rank that never arrives: the status word says so to the host, which ends the call and the session)
 }
 
 struct VgCtlArg { uint32_t w[kVgCtlWords]; };
@@ -810,7 +847,9 @@ hipError_t vgicp_launch_ctl_init(VgCtl* d_ctl2, const Pose16& guess, int max_ite
     return hipGetLastError();
 }
 // launch `index` of the device-resident loop: d_ctl2 = two VgCtl, d_rows2 = two buffers of 512 * 32 doubles
-hipError_t vgicp_launch_pass_pro(const VgicpArgs& a_in, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index) {
+// pc / xseq / d_reduced (sharded over the peer exchange, launches after the first): the exchange launch in front of the pass
+hipError_t vgicp_launch_pass_pro(const VgicpArgs& a_in, VgCtl* d_ctl2, double* d_rows2, VgOut* d_out, hipStream_t s, double seq, int index,
+                                 const PeerComm* pc, double xseq, double* d_reduced) {
     const uint32_t nb = vgicp_blocks(a_in.n_src);
     VgicpArgs a = a_in;
     a.partials = d_rows2 + (size_t)(index & 1) * 512 * 32;
@@ -819,6 +858,8 @@ hipError_t vgicp_launch_pass_pro(const VgicpArgs& a_in, VgCtl* d_ctl2, double* d
     pa.ctl_prev = index == 0 ? d_ctl2 : d_ctl2 + ((index + 1) & 1);
     pa.ctl_next = d_ctl2 + (index & 1);
     pa.out = d_out; pa.seq = seq; pa.rows_prev_n = nb; pa.first = index == 0 ? 1 : 0;
+    pa.reduced = pc ? d_reduced : nullptr;
+    if (pc && index > 0) hipLaunchKernelGGL(vgicp_peer_exchange_kernel, dim3(1), dim3(256), 0, s, pa.rows_prev, nb, pa.ctl_prev, *pc, xseq, d_reduced);
     hipLaunchKernelGGL(vgicp_pass_pro_kernel, dim3(nb), dim3(256), 0, s, a, pa);
     return hipGetLastError();
 }

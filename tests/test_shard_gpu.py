@@ -497,3 +497,154 @@ def test_peer_exchange_with_one_rank_runs_the_whole_protocol(gpu):
     np.testing.assert_array_equal(p_rccl, p_plain)
     print(f"per iteration over the unsharded call: peer exchange {(t_peer - t_plain) * 1e5:.2f} us, reduce + ncclAllReduce {(t_rccl - t_plain) * 1e5:.2f} us")
     assert t_peer < 2.0 * t_rccl, (t_plain, t_peer, t_rccl)
+
+
+def _peer_worker_ndt(rank, world_size, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world, m = synth.make_map(300_000, seed=S + 11, spacing=0.3)
+    scan, T = synth.make_scan(world, 0, seed=S + 11)
+    init = synth.perturb(T, S + 11, trans=0.1, rot_deg=0.5)
+    tile = shard.tile_for_method(m, rank, world_size, "ndt")
+    reg = make_register("ndt")
+    reg.set_shard(tile.lo, tile.hi, tile.halo)
+    handles = [None] * world_size
+    dist.all_gather_object(handles, reg.comm_peer_export())
+    reg.comm_init_peer(handles, rank, world_size)
+    d_scan, d_tile = torch.from_numpy(scan).cuda(), torch.from_numpy(tile.points).cuda()
+    poses, convs, its = [], [], []
+    for _ in range(3):      # (several calls: batches enqueued beyond the end of one call must not leak into the next, the sequence numbers keep agreeing)
+        pose = init.copy()
+        convs.append(reg.scan2Map(d_scan, d_tile, pose)); poses.append(pose); its.append(reg.stats()["iterations"])
+    q.put((rank, dict(poses=poses, conv=convs, iters=its, info=reg.comm_info())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ndt_over_the_peer_exchange_between_two_processes_on_one_card(gpu):
+    """Sharded NDT with the device-resident loop over the peer exchange (round 5): per evaluation pass the evaluation launch and ONE launch that folds
+    this rank's rows, pushes the 48 sums into every peer's receive buffer, folds what arrived in rank order and takes the controller's step
+    (ndt.hip: ndt_fold_exchange_ctl_kernel) -- no collective library, no host round trip.  Two processes on the one card: both ranks' poses,
+    verdicts and iteration counts equal, bit for bit, over several calls; the pose that of the unsharded handle to rounding."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 1313) % 2000)
+    procs = [ctx.Process(target=_peer_worker_ndt, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    world, m = synth.make_map(300_000, seed=S + 11, spacing=0.3)
+    scan, T = synth.make_scan(world, 0, seed=S + 11)
+    init = synth.perturb(T, S + 11, trans=0.1, rot_deg=0.5)
+    ref = init.copy()
+    plain = make_register("ndt")
+    c = plain.scan2Map(scan, m, ref)
+    assert got[0]["info"]["transport"] == "peer" and got[0]["info"]["nranks"] == 2
+    for k in range(3):
+        np.testing.assert_array_equal(got[0]["poses"][k], got[1]["poses"][k])
+        np.testing.assert_array_equal(got[0]["poses"][k], got[0]["poses"][0])
+    assert got[0]["conv"] == got[1]["conv"] == [c] * 3
+    assert got[0]["iters"] == got[1]["iters"] == [plain.stats()["iterations"]] * 3
+    dt, dr = synth.pose_error(got[0]["poses"][0], ref)
+    assert dt <= 2e-6 and dr <= 2e-6, (dt, dr)      # (the sums of the sharded loop are added up in another order: a float pose, an ulp or two)
+
+
+def test_ndt_peer_exchange_with_one_rank_equals_the_rccl_loop(gpu):
+    """one rank pushing to itself runs the whole protocol; the sharded device loop over it takes the same passes and arrives at the same pose, bit for
+    bit, as the same loop over a one-rank RCCL communicator (same evaluation kernel, same fold order) -- in two launches per pass instead of three
+    and a collective.  The price per pass over the unsharded call is printed."""
+    import time
+    import torch
+    world, m = synth.make_map(300_000, seed=S + 11, spacing=0.3)
+    scan, T = synth.make_scan(world, 0, seed=S + 11)
+    init = synth.perturb(T, S + 11, trans=0.1, rot_deg=0.5)
+    d_scan, d_map = torch.from_numpy(scan).cuda(), torch.from_numpy(m).cuda()
+
+    def timed(reg):
+        for _ in range(5):
+            p = init.copy(); reg.scan2Map(d_scan, d_map, p)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(30):
+            p = init.copy(); reg.scan2Map(d_scan, d_map, p)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 30, p, reg.stats()
+    plain = make_register("ndt", full_target=1)
+    t_plain, p_plain, s_plain = timed(plain)
+    peer = make_register("ndt")
+    peer.comm_init_peer([peer.comm_peer_export()], 0, 1)
+    t_peer, p_peer, s_peer = timed(peer)
+    rccl = make_register("ndt")
+    rccl.comm_init(shard.unique_id(), 0, 1)
+    t_rccl, p_rccl, s_rccl = timed(rccl)
+    np.testing.assert_array_equal(p_peer, p_rccl)
+    assert s_peer["iterations"] == s_rccl["iterations"] == s_plain["iterations"]
+    dt, dr = synth.pose_error(p_peer, p_plain)
+    assert dt <= 2e-6 and dr <= 2e-6, (dt, dr)
+    passes = max(1, s_rccl["attempts"])
+    print(f"sharded NDT, one rank, per call: unsharded {t_plain * 1e3:.3f} ms, peer {t_peer * 1e3:.3f} ms, rccl {t_rccl * 1e3:.3f} ms ({passes} passes)")
+    assert t_peer < t_rccl * 1.1, (t_plain, t_peer, t_rccl)
+
+
+def _peer_worker_vgicp(rank, world_size, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world, m = synth.make_map(200_000, seed=S + 12)
+    scan, T = synth.make_scan(world, 0, seed=S + 12, beams=32, azimuths=512)
+    init = synth.perturb(T, S + 12, trans=0.2, rot_deg=1.0)
+    tile = shard.tile_for_method(m, rank, world_size, "vgicp")
+    reg = make_register("vgicp")
+    reg.set_shard(tile.lo, tile.hi, tile.halo)
+    handles = [None] * world_size
+    dist.all_gather_object(handles, reg.comm_peer_export())
+    reg.comm_init_peer(handles, rank, world_size)
+    d_scan, d_tile = torch.from_numpy(scan).cuda(), torch.from_numpy(tile.points).cuda()
+    poses, convs, its, fit = [], [], [], []
+    for _ in range(3):
+        pose = init.copy()
+        convs.append(reg.scan2Map(d_scan, d_tile, pose)); poses.append(pose); its.append(reg.stats()["iterations"]); fit.append(reg.getFitnessScore())
+    q.put((rank, dict(poses=poses, conv=convs, iters=its, fit=fit, info=reg.comm_info())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vgicp_over_the_peer_exchange_between_two_processes_on_one_card(gpu):
+    """Sharded VGICP with the device-resident Levenberg-Marquardt loop over the peer exchange (round 5): in front of every pass ONE launch folds this
+    rank's rows, pushes the 32 sums into every peer's receive buffer and folds what arrived in rank order (vgicp.hip: vgicp_peer_exchange_kernel);
+    the pass's prologue takes the optimiser's step on the result -- no host round trip per pass.  Two processes on the one card: poses, verdicts,
+    iteration counts and fitness scores equal on both ranks, bit for bit, over several calls; the pose that of the unsharded handle to a float ulp."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 1717) % 2000)
+    procs = [ctx.Process(target=_peer_worker_vgicp, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    world, m = synth.make_map(200_000, seed=S + 12)
+    scan, T = synth.make_scan(world, 0, seed=S + 12, beams=32, azimuths=512)
+    init = synth.perturb(T, S + 12, trans=0.2, rot_deg=1.0)
+    ref = init.copy()
+    plain = make_register("vgicp")
+    c = plain.scan2Map(scan, m, ref)
+    assert got[0]["info"]["transport"] == "peer" and got[0]["info"]["nranks"] == 2
+    for k in range(3):
+        np.testing.assert_array_equal(got[0]["poses"][k], got[1]["poses"][k])
+        np.testing.assert_array_equal(got[0]["poses"][k], got[0]["poses"][0])
+    assert got[0]["conv"] == got[1]["conv"] == [c] * 3
+    assert got[0]["iters"] == got[1]["iters"] == [plain.stats()["iterations"]] * 3
+    assert got[0]["fit"] == got[1]["fit"]
+    dt, dr = synth.pose_error(got[0]["poses"][0], ref)
+    assert dt <= 2e-6 and dr <= 2e-6, (dt, dr)
