@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_tiles, uint32_t nb_max,
                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start,
                                                        const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
-                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift, int hoist) {
+                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift) {
     // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
     // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
     static_assert(kPlace || !kSub, "tiles are cut by a layout only");
@@ -442,15 +442,9 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     uint16_t* const sh_sub = reinterpret_cast<uint16_t*>(dyn_lds + 2 * (size_t)nb_max + 2);      // kSub: max_tiles entries (first bin | k << 13)
     DEV_STAMP(0, 0);
     constexpr uint32_t kBinChunk = 256u * kBinPer;      // points a block histograms at a time
-    float px[kBinPer], py[kBinPer], pz[kBinPer];
+    // (requesting a block's first chunk of points before the header has arrived -- two independent round trips -- was measured, round 5: nothing at
+    //  1 M points, 6-7 us WORSE at 10 M, where blocks queue up three to a CU)
     const uint32_t c_first = blockIdx.x * kBinChunk;
-    if (hoist && c_first < n) {      // the first chunk's points are requested before the header has arrived: two independent round trips overlap
-#pragma unroll
-        for (int u = 0; u < kBinPer; ++u) {
-            const uint32_t i = c_first + u * 256 + threadIdx.x;
-            load_xyz<kVec>(pts, i < n ? i : c_first, stride, px[u], py[u], pz[u]);
-        }
-    }
     uint32_t nb_lay = 0, nt_lay = 0;
     if (kPlace) { nb_lay = lay_cur[kLayMeta]; nt_lay = lay_cur[kLayMeta + 1]; }      // (requested beside the header)
     const GridHeader h = *hdr;
@@ -469,12 +463,11 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     for (uint32_t c0 = c_first; c0 < n; c0 += gridDim.x * kBinChunk) {
         uint32_t bin[kBinPer], loc[kBinPer];
         bool first[kBinPer];
-        if (c0 != c_first || !hoist) {
+        float px[kBinPer], py[kBinPer], pz[kBinPer];
 #pragma unroll
-            for (int u = 0; u < kBinPer; ++u) {      // all loads of the chunk in flight
-                const uint32_t i = c0 + u * 256 + threadIdx.x;
-                load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
-            }
+        for (int u = 0; u < kBinPer; ++u) {      // all loads of the chunk in flight
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
         }
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) {
@@ -1297,10 +1290,9 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const uint32_t nb_bin = use_layout ? nb_max : max_bins;      // bins the bin pass counts in LDS
         const size_t bin_lds = (size_t)nb_bin * 4 + (use_layout ? ((size_t)nb_bin + 4) * 4 : 0) + (use_sub ? ((size_t)max_bins + 8) * 2 : 0), place_lds = ((size_t)max_bins + 4) * 4,
                      tile_lds = std::max<size_t>((size_t)(1u << tshift) * 4, plan_lds ? ((size_t)nb_max + 4) * 4 + ((size_t)max_bins + 8) * 2 : 0);
-        const int bin_hoist = dev_env("PCR_BIN_NO_HOIST") ? 0 : 1;
 #define PCR_LAUNCH_BIN(VEC, PER, PLACE, SUB) hipLaunchKernelGGL((grid_bin_kernel<VEC, PER, PLACE, SUB>), dim3(bin_blocks), dim3(256), bin_lds, s, d_pts, n32, st, header.as<GridHeader>(), \
                                                     bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, nb_bin, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
-                                                    lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift, bin_hoist)
+                                                    lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
 #define PCR_LAUNCH_BIN_P(VEC, PLACE, SUB) do { if (bin_per == 4) PCR_LAUNCH_BIN(VEC, 4, PLACE, SUB); else if (bin_per == 8) PCR_LAUNCH_BIN(VEC, 8, PLACE, SUB); else PCR_LAUNCH_BIN(VEC, 16, PLACE, SUB); } while (0)
         if (use_layout && use_sub) { if (vec) PCR_LAUNCH_BIN_P(true, true, true); else PCR_LAUNCH_BIN_P(false, true, true); }
         else if (use_layout) { if (vec) PCR_LAUNCH_BIN_P(true, true, false); else PCR_LAUNCH_BIN_P(false, true, false); }
