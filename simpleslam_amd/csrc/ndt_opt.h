@@ -452,6 +452,53 @@ NDT_HD_FLAT bool ctl_advance(NdtCtl* c) {
 // wants a longer step than step_size every further trial is that same clamped step: with the reference's constants a More-Thuente
 // search that runs to its cap evaluates ONE point nine times over.  The reference recomputes it each time; n_deriv counts what the
 // reference evaluates, `replayed` how many of those were answered from here.
+// Repeated evaluations, fast: after ctl_decide has answered ONE request from the sums it holds (same point, same sums), the next More-Thuente
+// updates see the same trial value again and again -- phi_t, d_phi_t, psi_t and d_psi_t are constants, only the interval (a_l .. g_u) and the
+// iteration count move -- until the search ends or asks for another point.  This runs those updates on LOCAL copies of the dozen scalars involved
+// (on the device the state lives in LDS, and a step through ctl_advance is a chain of LDS round trips: up to nine such steps in one pass were what
+// one lane spent most of its 5.8 us on).  Each update is first SIMULATED -- the statements of ctl_advance's line-search branch, word for word -- and
+// committed only if it ends in yet another repeat; the update that ends the run is discarded here and taken by ctl_advance itself, so whatever
+// happens next has one source: ctl_advance.  Host and device run the same code.
+NDT_HD_FLAT void ctl_replay_run(NdtCtl* c) {
+    if (c->phase != kNdtPhaseLsLoop || c->kind != kNdtPassDeriv) return;
+    const double mu = 1.e-4, nu = 0.9;
+    const int max_it = 10;
+    const double phi_t = -c->score;
+    double d_phi_t = 0;
+    for (int i = 0; i < 6; ++i) d_phi_t += c->grad[i] * c->dir[i];
+    d_phi_t = -d_phi_t;
+    const double phi_0 = c->phi_0, d_phi_0 = c->d_phi_0, step_min = c->step_min, step_max = c->step_max;
+    double a_l = c->a_l, f_l = c->f_l, g_l = c->g_l, a_u = c->a_u, f_u = c->f_u, g_u = c->g_u, a_t = c->a_t;
+    int it = c->it, open_interval = c->open_interval, n = 0;
+    double xt_new[6];
+    for (;;) {
+        const double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+        double al = a_l, fl = f_l, gl = g_l, au = a_u, fu = f_u, gu = g_u;
+        int oi = open_interval;
+        if (oi && (psi_t <= 0 && d_psi_t >= 0)) {
+            oi = 0;
+            fl = fl + phi_0 - mu * d_phi_0 * al; gl = gl + mu * d_phi_0;
+            fu = fu + phi_0 - mu * d_phi_0 * au; gu = gu + mu * d_phi_0;
+        }
+        const bool ic = oi ? update_interval(al, fl, gl, au, fu, gu, a_t, psi_t, d_psi_t) : update_interval(al, fl, gl, au, fu, gu, a_t, phi_t, d_phi_t);
+        const int it2 = it + 1;
+        if (ic || !(it2 < max_it) || (psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) break;      // the search ends: ctl_advance's turn
+        double at2 = oi ? trial_value(al, fl, gl, au, fu, gu, a_t, psi_t, d_psi_t) : trial_value(al, fl, gl, au, fu, gu, a_t, phi_t, d_phi_t);
+        at2 = min_std(at2, step_max);
+        at2 = max_std(at2, step_min);
+        bool same = true;
+        for (int i = 0; i < 6; ++i) { xt_new[i] = c->p[i] + c->dir[i] * at2; same = same && xt_new[i] == c->x_eval[i]; }
+        if (!same) break;                                                                   // another point: ctl_advance's turn
+        a_l = al; f_l = fl; g_l = gl; a_u = au; f_u = fu; g_u = gu; a_t = at2; it = it2; open_interval = oi;
+        ++n;
+    }
+    if (!n) return;
+    c->a_l = a_l; c->f_l = f_l; c->g_l = g_l; c->a_u = a_u; c->f_u = f_u; c->g_u = g_u; c->a_t = a_t;
+    c->it = it; c->open_interval = open_interval; c->interval_converged = 0;
+    for (int i = 0; i < 6; ++i) c->x_t[i] = c->p[i] + c->dir[i] * a_t;      // (what the last committed update stored: the values compare equal to x_eval; the bits are these)
+    c->n_deriv += n; c->replayed += n;
+}
+
 // What a pass's sums do to entry i of the Hessian the state machine keeps (kind / phase: of the request the pass answered).  Apart from ctl_decide so
 // that the device can let 36 lanes take the entries in while one lane decides (hess_taken below).
 NDT_HD_FLAT double ctl_hess_entry(int kind, int phase, const double sums[43], int i) {
@@ -486,6 +533,7 @@ NDT_HD_FLAT bool ctl_decide(NdtCtl* c, const double sums[43], bool hess_taken = 
         // (x_t == x_eval compares values: +0 / -0 would pass as equal and give the same pose; NaN never passes)
         c->n_deriv += 1; c->replayed += 1;
         if (!hess_zero) { for (int i = 0; i < 36; ++i) c->hess[i] = 0.0; hess_zero = true; }
+        ctl_replay_run(c);      // (the repeats that follow, on local copies; whatever ends them is left to ctl_advance)
     }
 }
 
