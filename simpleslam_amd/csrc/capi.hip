@@ -862,7 +862,7 @@ int vgicp_source_enqueue(pcr_handle* h, const float* d_src, size_t n_src, size_t
                                                  h->src_cov6.as<double>(), h->side_stream, nullptr, nullptr, &h->src_scratch,
                                                  (h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000) ? h->ev_cov + 2 : nullptr)) != hipSuccess)
         err = std::string("vgicp_launch_cov: ") + hipGetErrorString(e);
-    if (e == hipSuccess && h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000) h->ev_cov_src_used = true;
+    if (e == hipSuccess && h->profile >= 2 && h->ev_cov[2] && n_src > 0 && n_src <= 300000 && dev_env("PCR_COV_OLD") == nullptr) h->ev_cov_src_used = true;      // (the development switch takes the old kernel, which records none of the three event pairs)
     h->fit_copied_from = nullptr;
     if (e == hipSuccess && !sharded(h) && n_src > 0) {      // the scan, kept for a later pcr_fitness() (off the critical path here)
         const size_t bytes = n_src * stride_floats * sizeof(float);
@@ -1327,7 +1327,13 @@ int ndt_prepare_target(pcr_handle* h, const float* d_dst, size_t n_dst, size_t s
         bf.want_tail = true;
         bf.tail.vox_slot = h->nd_slot.as<uint32_t>(); bf.tail.list = h->nd_list.as<uint32_t>(); bf.tail.count = nd_count; bf.tail.count_next = nd_count_next;
         bf.tail.min_points = min_points; bf.tail.capacity = (uint32_t)std::min<size_t>(max_vox, 0xffffffffu);
+        const size_t cap_before = h->grid.cell_capacity;
+        const void* const slot_before = h->nd_slot.p;
         if (h->grid.build(d_dst, n_dst, stride_floats, res, h->stream, &h->err, 0.0, 1, nullptr, true, want_roi && !no_filter ? &bf : nullptr) != hipSuccess) return 1;
+        // (the tile pass has been handed vox_slot and the list BEFORE the build: nothing in build() may move them -- it never grows the cell table, only
+        //  callers do -- but a change that broke that would write through a freed pointer: refuse loudly instead)
+        if (bf.tail_applied && (h->grid.cell_capacity != cap_before || h->nd_slot.p != slot_before))
+            return fail(h, "internal: the cell table changed size inside a deferred NDT build whose tile pass lists the voxel cells");
     } else if (settle_grid(h, h->grid, d_dst, n_dst, stride_floats, res, 1)) return 1;
     h->tgt_ptr = d_dst; h->tgt_n = n_dst; h->tgt_stride = stride_floats; h->have_target = true;
     H_TRY(h->nd_slot.reserve(((size_t)h->grid.cell_capacity + 64) * sizeof(uint32_t)));
