@@ -128,6 +128,8 @@ struct pcr_handle {
     double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
     double* out48_dev = nullptr;
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
+    unsigned long long vf_builds = 0, vf_stale = 0;      // index builds of the voxel filter, and how many found the reused box / layout too small
+    char* vf_ret = nullptr;              // page-locked: what the voxel filter's last block reports (VfResult: the voxel count + the index header's verdict)
     DeviceBuf vg_reduced;                // sharded VGICP over the peer exchange: a pass's 32 sums folded over the rows and the ranks
     DeviceBuf nd_sums;                   // sharded device loop: the 48 sums of a pass, all-reduced in place
     NdtOut* nd_out_host = nullptr;       // host-mapped: its result and progress word
@@ -1815,11 +1817,13 @@ void pcr_destroy(pcr_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); pin_forget_stream(h->stream); }
+    if (dev_env("PCR_VF_DEBUG") && h->vf_builds) fprintf(stderr, "voxel filter: %llu index builds, %llu of them over a box or layout that did not hold the cloud\n", h->vf_builds, h->vf_stale);      // (development builds)
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     h->grid.release(); h->tgt_stage.release(); h->src_stage.release();
     peer_close(h);
     if (h->peer_own) (void)hipFree(h->peer_own);
     if (h->peer_status_host) (void)hipHostFree(h->peer_status_host);
+    if (h->vf_ret) (void)hipHostFree(h->vf_ret);
     h->prof_count.release();
     for (hipEvent_t e : h->ev_cov) if (e) (void)hipEventDestroy(e);
     h->vf_grid.release(); h->vf_in.release(); h->vf_out.release(); h->vf_head.release(); h->vf_sums.release(); h->vf_count.release();
@@ -1985,17 +1989,66 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
     const size_t sf = stride_bytes / 4;
     const float* d_pts = static_cast<const float*>(pts);
     if (!on_device && stage_host(h, &h->vf_in, pts, n, stride_bytes, &d_pts, true)) return 1;
-    GridHeader hdr;
+    // ONE round trip: the two launches of the filter are queued right behind the index build -- they read the header themselves and do nothing
+    // when it says overflow, stale or empty -- and their last block writes the voxel count and the header's verdict into page-locked memory.
+    // (Round 4 read the header first, then the count: two more synchronisations and an idle device in between, ~35 us of the 0.16 ms a
+    //  65 536-point scan took: round 5, scripts/seq_breakdown.py.)
+    // The index reuses the previous call's box and tile layout when the cloud still fits (GridIndex::hint_ok): the order of the voxels -- idx sorts by
+    // (z, y, x) -- does not depend on where the box starts, so the output is the same either way; a cloud that does not fit comes back `stale` and is
+    // built afresh, from then on with room around the box (a sub-map's box moves with the vehicle) and half as much again per bin.
+    H_TRY(h->vf_head.reserve((n + 4096) * sizeof(uint32_t)));
+    H_TRY(h->vf_sums.reserve((n / 2048 + 2) * sizeof(uint32_t)));
+    H_TRY(h->vf_count.reserve(voxel_filter_wave_bytes(n)));
+    float* d_out = static_cast<float*>(out);
+    size_t cap = out_capacity;
+    if (!out_on_device) {
+        cap = std::min(out_capacity, n);
+        H_TRY(h->vf_out.reserve((cap ? cap : 1) * stride_bytes));
+        d_out = h->vf_out.as<float>();
+    }
+    if (!h->vf_ret) H_TRY(hipHostMalloc((void**)&h->vf_ret, sizeof(VfResult) + 64, hipHostMallocDefault));
+    volatile VfResult& ret = *reinterpret_cast<VfResult*>(h->vf_ret);
+    h->vf_grid.no_hints = h->prm.index_no_hints != 0;
+    h->vf_grid.cut_sparse = true; h->vf_grid.coherent_input = true;
     bool settled = false;
-    for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
-        if (h->vf_grid.build(d_pts, n, sf, leaf, h->stream, &h->err, 0.0, 1) != hipSuccess) return 1;
-        H_TRY(hipMemcpyAsync(&hdr, h->vf_grid.header.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+    uint32_t count = 0;
+    int too_fine = 0;
+    for (int attempt = 0; attempt < 6 && !settled; ++attempt) {
+        if (h->vf_grid.build(d_pts, n, sf, leaf, h->stream, &h->err, 0.0, 1, nullptr, true) != hipSuccess) return 1;
+        H_TRY(voxel_filter_launch(h->vf_grid, d_pts, sf, n, h->vf_head.as<uint32_t>(), h->vf_sums.as<uint32_t>(), h->vf_count.p, d_out, cap,
+                                  h->vf_ret, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
-        if (!hdr.overflow) { settled = true; h->vf_grid.note_cells(hdr.n_cells); }
-        else if (h->vf_grid.grow_cells(hdr.n_cells, &h->err) != hipSuccess) return 1;
+        ++h->vf_builds;
+        if (dev_env("PCR_VF_DEBUG") && n > 100000) {      // (development builds: the layout this build planned -- bins, tiles, the heaviest bin)
+            std::vector<uint32_t> lay(3 * kMaxBins + 32);
+            (void)hipMemcpy(lay.data(), h->vf_grid.layout[h->vf_grid.lay_idx].p, lay.size() * 4, hipMemcpyDeviceToHost);
+            std::vector<uint32_t> bs(kMaxBins + 8);
+            (void)hipMemcpy(bs.data(), h->vf_grid.bin_start.p, bs.size() * 4, hipMemcpyDeviceToHost);
+            const uint32_t nb = lay[3 * kMaxBins + 24], nt = lay[3 * kMaxBins + 25];
+            uint32_t room_max = 0, kmax = 0;
+            for (uint32_t b = 0; b < nb && b < (uint32_t)kMaxBins; ++b) { room_max = std::max(room_max, lay[b + 1] - lay[b]); kmax = std::max(kmax, lay[2 * kMaxBins + 16 + b] >> 26); }
+            uint32_t held_max = 0;
+            const uint32_t nb_used = h->vf_grid.used_layout ? h->vf_grid.lay_nb_max : 0;
+            for (uint32_t b = 0; b + 1 < bs.size(); ++b) if (bs[b + 1] >= bs[b]) held_max = std::max(held_max, bs[b + 1] - bs[b]);
+            fprintf(stderr, "voxel filter: n %zu used_hint %d used_layout %d tshift %d stale %d overflow %d | next layout: %u bins over %u tiles, widest room %u, deepest cut %u | this build's fullest bin %u (nb_max %u)\n",
+                    n, (int)h->vf_grid.used_hint, (int)h->vf_grid.used_layout, h->vf_grid.tiled_shift, (int)ret.stale, (int)ret.overflow, nb, nt, room_max, kmax, held_max, nb_used);
+        }
+        if (ret.stale) {      // the box (or a bin's room) taken over from the previous call does not hold this cloud
+            ++h->vf_stale;
+            if (dev_env("PCR_VF_DEBUG")) fprintf(stderr, "voxel filter: n %zu leaf %g stale %d (1 box, 2 room, 3 layout)\n", n, leaf, (int)ret.stale);
+            // (the cell count the tile size goes by is kept once the box has its margin: a build without it takes the dense path -- 23 us instead of 11 for a scan)
+            if (h->vf_grid.hint_margin == 0) { h->vf_grid.hint_margin = 16; h->vf_grid.hint_margin_z_pcl = 4; h->vf_grid.cells_hint = 0; }
+            h->vf_grid.lay_room_shift = 1; h->vf_grid.lay_room_add = 256;
+            continue;
+        }
+        if (!ret.overflow) {
+            settled = true; count = ret.count; too_fine = ret.too_fine;
+            h->vf_grid.note_cells(ret.n_cells);
+            if (!ret.empty && !ret.too_fine) h->vf_grid.confirm();
+        } else if (h->vf_grid.grow_cells(ret.n_cells, &h->err) != hipSuccess) return 1;
     }
     if (!settled) return fail(h, "voxel table could not be sized");
-    if (hdr.too_fine) {
+    if (too_fine) {
         // pcl::VoxelGrid: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
         *n_out = n;
         if (out_capacity < n) return fail(h, "output capacity too small (leaf too small for the data: the input is returned unfiltered)");
@@ -2004,26 +2057,15 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
         h->err = "leaf size too small for the input: integer voxel indices would overflow; input returned unfiltered";
         return 0;
     }
-    H_TRY(h->vf_head.reserve((n + 4096) * sizeof(uint32_t)));
-    H_TRY(h->vf_sums.reserve((n / 2048 + 2) * sizeof(uint32_t)));
-    H_TRY(h->vf_count.reserve(16));
-    float* d_out = static_cast<float*>(out);
-    size_t cap = out_capacity;
-    if (!out_on_device) {
-        cap = std::min(out_capacity, n);
-        H_TRY(h->vf_out.reserve((cap ? cap : 1) * stride_bytes));
-        d_out = h->vf_out.as<float>();
-    }
-    H_TRY(voxel_filter_launch(h->vf_grid, d_pts, sf, n, h->vf_head.as<uint32_t>(), h->vf_sums.as<uint32_t>(), d_out, cap,
-                              h->vf_count.as<uint32_t>(), h->stream));
-    uint32_t count = 0;
-    H_TRY(hipMemcpyAsync(&count, h->vf_count.p, sizeof(count), hipMemcpyDeviceToHost, h->stream));
-    H_TRY(hipStreamSynchronize(h->stream));
     *n_out = count;
     if (count > out_capacity) return fail(h, "output capacity too small: " + std::to_string(count) + " voxels are occupied");
     if (!out_on_device && count) H_TRY(hipMemcpy(out, d_out, (size_t)count * stride_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+
+}  // extern "C"
+hipStream_t pcr_internal_stream(const pcr_handle* h) { return h ? h->stream : nullptr; }
+extern "C" {
 
 double pcr_fitness(pcr_handle* h) {
     if (!h) return -1.0;

@@ -37,7 +37,7 @@ __device__ inline float wave_max(float v) {
 __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride,
                                                                float* __restrict__ partials, uint32_t* __restrict__ ticket,
                                                                GridHeader* __restrict__ hdr, uint64_t capacity, double cell, double shift, int pcl_mode,
-                                                               const ClampBox clamp, int margin_xy, GridHeader* __restrict__ mirror, const HeaderTwin twin) {
+                                                               const ClampBox clamp, int margin_xy, GridHeader* __restrict__ mirror, const HeaderTwin twin, int margin_z_pcl) {
     // mirror: a host-mapped copy of the header (or nullptr), written here so that no copy has to be queued behind the build when nothing
     // later in it can change the header (a build without hints).  twin: a second index over the SAME cloud at another cell size gets its
     // header from the same box (the coarse level of a scan's covariance search: one pass over the cloud instead of two).
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
         h.pcl_mode = pcl_mode; h.inv_leaf_f = 1.0f / (float)cell; h.too_fine = 0; h.sum_sq = 0.f; h.sum_sq_u = 0ull;
         h.min_b[0] = h.min_b[1] = h.min_b[2] = 0;
         h.clamped = (clamp.use && !pcl_mode) ? 1 : 0; h.cut_mask = 0; h.stale = 0; h.pad2_ = 0;
-        double nc = 1.0;
+        double nc = 1.0, nc_tight = 1.0;      // (nc_tight: cells of the box WITHOUT the room left for the next cloud -- pcl's own count)
         for (int d = 0; d < 3; ++d) {
             float lo = fminf(fminf(sh[0][d], sh[1][d]), fminf(sh[2][d], sh[3][d]));
             float hi = fmaxf(fmaxf(sh[0][3 + d], sh[1][3 + d]), fmaxf(sh[2][3 + d], sh[3][3 + d]));
@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
             if (pcl_mode) {
                 // pcl::VoxelGrid::applyFilter: min_b = floor(min_p * inverse_leaf_size), float arithmetic throughout
                 float flo = floorf(lo * h.inv_leaf_f), fhi = floorf(hi * h.inv_leaf_f);
-                if (d < 2 && !h.empty && margin_xy) { flo -= (float)margin_xy; fhi += (float)margin_xy; }      // (NDT only, after a hint has failed: voxel membership does not depend on where the lattice starts)
+                nc_tight *= (double)fhi - (double)flo + 1.0;
+                // (after a hint has failed: voxel membership does not depend on where the lattice starts, and neither does the ORDER of the voxels -- idx sorts
+                //  by (z, y, x) whatever the box: NDT pads x and y, the voxel filter z as well)
+                const int mg = d < 2 ? margin_xy : margin_z_pcl;
+                if (!h.empty && mg) { flo -= (float)mg; fhi += (float)mg; }
                 const double dim = (double)fhi - (double)flo + 1.0;
                 h.min_b[d] = fabsf(flo) < 2.0e9f ? (int32_t)flo : 0;
                 h.org[d] = (double)flo; h.origin[d] = (double)flo * cell;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
             h.dims[d] = dim < 2.0e9 ? (int32_t)dim : 0x7fffffff;
             nc *= dim;
         }
-        if (pcl_mode && nc > 2147483647.0) h.too_fine = 1;      // (dx*dy*dz) > INT_MAX
+        if (pcl_mode && nc_tight > 2147483647.0) h.too_fine = 1;      // (dx*dy*dz) > INT_MAX
         // keys are uint32 and the table holds n_cells + 1 starts
         if (h.too_fine) { h.overflow = 0; h.empty = 1; h.n_cells = 1; }      // nothing is indexed; the caller copies its input
         else if (nc + 1.0 > (double)capacity || nc > 4.0e9) { h.overflow = 1; h.n_cells = nc < 1.8e19 ? (uint64_t)nc : ~0ull; }
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     const uint32_t nb = kPlace ? nb_lay : ntiles;
     if (kPlace) {
         // (a layout made for another lattice, one that holds cuts this kernel does not read, or none: nothing is binned, the caller rebuilds without hints)
-        if (nb == 0u || nb > nb_max || nt_lay != ntiles || ntiles > max_tiles || (!kSub && nb != ntiles)) { if (threadIdx.x == 0) hdr->stale = 1; return; }
+        if (nb == 0u || nb > nb_max || nt_lay != ntiles || ntiles > max_tiles || (!kSub && nb != ntiles)) { if (threadIdx.x == 0) hdr->stale = 3; return; }      // (stale: 1 = a point outside the box, 2 = a bin outgrew its room, 3 = no usable layout; callers test != 0)
         for (uint32_t b = threadIdx.x; b <= nb; b += 256) sh_lay[b] = lay_cur[b];
         if (kSub) for (uint32_t t = threadIdx.x; t < ntiles; t += 256) sh_sub[t] = (uint16_t)lay_cur[kLaySub + t];
     }
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                     else over = true;
                 }
             }
-            if (over) hdr->stale = 1;      // the bin has outgrown the room the previous build left it
+            if (over) hdr->stale = 2;      // the bin has outgrown the room the previous build left it
         } else {
 #pragma unroll
             for (int u = 0; u < kBinPer; ++u) {
@@ -623,6 +627,23 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
     }
 }
 
+// rank of this lane's point among the points of cell c counted so far; one atomic per run of equal cells in consecutive lanes (every lane of the wave calls)
+__device__ inline uint32_t hist_claim_runs(uint32_t* hist, uint32_t c, bool valid) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t cc = valid ? c : 0xffffffffu;
+    const uint32_t prev = __shfl_up(cc, 1, 64);
+    const bool leader = lane == 0 || prev != cc;
+    const unsigned long long lead = __ballot(leader);
+    const unsigned long long below = lead & (~0ull >> (63 - lane));
+    const int start = 63 - __clzll(below);
+    const unsigned long long above = lane == 63 ? 0ull : (lead >> (lane + 1)) << (lane + 1);
+    const int end = above ? __ffsll((long long)above) - 1 : 64;
+    uint32_t base = 0;
+    if (leader && valid) base = atomicAdd(&hist[c], (uint32_t)(end - start));
+    base = __shfl(base, start, 64);
+    return base + (uint32_t)(lane - start);
+}
+
 // ---- block 0 of the tile pass: the layout of the NEXT build, planned beside the blocks that sort ----
 // In: this build's bin_start (points per bin) and the layout the cloud was binned by (lay_cur; nullptr: by tile).  Out: lay_next.  Per tile, with k the
 // current number of cuts: one more when its fullest slab holds more than `hs` points (and a slab would keep >= 4 cells), one fewer when every pair of
@@ -632,7 +653,7 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const float* __restrict
 // (Measured and not kept, round 5: the scan of the bin counters here too, its results published to the other blocks of the launch as tagged 64-bit
 //  words they polled -- it takes the ticket and the last block's scan off the bin pass, but block 0's 8 K counter loads queue behind the 16 MB the
 //  other blocks ask for at the same moment: published after 12 us at 1 M points, 28 us at 10 M, every block waiting; profiles/r05_notes.md.)
-struct TilePlan { uint32_t* lay_next; uint32_t hs; uint32_t nb_max; int32_t enabled; int32_t copy_only; int32_t cuts; int32_t pad_; };      // cuts: tiles may be cut (hs finite) -- else bin = tile, always
+struct TilePlan { uint32_t* lay_next; uint32_t hs; uint32_t nb_max; int32_t enabled; int32_t copy_only; int32_t cuts; int32_t room_shift; uint32_t room_add; uint32_t pad_; };      // room_shift: a bin's room = what it held + that >> room_shift + 32 (3: an eighth)      // cuts: tiles may be cut (hs finite) -- else bin = tile, always
 
 template <int kThreads>
 __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const uint32_t* __restrict__ bin_start,
@@ -642,6 +663,8 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
     if (lay_cur) nb_lay = lay_cur[kLayMeta];
     const GridHeader h = *hdr;
     uint32_t* const out = plan.lay_next;
+    const int rs = plan.room_shift;
+    const uint32_t ra = plan.room_add;
     const uint32_t ntiles = (uint32_t)(h.n_cells >> shift) + 1u;
     const uint32_t nb = lay_cur ? nb_lay : ntiles;
     const bool unusable = h.overflow || h.empty || h.stale || nb == 0u || nb > plan.nb_max || ntiles > (uint32_t)kMaxBins;
@@ -662,7 +685,7 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
 #pragma unroll
             for (uint32_t j = 0; j <= 8; ++j) c[j] = bin_start[min(b0 + j0 + j, nb)];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) if (j0 + j < per && b0 + j0 + j < nb) { const uint32_t e = c[j + 1] - c[j]; room += e + (e >> 3) + 32u; }
+            for (uint32_t j = 0; j < 8; ++j) if (j0 + j < per && b0 + j0 + j < nb) { const uint32_t e = c[j + 1] - c[j]; room += e + (e >> rs) + ra; }
         }
         uint32_t room_total;
         uint32_t lo = block_exclusive_scan<kThreads>(room, &room_total, sh_scan32);
@@ -675,7 +698,7 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
                 if (j0 + j < per && b0 + j0 + j < nb) {
                     const uint32_t e = c[j + 1] - c[j], b = b0 + j0 + j;
                     out[b] = lo; out[kLaySub + b] = b; out[kLayMap + b] = b;
-                    lo += e + (e >> 3) + 32u;
+                    lo += e + (e >> rs) + ra;
                 }
         }
         if (threadIdx.x == 0) { out[nb] = room_total; out[kLayMeta] = nb; out[kLayMeta + 1] = ntiles; }
@@ -695,7 +718,16 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
     for (uint32_t t = threadIdx.x; t < ntiles; t += kThreads) sub[t] = lay_cur ? (uint16_t)lay_cur[kLaySub + t] : (uint16_t)t;
     __syncthreads();
     const int kmax = plan.cuts ? min(kMaxSplit, shift - 2) : 0;      // (no cuts: a layout that holds some -- planned when the cloud was smaller -- is merged back step by step)
-    const uint32_t per = (ntiles + kThreads - 1) / kThreads, t0 = min(threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
+    // a thread's run of tiles: those whose first bin lies in its share of the BINS (the work below is per bin: with equal shares of the tiles the thread
+    // that owned the eight tiles under the vehicle's path, cut into 64 slabs each, walked 512 bins three times over while the others had left -- the
+    // launch took 166 us, round 5; the first bins of the tiles ascend, so a share's first tile is found by bisection)
+    auto first_tile = [&](uint32_t i) -> uint32_t {
+        const uint32_t want = (uint32_t)(((unsigned long long)i * nb) / kThreads);
+        uint32_t lo = 0, hi = ntiles;      // smallest t with first_bin(t) >= want (ntiles: none)
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((sub[mid] & 0x1fffu) < want) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    const uint32_t t0 = first_tile(threadIdx.x), t1 = threadIdx.x + 1 == kThreads ? ntiles : first_tile(threadIdx.x + 1);
     // what becomes of tile t: new k in the low bits of the result, its room << 8
     auto decide = [&](uint32_t t, bool may_cut) -> unsigned long long {
         const uint32_t e = sub[t], base = e & 0x1fffu;
@@ -706,8 +738,8 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
         for (uint32_t i = 0; i < nc; ++i) {
             const uint32_t c = start[base + i + 1] - start[base + i];
             maxc = max(maxc, c);
-            same += (unsigned long long)c + (c >> 3) + 32u;
-            if (i & 1u) { const uint32_t s2 = prev + c; maxpair = max(maxpair, s2); merged += (unsigned long long)s2 + (s2 >> 3) + 32u; }
+            same += (unsigned long long)c + (c >> rs) + ra;
+            if (i & 1u) { const uint32_t s2 = prev + c; maxpair = max(maxpair, s2); merged += (unsigned long long)s2 + (s2 >> rs) + ra; }
             prev = c;
         }
         if (may_cut && maxc > plan.hs && k < kmax) return (unsigned long long)(k + 1) | ((2ull * same) << 8);      // (both children get their parent's room)
@@ -740,7 +772,7 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
             else est = start[base + 2 * i + 2] - start[base + 2 * i];
             out[kLayMap + nbin] = t | (i << 13) | ((uint32_t)kn << 26);
             out[nbin] = pos;
-            pos += est + (est >> 3) + 32u;
+            pos += est + (est >> rs) + ra;
             ++nbin;
         }
     }
@@ -766,7 +798,10 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
 //  launches got SLOWER, 22.1 -> 30.8 us and 29.5 -> 41.9 us: a block of this pass is a chain of latencies, not a stream of stores, and the mask test put
 //  one more dependent round trip -- header, row decode, mask bytes, a block-wide OR -- in front of every one of its 3 350 blocks.  The region-only
 //  index itself (the bin pass drops the points outside the mask) is kept: profiles/r05_notes.md.)
-template <int kTilePer, int kMode, int kThreads, bool kTail, bool kPlan>
+// kRuns (GridIndex::coherent_input -- the voxel filter's clouds: scans and concatenations of scans, stored ring by ring): one LDS atomic per RUN of equal
+// cells in consecutive lanes, as the bin pass does for bins.  Consecutive returns of a ring fall into the same 0.5 m voxel eight to forty at a time, and
+// 64 same-address LDS atomics serialise: the slab of 32 cells under the vehicle's path -- 12 000 points -- took its block 170 us (round 5).
+template <int kTilePer, int kMode, int kThreads, bool kTail, bool kPlan, bool kRuns = false>
 // kPlan: the launch that carries block 0 (tile_block0; plan.enabled says whether it does).  src_start: where bin b's points lie in `tiled` -- bin_start after the placing pass, the layout hint when the bin kernel placed them.
 // lay_cur: the layout the points were binned by (nullptr: by tile).  plan.enabled: block 0 is tile_block0 and sorts nothing.
 // (forcing the 8-per-thread instantiation to 128 registers -- four blocks per CU instead of three -- changed nothing: 46.7 / 47.2 us either way, round 5)
@@ -841,11 +876,16 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
             for (int u = 0; u < kTilePer; ++u) {
                 const uint32_t j = u * (uint32_t)kThreads + threadIdx.x;
                 cr[u] = 0u;
+                uint32_t c = 0u;
                 if (j < np) {
                     uint32_t key = 0;
                     point_key(h, p[u].x, p[u].y, p[u].z, &key);
-                    const uint32_t c = key - (uint32_t)cell0;
-                    cr[u] = (c << 18) | atomicAdd(&hist[c], 1u);          // c < 2^13, rank < 4096 <= 2^18
+                    c = key - (uint32_t)cell0;
+                    if (!kRuns) cr[u] = (c << 18) | atomicAdd(&hist[c], 1u);          // c < 2^13, rank < 4096 <= 2^18
+                }
+                if (kRuns && u * (uint32_t)kThreads < np) {      // (block-uniform: whole waves)
+                    const uint32_t r = hist_claim_runs(hist, c, j < np);
+                    if (j < np) cr[u] = (c << 18) | r;
                 }
             }
         }
@@ -856,10 +896,16 @@ __global__ __launch_bounds__(kThreads) void grid_tile_kernel(const GridHeader* _
 #pragma unroll
                 for (int u = 0; u < kTilePer; ++u) {
                     const uint32_t j = j0 + u * (uint32_t)kThreads + threadIdx.x;
+                    uint32_t c = 0u;
                     if (j < np) {
                         uint32_t key = 0;
                         point_key(h, p[u].x, p[u].y, p[u].z, &key);
-                        scratch_rank[p0 + j] = atomicAdd(&hist[key - (uint32_t)cell0], 1u);
+                        c = key - (uint32_t)cell0;
+                        if (!kRuns) scratch_rank[p0 + j] = atomicAdd(&hist[c], 1u);
+                    }
+                    if (kRuns) {
+                        const uint32_t r = hist_claim_runs(hist, c, j < np);
+                        if (j < np) scratch_rank[p0 + j] = r;
                     }
                 }
             }
@@ -1220,7 +1266,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         }
         hipLaunchKernelGGL(grid_bbox_header_kernel, dim3(kBBoxBlocks), dim3(256), 0, s, d_pts, n32, st, bbox_partials.as<float>(),
                            ticket.as<uint32_t>(), header.as<GridHeader>(), (uint64_t)cap_eff, cell, shift, pcl_mode, cb,
-                           (allow_hint && !cb.use) ? hint_margin : 0, header_mirror, tw);
+                           (allow_hint && !cb.use) ? hint_margin : 0, header_mirror, tw, (allow_hint && !cb.use) ? hint_margin_z_pcl : 0);
         mirrored = header_mirror != nullptr;
     } else if (preset) mirrored = header_mirror != nullptr;
     // Tile size from the CAPACITY of the cell table (the device-side cell count never exceeds it: a larger box is an overflow):
@@ -1255,7 +1301,9 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         // 1.5 us (more bins: more claims); 1 024 costs it 4 us.  At 10 M points (tiles of 8 192 cells, sixteen points per thread) cutting does NOT pay: the bin
         // pass's stores scatter over twice the bins (151 -> 186-235 us) and the tile pass, whose length there is blocks x latency / occupancy and not its heaviest
         // block, stays at 153-169 us: clouds whose tiles hold more than ~1 000 points on average are never cut.
-        uint32_t hs = per8 ? 2048u : 0u;
+        // (cut_sparse -- the voxel filter's index: a concatenation of raw key frames on the 0.5 m lattice is a sparse grid whose few tiles next to the vehicle's
+        //  path hold tens of thousands of points each; one block sorted such a tile alone, 95 us of a 150 us build.  Its bins hold up to 4 096 points in registers.)
+        uint32_t hs = per8 ? 2048u : (sparse && cut_sparse ? 3072u : 0u);
         if (const char* e = dev_env("PCR_BIN_SPLIT")) hs = (uint32_t)std::max(0, atoi(e));      // (development: 0 = tiles are never cut)
         if (hs == 0u) hs = 0xffffffffu;
         // bins a layout may hold: the tiles + two bins per `hs` points (a slab that was cut holds between hs / 2 and hs), never fewer than the tiles the table
@@ -1270,7 +1318,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
             if (!layout[i].p) { PCR_TRY(layout[i].reserve(kLayWords * sizeof(uint32_t))); PCR_TRY(hipMemsetAsync(layout[i].p, 0, kLayWords * sizeof(uint32_t), s)); }      // (meta word 0: no layout)
         if (use_layout) {      // room for every bin's slack, the children of a tile that is cut one step further get their parent's room each:
                                // at most twice the cloud's (the device also checks every store against the capacity it is told)
-            const size_t need = 2 * (lay_n + lay_n / 8) + (size_t)32 * (nb_max + 1) + 16;
+            const size_t need = 2 * (lay_n + (lay_n >> lay_room_shift)) + (size_t)lay_room_add * (nb_max + 1) + 16;
             if (need > n + 16) PCR_TRY(tiled.reserve(need * sizeof(float4)));
         }
         const uint32_t tiled_cap = (uint32_t)std::min<size_t>(tiled.cap / sizeof(float4), 0xfffffff0u);
@@ -1313,7 +1361,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         memset(&tail, 0, sizeof tail);
         // block 0 of the (first) tile launch plans the layout of the next build; the others take a bin each
         TilePlan plan;
-        plan.lay_next = lay_next; plan.hs = hs; plan.nb_max = nb_max; plan.enabled = 1; plan.copy_only = filtered ? 1 : 0; plan.cuts = cuts_now ? 1 : 0; plan.pad_ = 0;
+        plan.lay_next = lay_next; plan.hs = hs; plan.nb_max = nb_max; plan.enabled = 1; plan.copy_only = filtered ? 1 : 0; plan.cuts = cuts_now ? 1 : 0; plan.room_shift = lay_room_shift; plan.room_add = lay_room_add; plan.pad_ = 0;
         // the tile pass: as many blocks as the device holds at once (a block takes bin after bin), + block 0
         static const int n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
         int per_cu = 0;      // (0 = a block per bin: persistent blocks -- 6 / 4 / 2 per CU by their registers -- measured no better at 1 M points and 6 % worse at 10 M, round 5)      // (blocks of 256 threads by their registers: 77 / 128 (130 with the tail) / 216 VGPRs)
@@ -1324,9 +1372,10 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const uint32_t bins_bound = use_layout ? nb_max : max_bins;
         const uint32_t bins_expected = tiles_est ? (uint32_t)std::min<uint64_t>(bins_bound, tiles_est + 16 + (use_layout && hs != 0xffffffffu ? (uint64_t)n / hs : 0)) : bins_bound;
         const int tile_blocks = (int)std::min<uint32_t>(bins_expected, per_cu > 0 ? (uint32_t)(n_cu * per_cu) : bins_expected) + 1;
-#define PCR_LAUNCH_TILE_T(PER, MODE, THREADS, TAIL, PLAN) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS, TAIL, PLAN>), dim3(tile_blocks), dim3(THREADS), tile_lds, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
+#define PCR_LAUNCH_TILE_R(PER, MODE, THREADS, TAIL, PLAN, RUNS) hipLaunchKernelGGL((grid_tile_kernel<PER, MODE, THREADS, TAIL, PLAN, RUNS>), dim3(tile_blocks), dim3(THREADS), (PLAN) ? tile_lds : (size_t)(1u << tshift) * 4, s, header.as<GridHeader>(), tile_sq.as<unsigned long long>(), \
                            bin_start.as<uint32_t>(), bin_count.as<uint32_t>(), tiled.as<float4>(), cell_start.as<uint32_t>(), sorted.as<float4>(), keys.as<uint32_t>(), tshift, \
                            use_layout ? lay_cur : (const uint32_t*)bin_start.as<uint32_t>(), use_layout ? lay_cur : (const uint32_t*)nullptr, plan, tail)
+#define PCR_LAUNCH_TILE_T(PER, MODE, THREADS, TAIL, PLAN) PCR_LAUNCH_TILE_R(PER, MODE, THREADS, TAIL, PLAN, false)
 #define PCR_LAUNCH_TILE(PER, MODE, THREADS) PCR_LAUNCH_TILE_T(PER, MODE, THREADS, false, true)
         // (blocks of 1 024 threads for the 5 M and 10 M-point maps -- grid_tile_kernel<4, 0, 1024>, PCR_TILE_WIDE in a development build -- cut the
         //  slowest tile of the 10 M-point map from 165 to 69 us and left the kernel at 165 us: one block per CU then, 19 rounds of ~8 us;
@@ -1336,13 +1385,18 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
         const bool with_tail = filtered && filter->want_tail && !sparse && tshift <= 13 && dev_env("PCR_NDT_NO_TAIL") == nullptr;
         if (with_tail) { tail = filter->tail; tail.mask = keep_mask; tail.mshift = keep_mshift; filter->tail_applied = true; }
         // (sparse grids: the launch of the light tiles carries no planning block -- its 58 registers are what lets eight of its blocks share a CU)
-        if (sparse) { PCR_LAUNCH_TILE_T(1, 1, 256, false, false); PCR_LAUNCH_TILE(16, 2, 256); }
+        // (the heavy bins of the voxel filter's clouds by blocks of 1 024 threads: what a block holds in registers is the same 4 096 points, a bin of 12 000 --
+        //  three chunks, two sweeps each -- is through four times sooner)
+        if (coherent_input && sparse) { PCR_LAUNCH_TILE_R(1, 1, 256, false, false, true); if (dev_env("PCR_VF_NARROW")) PCR_LAUNCH_TILE_R(16, 2, 256, false, true, true); else PCR_LAUNCH_TILE_R(4, 2, 1024, false, true, true); }
+        else if (coherent_input && !with_tail) { if (per8) PCR_LAUNCH_TILE_R(8, 0, 256, false, true, true); else PCR_LAUNCH_TILE_R(16, 0, 256, false, true, true); }
+        else if (sparse) { PCR_LAUNCH_TILE_T(1, 1, 256, false, false); PCR_LAUNCH_TILE(16, 2, 256); }
         else if (with_tail) { if (per8) PCR_LAUNCH_TILE_T(8, 0, 256, true, true); else PCR_LAUNCH_TILE_T(16, 0, 256, true, true); }
         else if (per8) PCR_LAUNCH_TILE(8, 0, 256);
         else if (wide > 0 && tiles_est && n / tiles_est >= (uint64_t)wide) PCR_LAUNCH_TILE(4, 0, 1024);
         else PCR_LAUNCH_TILE(16, 0, 256);
 #undef PCR_LAUNCH_TILE
 #undef PCR_LAUNCH_TILE_T
+#undef PCR_LAUNCH_TILE_R
         lay_nb_max = nb_max; lay_cuts = cuts_now || use_sub;
         lay_idx ^= 1; lay_ok = true; lay_shift = tshift;      // (what this build's last block wrote serves the next one)
         if (!filtered) lay_n = n;

@@ -201,8 +201,11 @@ struct GridIndex {
     double hint_cell = 0.0, hint_shift = 0.0;
     int hint_pcl = 0;                           // lattice kind of the build the hint comes from (a hint serves only a build of the same kind)
     int hint_margin = 0;                        // cells added around a fresh box in x and y (0 until a hint has failed once)
+    int hint_margin_z_pcl = 0;                  // ... and in z, for a pcl::VoxelGrid lattice (the voxel filter; the other lattices: see grid_bbox_header_kernel)
     bool used_hint = false;                     // the last build() reused the header
     bool no_hints = false;                      // pcr_params.index_no_hints: never reuse a header or a tile layout
+    bool coherent_input = false;                // the clouds are stored in a spatially coherent order (scans, ring by ring): the tile pass counts by runs of equal cells (grid_tile_kernel: kRuns)
+    bool cut_sparse = false;                    // sparse grids too have their heavy tiles cut into slabs by the layout hint (grid_index.hip: BINS); the voxel filter's index
     bool split_sparse_tiles = true;             // sparse grids: light and heavy tiles by an instantiation of the tile kernel each (grid_index.hip)
     bool prefer_one_level = false;              // build by the one-level path (histogram with ranks -> scan -> scatter): a small cloud on a COARSE grid puts
                                                 // a third of its points into one tile, which one block of the tiled path then sorts alone
@@ -214,6 +217,8 @@ struct GridIndex {
     uint32_t lay_nb_max = 0;                    // bins the layout in hand was planned for (the next build must have room for as many)
     bool lay_cuts = false;                      // ... and it may hold tiles that are cut (the bin pass then reads the tiles' words)
     size_t lay_n = 0;
+    uint32_t lay_room_add = 32;                 // ... + lay_room_add
+    int lay_room_shift = 3;                     // a bin's room in the layout: what it held + that >> lay_room_shift + 32 (the voxel filter's clouds change more from call to call: 1)
     bool lay_ok = false, used_layout = false;
     bool filtered = false;                      // the last build() indexed the points of a region only (BuildFilter)
     // A build WITHOUT hints computes the bounding box itself; then (grid_bbox_header_kernel)
@@ -357,8 +362,12 @@ hipError_t fitness_launch(const GridIndex& grid, const float* d_src, size_t n_sr
 uint32_t vgicp_blocks(uint32_t n_src);
 
 // pcl::VoxelGrid on the device (voxel_filter.hip); grid must have been built with pcl_mode = 1
-hipError_t voxel_filter_launch(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, uint32_t* d_head, uint32_t* d_sums,
-                               float* d_out, size_t out_capacity, uint32_t* d_n_out, hipStream_t s);
+// (two launches queued behind the build; they read the header themselves and do nothing when it says overflow, stale or empty.  d_inten: n floats,
+//  d_sums: n / 2048 + 2 words, d_wave: voxel_filter_wave_bytes(n); result_mapped: page-locked host memory the last block writes -- valid once the stream has been synchronised)
+struct VfResult { uint32_t count; int32_t overflow, too_fine, stale, empty; uint32_t pad_; unsigned long long n_cells; };
+size_t voxel_filter_wave_bytes(size_t n);
+hipError_t voxel_filter_launch(const GridIndex& grid, const float* d_orig, size_t stride_floats, size_t n, uint32_t* d_inten, uint32_t* d_sums,
+                               void* d_wave, float* d_out, size_t out_capacity, void* result_mapped, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // NDT (ndt.hip)
@@ -418,3 +427,8 @@ hipError_t loam_launch_reduce(const LoamArgs& a, int k, double* d_out, hipStream
 uint32_t loam_grid_blocks(uint32_t n_src);
 
 }  // namespace pcr
+
+// (library-internal, not part of the C ABI) the stream a handle queues its work on: the sub-map assembly queues its transform pass in front of the
+// voxel filter it runs through a handle, on that handle's stream, so that one synchronisation serves both
+struct pcr_handle;
+hipStream_t pcr_internal_stream(const pcr_handle* h);

@@ -13,11 +13,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <string>
 #include <vector>
 
 #include "../../include/pcr_hip.h"
+
+// (library-internal, defined in capi.hip) the stream a handle queues its work on
+hipStream_t pcr_internal_stream(const pcr_handle* h);
 
 namespace {
 
@@ -31,10 +35,8 @@ struct KfDesc {              // one selected key frame in the concatenation
 // One thread per output point.  pto = tr * pfrom in float: ((r0 x + r1 y) + r2 z) + t per row -- Eigen's coefficient-based
 // 3x3 * 3x1 product followed by the translation; compiled without FMA contraction so that the voxel a point falls
 // into is the one the CPU computes.
-__global__ __launch_bounds__(256) void submap_transform_kernel(const float* __restrict__ store, const KfDesc* __restrict__ kf, int n_kf,
-                                                               unsigned int n_total, unsigned int stride, float* __restrict__ out) {
-    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_total) return;
+__device__ inline void submap_transform_point(const float* __restrict__ store, const KfDesc* __restrict__ kf, int n_kf, unsigned int i, unsigned int stride,
+                                              float* __restrict__ out) {
     int lo = 0, hi = n_kf - 1;                    // last key frame whose first_out <= i
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (kf[mid].first_out <= i) lo = mid; else hi = mid - 1; }
     const KfDesc d = kf[lo];
@@ -45,6 +47,22 @@ __global__ __launch_bounds__(256) void submap_transform_kernel(const float* __re
     o[1] = ((d.R[3] * x + d.R[4] * y) + d.R[5] * z) + d.t[1];
     o[2] = ((d.R[6] * x + d.R[7] * y) + d.R[8] * z) + d.t[2];
     for (unsigned int c = 3; c < stride; ++c) o[c] = p[c];          // data[3] = 1 and the intensity travel unchanged
+}
+
+__global__ __launch_bounds__(256) void submap_transform_kernel(const float* __restrict__ store, const KfDesc* __restrict__ kf, int n_kf,
+                                                               unsigned int n_total, unsigned int stride, float* __restrict__ out) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_total) submap_transform_point(store, kf, n_kf, i, stride, out);
+}
+
+// ... the same with the descriptors in the kernel's ARGUMENTS (up to 48 key frames: 3 KB of the 4 KB a launch carries): no copy in front of the launch,
+// no buffer to keep alive behind it
+static constexpr int kPackMax = 48;
+struct KfPack { KfDesc d[kPackMax]; };
+__global__ __launch_bounds__(256) void submap_transform_pack_kernel(const float* __restrict__ store, const KfPack pack, int n_kf,
+                                                                    unsigned int n_total, unsigned int stride, float* __restrict__ out) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_total) submap_transform_point(store, pack.d, n_kf, i, stride, out);
 }
 
 struct Buf {
@@ -69,6 +87,8 @@ struct pcr_map {
     pcr_handle* filter = nullptr;     // device context of the voxel filter
     size_t stride = 0;                // bytes per point, fixed by the first key frame
     Buf store, concat, submap, desc;
+    KfDesc* desc_host = nullptr;      // page-locked staging of the descriptors
+    size_t desc_host_cap = 0;
     size_t store_floats = 0;
     struct Kf { size_t off_floats, n; double pose[16]; };
     std::vector<Kf> kfs;
@@ -102,6 +122,7 @@ void pcr_map_destroy(pcr_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     m->store.release(); m->concat.release(); m->submap.release(); m->desc.release();
+    if (m->desc_host) (void)hipHostFree(m->desc_host);
     pcr_destroy(m->filter);
     delete m;
 }
@@ -154,11 +175,28 @@ static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap) {
     M_TRY(m->concat.reserve(total * m->stride));
     M_TRY(m->submap.reserve(total * m->stride));
     M_TRY(m->desc.reserve(desc.size() * sizeof(KfDesc)));
-    M_TRY(hipMemcpy(m->desc.p, desc.data(), desc.size() * sizeof(KfDesc), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(submap_transform_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, 0, static_cast<const float*>(m->store.p),
+    // the descriptors and the transform pass go onto the FILTER's stream, in front of the filter's own launches: one synchronisation -- the filter's,
+    // for its voxel count -- serves the whole assembly (round 4: a blocking copy, the pass on the null stream, a device-wide synchronisation, then the
+    // filter with two more: 0.49 ms for a 500 k-point concatenation of which a third was waiting; round 5, scripts/seq_breakdown.py)
+    hipStream_t fs = pcr_internal_stream(m->filter);
+    if (desc.size() <= (size_t)kPackMax) {
+        KfPack pack;
+        memcpy(pack.d, desc.data(), desc.size() * sizeof(KfDesc));
+        hipLaunchKernelGGL(submap_transform_pack_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, fs, static_cast<const float*>(m->store.p),
+                           pack, (int)desc.size(), (unsigned int)total, (unsigned int)sf, static_cast<float*>(m->concat.p));
+    } else {
+    if (m->desc_host_cap < desc.size()) {
+        if (m->desc_host) (void)hipHostFree(m->desc_host);
+        m->desc_host = nullptr; m->desc_host_cap = 0;
+        M_TRY(hipHostMalloc((void**)&m->desc_host, (desc.size() + 64) * sizeof(KfDesc), hipHostMallocDefault));
+        m->desc_host_cap = desc.size() + 64;
+    }
+    memcpy(m->desc_host, desc.data(), desc.size() * sizeof(KfDesc));      // (page-locked staging: the copy below does not block; the previous assembly's has completed -- its filter synchronised)
+    M_TRY(hipMemcpyAsync(m->desc.p, m->desc_host, desc.size() * sizeof(KfDesc), hipMemcpyHostToDevice, fs));
+    hipLaunchKernelGGL(submap_transform_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, fs, static_cast<const float*>(m->store.p),
                        static_cast<const KfDesc*>(m->desc.p), (int)desc.size(), (unsigned int)total, (unsigned int)sf, static_cast<float*>(m->concat.p));
+    }
     M_TRY(hipGetLastError());
-    M_TRY(hipDeviceSynchronize());                         // the filter runs on its own (non-blocking) stream
     size_t n_out = 0;
     if (pcr_voxel_filter(m->filter, m->concat.p, total, m->stride, 1, grid_size, m->submap.p, total, 1, &n_out))
         return mfail(m, std::string("voxel filter: ") + pcr_last_error(m->filter));
