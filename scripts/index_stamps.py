@@ -28,6 +28,9 @@ pose = T0.copy(); reg.scan2Map(ds, dm, pose)
 buf = np.zeros(2 * 8192 * 8, np.uint64)
 L.pcr_dev_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
 st = buf.reshape(2, 8192, 8).astype(np.int64)
+b0 = st[1][0]
+if b0[0] > 0 and b0[7] > 0:
+    print(f"tile kernel, block 0 (the planner): counts + tile words in LDS after {(b0[5] - b0[0]) / 100:.1f} us, decided + scanned after {(b0[6] - b0[0]) / 100:.1f} us, layout written after {(b0[7] - b0[0]) / 100:.1f} us")
 for k, name, labels in ((0, "bin", ["start", "keys+lds done", "barrier", "claims back", "chunk loop done", "ticket", "last block done"]), (1, "tile", ["start", "loaded+hist", "scanned", "stored", "end"])):
     a = st[k][1:] if k == 1 else st[k]; used = a[:, 0] > 0; a = a[used][:, :5] if k == 1 else a[used]
     if not len(a): continue

@@ -715,19 +715,25 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
         if (threadIdx.x == 0) { out[kLayMeta] = nb; out[kLayMeta + 1] = ntiles; }
         return;
     }
-    for (uint32_t t = threadIdx.x; t < ntiles; t += kThreads) sub[t] = lay_cur ? (uint16_t)lay_cur[kLaySub + t] : (uint16_t)t;
-    __syncthreads();
+    int deep = 0;      // some tile is cut four times or more
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kThreads) { const uint16_t e = lay_cur ? (uint16_t)lay_cur[kLaySub + t] : (uint16_t)t; sub[t] = e; deep |= (e >> 13) >= 4u ? 1 : 0; }
+    const bool by_bins = __syncthreads_or(deep) != 0;
+    DEV_STAMP(1, 5);
     const int kmax = plan.cuts ? min(kMaxSplit, shift - 2) : 0;      // (no cuts: a layout that holds some -- planned when the cloud was smaller -- is merged back step by step)
-    // a thread's run of tiles: those whose first bin lies in its share of the BINS (the work below is per bin: with equal shares of the tiles the thread
-    // that owned the eight tiles under the vehicle's path, cut into 64 slabs each, walked 512 bins three times over while the others had left -- the
-    // launch took 166 us, round 5; the first bins of the tiles ascend, so a share's first tile is found by bisection)
+    // a thread's run of tiles: an equal share of the tiles -- or, once some tile is cut deep, those whose first bin lies in its share of the BINS (the work
+    // below is per bin: with equal shares of the tiles the thread that owned the eight tiles under the vehicle's path, cut into 64 slabs each, walked 512
+    // bins three times over while the others had left -- the launch took 166 us, round 5; the first bins of the tiles ascend, so a share's first tile is
+    // found by bisection.  Shallow layouts keep the equal shares: this block is the tile pass's longest at 1 M points, and the two bisections -- 22
+    // dependent LDS reads -- made that pass 1.7 us longer)
     auto first_tile = [&](uint32_t i) -> uint32_t {
         const uint32_t want = (uint32_t)(((unsigned long long)i * nb) / kThreads);
         uint32_t lo = 0, hi = ntiles;      // smallest t with first_bin(t) >= want (ntiles: none)
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((sub[mid] & 0x1fffu) < want) lo = mid + 1; else hi = mid; }
         return lo;
     };
-    const uint32_t t0 = first_tile(threadIdx.x), t1 = threadIdx.x + 1 == kThreads ? ntiles : first_tile(threadIdx.x + 1);
+    const uint32_t per = (ntiles + kThreads - 1) / kThreads;
+    const uint32_t t0 = by_bins ? first_tile(threadIdx.x) : min(threadIdx.x * per, ntiles);
+    const uint32_t t1 = by_bins ? (threadIdx.x + 1 == kThreads ? ntiles : first_tile(threadIdx.x + 1)) : min(t0 + per, ntiles);
     // what becomes of tile t: new k in the low bits of the result, its room << 8
     auto decide = [&](uint32_t t, bool may_cut) -> unsigned long long {
         const uint32_t e = sub[t], base = e & 0x1fffu;
@@ -760,6 +766,7 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
         if (threadIdx.x == 0) { out[kLayMeta] = 0u; out[kLayMeta + 1] = 0u; }
         return;
     }
+    DEV_STAMP(1, 6);
     uint32_t nbin = (uint32_t)(off >> 40), pos = (uint32_t)(off & 0xffffffffffull);
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t e = sub[t], base = e & 0x1fffu;
@@ -777,6 +784,7 @@ __device__ void tile_block0(const GridHeader* __restrict__ hdr, int shift, const
         }
     }
     if (threadIdx.x == kThreads - 1) { out[nbin] = pos; out[kLayMeta] = nbin; out[kLayMeta + 1] = ntiles; }      // (the last thread ends at the totals)
+    DEV_STAMP(1, 7);
 }
 
 // The other blocks: a bin each (a tile, or one of the slabs a heavy tile was cut into: see BINS above), bin after bin -- the grid is sized to what the
