@@ -128,7 +128,7 @@ __device__ __forceinline__ void merge_with_partner(uint32_t key[kCovK + 1]) {
 template <int kGroup, int kLpq>
 __global__ __launch_bounds__(256, kLpq) void cov_ring1_kernel(GridView g, uint32_t n_sorted_max, uint32_t* __restrict__ nbr, uint32_t n_cap,
                                                         uint32_t* __restrict__ queue, unsigned long long* __restrict__ queue_seed,
-                                                        uint32_t* __restrict__ queue_count, const RoiView roi) {
+                                                        uint32_t* __restrict__ queue_count, const RoiView roi, uint32_t dense_limit) {
     static_assert(kLpq == 1 || kLpq == 2 || kLpq == 4, "lanes per query");
     constexpr int kShift = kLpq == 4 ? 2 : (kLpq == 2 ? 1 : 0);
     constexpr int kPer = kCovK / kLpq;      // listed candidates each lane of a query looks up again
@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256, kLpq) void cov_ring1_kernel(GridView g, uint32
     const uint32_t max_total = wave_max_uniform(total);
     const uint32_t bits = min(32u - (uint32_t)__clz((int)(max_total | 1u)), (uint32_t)kMaxIdBits);      // wave-uniform: 2^bits > every lane's count, or the cap
     const uint32_t idmask = (1u << bits) - 1u;
-    const bool too_many = total > idmask;
+    // (dense_limit: a query with more candidates in its block than that goes to the queue at once -- a wave per query, lanes = candidates -- and
+    //  its lanes lengthen nobody's walk here: next to the sensor a block holds 886 candidates against 277 on average, and a wave walks as far as its
+    //  longest run)
+    const bool too_many = total > idmask || total > dense_limit;
     uint32_t key[kCovK + 1];      // key[kCovK]: the smallest key that is NOT in the list
 #pragma unroll
     for (int i = 0; i <= kCovK; ++i) key[i] = kKeyEmpty;
@@ -565,7 +568,8 @@ hipError_t cov_search_launch(const GridIndex& grid, const GridIndex* coarse1, co
     const uint32_t qblocks = (uint32_t)((n * (size_t)lpq + 255) / 256);
     // (ev: events stamped at each kernel's own begin and end -- profiling passes)
 #define COV_LAUNCH_A(G, L) hipExtLaunchKernelGGL((cov_ring1_kernel<G, L>), dim3(qblocks), dim3(256), 0, s, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, 0, grid.view(), (uint32_t)n, \
-                                                 sc.nbr.as<uint32_t>(), n_cap, sc.queue.as<uint32_t>(), sc.seed.as<unsigned long long>(), sc.count.as<uint32_t>(), rv)
+                                                 sc.nbr.as<uint32_t>(), n_cap, sc.queue.as<uint32_t>(), sc.seed.as<unsigned long long>(), sc.count.as<uint32_t>(), rv, dense_limit)
+    static const uint32_t dense_limit = dev_env("PCR_COV_DENSE") ? (uint32_t)atoi(dev_env("PCR_COV_DENSE")) : 0xffffffffu;      // (development: candidates in a query's block from which it is queued at once)
     static const int grp = dev_env("PCR_COV_GROUP") ? atoi(dev_env("PCR_COV_GROUP")) : 4;
     if (lpq == 1) COV_LAUNCH_A(8, 1); else if (lpq == 2) { if (grp == 4) COV_LAUNCH_A(4, 2); else COV_LAUNCH_A(8, 2); } else { if (grp == 4) COV_LAUNCH_A(4, 4); else COV_LAUNCH_A(8, 4); }
 #undef COV_LAUNCH_A

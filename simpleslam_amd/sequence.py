@@ -39,7 +39,7 @@ def make_drive(n_scans, seed, map_points=200_000, beams=64, azimuths=1024, step=
 def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap=MIN_KF_GAP):
     """Run the loop; -> dict(poses, converged, iterations, submap_points, keyframes, updates, seconds, scan2map_seconds)."""
     pose = np.array(start_pose, float)
-    kf_pos, last_update = [], None
+    kf_pos, n_kf, last_update = np.zeros((len(scans), 3)), 0, None      # (one array: the nearest key frame by one numpy expression, not a Python loop over them)
     poses, conv, iters, sub_n = [], [], [], []
     updates = 0
     t_s2m = 0.0
@@ -57,16 +57,16 @@ def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap
         t = pose[:3, 3]
         need_update = last_update is None or float(np.linalg.norm(last_update - t)) > kf_gap       # setCurPose
         # putKeyFrame: nearestKSearch's squared distance against minKFGap (MapManager.cpp:141-143)
-        if not kf_pos or min(float(np.sum((q - t) ** 2)) for q in kf_pos) > kf_gap:
+        if n_kf == 0 or float(np.min(np.sum((kf_pos[:n_kf] - t) ** 2, axis=1))) > kf_gap:
             front.add_keyframe(scan, pose)
-            kf_pos.append(t.copy())
+            kf_pos[n_kf] = t; n_kf += 1
         if need_update:
             front.update_map(t, radius, grid)
             last_update = t.copy()
             updates += 1
         poses.append(pose.copy()); sub_n.append(front.submap_points())
     front.finish()
-    return dict(poses=poses, converged=conv, iterations=iters, submap_points=sub_n, keyframes=len(kf_pos), updates=updates,
+    return dict(poses=poses, converged=conv, iterations=iters, submap_points=sub_n, keyframes=n_kf, updates=updates,
                 seconds=time.perf_counter() - t0, scan2map_seconds=t_s2m)
 
 
