@@ -230,6 +230,13 @@ const char* pcr_map_last_error(const pcr_map* m);
 int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_bytes, int on_device, const double pose[16]);
 int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes);
 int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap);
+/* The same in two halves, for a caller that has something else to do meanwhile -- the reference assembles its sub-map on a map thread of its own
+ * (frontend/src/MapManager.cpp:109-119 notifies it and LidarOdometry goes on with the next scan): pcr_map_update_begin selects the key frames, starts a
+ * new generation and QUEUES the assembly on the map's stream; pcr_map_wait collects it (the update's one synchronisation; errors of the assembly are
+ * reported here).  Every call that needs the sub-map (pcr_map_submap, pcr_scan2map_submap) or changes the store (pcr_map_add_keyframe, another update)
+ * collects a queued assembly first, so the result never depends on when the wait happens: pcr_map_update = begin + wait. */
+int pcr_map_update_begin(pcr_map* m, const double position[3], double radius, double grid_size);
+int pcr_map_wait(pcr_map* m, size_t* n_submap);
 /* LoopClosureManager::loopFindNearKeyframes (backend/src/LoopClosureManager.cpp:40-60): key frames key - search_num .. key + search_num
  * (clipped to the store), transformed, concatenated, voxel-filtered: the target of the loop-closure registration (:96-99). */
 int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid_size, size_t* n_submap);

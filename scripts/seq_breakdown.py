@@ -12,7 +12,7 @@ d_scans = [torch.from_numpy(s).cuda() for s in scans]
 class Timed(sequence.GpuFront):
     def __init__(self, reg):
         super().__init__(reg)
-        self.t = {"voxel": 0.0, "scan2map": 0.0, "add_keyframe": 0.0, "update_map": 0.0}
+        self.t = {"voxel": 0.0, "scan2map": 0.0, "add_keyframe": 0.0, "update_map": 0.0, "submap_points": 0.0}
         self.n = {k: 0 for k in self.t}
 
     def _time(self, name, fn, *a):
@@ -23,6 +23,7 @@ class Timed(sequence.GpuFront):
     def scan2map(self, ds, pose): return self._time("scan2map", super().scan2map, ds, pose)
     def add_keyframe(self, scan, pose): return self._time("add_keyframe", super().add_keyframe, scan, pose)
     def update_map(self, p, r, g): return self._time("update_map", super().update_map, p, r, g)
+    def submap_points(self): return self._time("submap_points", super().submap_points)      # (collects a queued assembly)
 
 
 for rep in range(2):

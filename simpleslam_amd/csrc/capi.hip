@@ -128,6 +128,7 @@ struct pcr_handle {
     double* out48_host = nullptr;        // host-mapped: 48 doubles written by ndt_sum_partials_kernel
     double* out48_dev = nullptr;
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
+    struct VfJob { const float* d_pts; size_t n, sf; double leaf; float* d_out; size_t cap; } vf_job = {};      // the filter that is queued (vf_enqueue / vf_settle)
     unsigned long long vf_builds = 0, vf_stale = 0;      // index builds of the voxel filter, and how many found the reused box / layout too small
     char* vf_ret = nullptr;              // page-locked: what the voxel filter's last block reports (VfResult: the voxel count + the index header's verdict)
     DeviceBuf vg_reduced;                // sharded VGICP over the peer exchange: a pass's 32 sums folded over the rows and the ranks
@@ -1974,6 +1975,98 @@ int pcr_invalidate_target(pcr_handle* h) {
     return 0;
 }
 
+}  // extern "C"
+namespace {
+// The voxel filter in two halves: everything queued (vf_enqueue), then the one synchronisation and what its result asks for (vf_settle).
+// pcr_voxel_filter is the two back to back; the sub-map assembly (submap.hip) queues an assembly with the first and collects it with the second when the
+// sub-map is next asked for -- the kernels of an assembly then run beside the next scan's own filter (pcr_map_update_begin).
+int vf_enqueue(pcr_handle* h) {
+    const pcr_handle::VfJob& j = h->vf_job;
+    if (h->vf_grid.build(j.d_pts, j.n, j.sf, j.leaf, h->stream, &h->err, 0.0, 1, nullptr, true) != hipSuccess) return 1;
+    H_TRY(voxel_filter_launch(h->vf_grid, j.d_pts, j.sf, j.n, h->vf_head.as<uint32_t>(), h->vf_sums.as<uint32_t>(), h->vf_count.p, j.d_out, j.cap,
+                              h->vf_ret, h->stream));
+    return 0;
+}
+int vf_begin(pcr_handle* h, const float* d_pts, size_t n, size_t sf, double leaf, float* d_out, size_t cap) {
+    // ONE round trip: the two launches of the filter are queued right behind the index build -- they read the header themselves and do nothing
+    // when it says overflow, stale or empty -- and their last block writes the voxel count and the header's verdict into page-locked memory.
+    // (Round 4 read the header first, then the count: two more synchronisations and an idle device in between, ~35 us of the 0.16 ms a
+    //  65 536-point scan took: round 5, scripts/seq_breakdown.py.)
+    // The index reuses the previous call's box and tile layout when the cloud still fits (GridIndex::hint_ok): the order of the voxels -- idx sorts by
+    // (z, y, x) -- does not depend on where the box starts, so the output is the same either way; a cloud that does not fit comes back `stale` and is
+    // built afresh, from then on with room around the box (a sub-map's box moves with the vehicle) and half as much again per bin.
+    H_TRY(h->vf_head.reserve((n + 4096) * sizeof(uint32_t)));
+    H_TRY(h->vf_sums.reserve((n / 2048 + 2) * sizeof(uint32_t)));
+    H_TRY(h->vf_count.reserve(voxel_filter_wave_bytes(n)));
+    if (!h->vf_ret) H_TRY(hipHostMalloc((void**)&h->vf_ret, sizeof(VfResult) + 64, hipHostMallocDefault));
+    h->vf_grid.no_hints = h->prm.index_no_hints != 0;
+    h->vf_grid.cut_sparse = true; h->vf_grid.coherent_input = true;
+    h->vf_job = pcr_handle::VfJob{d_pts, n, sf, leaf, d_out, cap};
+    return vf_enqueue(h);
+}
+int vf_settle(pcr_handle* h, uint32_t* count, int* too_fine) {
+    volatile VfResult& ret = *reinterpret_cast<VfResult*>(h->vf_ret);
+    const size_t n = h->vf_job.n;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        if (attempt && vf_enqueue(h)) return 1;
+        H_TRY(hipStreamSynchronize(h->stream));
+        ++h->vf_builds;
+        if (dev_env("PCR_VF_DEBUG") && n > 100000) {      // (development builds: the layout this build planned -- bins, tiles, the heaviest bin)
+            std::vector<uint32_t> lay(3 * kMaxBins + 32);
+            (void)hipMemcpy(lay.data(), h->vf_grid.layout[h->vf_grid.lay_idx].p, lay.size() * 4, hipMemcpyDeviceToHost);
+            const uint32_t nb = lay[3 * kMaxBins + 24], nt = lay[3 * kMaxBins + 25];
+            uint32_t room_max = 0, kmax = 0;
+            for (uint32_t b = 0; b < nb && b < (uint32_t)kMaxBins; ++b) { room_max = std::max(room_max, lay[b + 1] - lay[b]); kmax = std::max(kmax, lay[2 * kMaxBins + 16 + b] >> 26); }
+            fprintf(stderr, "voxel filter: n %zu used_hint %d used_layout %d tshift %d stale %d overflow %d | next layout: %u bins over %u tiles, widest room %u, deepest cut %u\n",
+                    n, (int)h->vf_grid.used_hint, (int)h->vf_grid.used_layout, h->vf_grid.tiled_shift, (int)ret.stale, (int)ret.overflow, nb, nt, room_max, kmax);
+        }
+        if (ret.stale) {      // the box (or a bin's room) taken over from the previous call does not hold this cloud
+            ++h->vf_stale;
+            if (dev_env("PCR_VF_DEBUG")) fprintf(stderr, "voxel filter: n %zu leaf %g stale %d (1 box, 2 room, 3 layout)\n", n, h->vf_job.leaf, (int)ret.stale);
+            // (the cell count the tile size goes by is kept once the box has its margin: a build without it takes the dense path -- 23 us instead of 11 for a scan)
+            if (h->vf_grid.hint_margin == 0) { h->vf_grid.hint_margin = 16; h->vf_grid.hint_margin_z_pcl = 4; h->vf_grid.cells_hint = 0; }
+            h->vf_grid.lay_room_shift = 1; h->vf_grid.lay_room_add = 256;
+            continue;
+        }
+        if (!ret.overflow) {
+            *count = ret.count; *too_fine = ret.too_fine;
+            h->vf_grid.note_cells(ret.n_cells);
+            if (!ret.empty && !ret.too_fine) h->vf_grid.confirm();
+            return 0;
+        }
+        if (h->vf_grid.grow_cells(ret.n_cells, &h->err) != hipSuccess) return 1;
+    }
+    return fail(h, "voxel table could not be sized");
+}
+}  // namespace
+// (library-internal, for submap.hip: a filter of device memory into device memory, queued / collected; out_capacity >= n)
+int pcr_internal_vf_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity) {
+    if (!h) return 1;
+    h->err.clear();
+    if (!d_pts || !d_out || n == 0 || n > 0xfffffff0ull || out_capacity < n) return fail(h, "voxel filter: bad arguments");
+    if (!(leaf > 0)) return fail(h, "leaf size must be positive");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    return vf_begin(h, static_cast<const float*>(d_pts), n, stride_bytes / 4, leaf, static_cast<float*>(d_out), out_capacity);
+}
+int pcr_internal_vf_end(pcr_handle* h, size_t* n_out) {
+    if (!h || !n_out) return 1;
+    *n_out = 0;
+    if (set_device(h)) return 1;
+    uint32_t count = 0;
+    int too_fine = 0;
+    if (vf_settle(h, &count, &too_fine)) return 1;
+    if (too_fine) {      // pcl::VoxelGrid: output = input (see pcr_voxel_filter)
+        const pcr_handle::VfJob& j = h->vf_job;
+        H_TRY(hipMemcpyAsync(j.d_out, j.d_pts, j.n * j.sf * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        *n_out = j.n;
+        return 0;
+    }
+    *n_out = count;
+    return 0;
+}
+extern "C" {
+
 int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double leaf, void* out,
                      size_t out_capacity, int out_on_device, size_t* n_out) {
     if (!h) return 1;
@@ -1989,16 +2082,6 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
     const size_t sf = stride_bytes / 4;
     const float* d_pts = static_cast<const float*>(pts);
     if (!on_device && stage_host(h, &h->vf_in, pts, n, stride_bytes, &d_pts, true)) return 1;
-    // ONE round trip: the two launches of the filter are queued right behind the index build -- they read the header themselves and do nothing
-    // when it says overflow, stale or empty -- and their last block writes the voxel count and the header's verdict into page-locked memory.
-    // (Round 4 read the header first, then the count: two more synchronisations and an idle device in between, ~35 us of the 0.16 ms a
-    //  65 536-point scan took: round 5, scripts/seq_breakdown.py.)
-    // The index reuses the previous call's box and tile layout when the cloud still fits (GridIndex::hint_ok): the order of the voxels -- idx sorts by
-    // (z, y, x) -- does not depend on where the box starts, so the output is the same either way; a cloud that does not fit comes back `stale` and is
-    // built afresh, from then on with room around the box (a sub-map's box moves with the vehicle) and half as much again per bin.
-    H_TRY(h->vf_head.reserve((n + 4096) * sizeof(uint32_t)));
-    H_TRY(h->vf_sums.reserve((n / 2048 + 2) * sizeof(uint32_t)));
-    H_TRY(h->vf_count.reserve(voxel_filter_wave_bytes(n)));
     float* d_out = static_cast<float*>(out);
     size_t cap = out_capacity;
     if (!out_on_device) {
@@ -2006,48 +2089,9 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
         H_TRY(h->vf_out.reserve((cap ? cap : 1) * stride_bytes));
         d_out = h->vf_out.as<float>();
     }
-    if (!h->vf_ret) H_TRY(hipHostMalloc((void**)&h->vf_ret, sizeof(VfResult) + 64, hipHostMallocDefault));
-    volatile VfResult& ret = *reinterpret_cast<VfResult*>(h->vf_ret);
-    h->vf_grid.no_hints = h->prm.index_no_hints != 0;
-    h->vf_grid.cut_sparse = true; h->vf_grid.coherent_input = true;
-    bool settled = false;
     uint32_t count = 0;
     int too_fine = 0;
-    for (int attempt = 0; attempt < 6 && !settled; ++attempt) {
-        if (h->vf_grid.build(d_pts, n, sf, leaf, h->stream, &h->err, 0.0, 1, nullptr, true) != hipSuccess) return 1;
-        H_TRY(voxel_filter_launch(h->vf_grid, d_pts, sf, n, h->vf_head.as<uint32_t>(), h->vf_sums.as<uint32_t>(), h->vf_count.p, d_out, cap,
-                                  h->vf_ret, h->stream));
-        H_TRY(hipStreamSynchronize(h->stream));
-        ++h->vf_builds;
-        if (dev_env("PCR_VF_DEBUG") && n > 100000) {      // (development builds: the layout this build planned -- bins, tiles, the heaviest bin)
-            std::vector<uint32_t> lay(3 * kMaxBins + 32);
-            (void)hipMemcpy(lay.data(), h->vf_grid.layout[h->vf_grid.lay_idx].p, lay.size() * 4, hipMemcpyDeviceToHost);
-            std::vector<uint32_t> bs(kMaxBins + 8);
-            (void)hipMemcpy(bs.data(), h->vf_grid.bin_start.p, bs.size() * 4, hipMemcpyDeviceToHost);
-            const uint32_t nb = lay[3 * kMaxBins + 24], nt = lay[3 * kMaxBins + 25];
-            uint32_t room_max = 0, kmax = 0;
-            for (uint32_t b = 0; b < nb && b < (uint32_t)kMaxBins; ++b) { room_max = std::max(room_max, lay[b + 1] - lay[b]); kmax = std::max(kmax, lay[2 * kMaxBins + 16 + b] >> 26); }
-            uint32_t held_max = 0;
-            const uint32_t nb_used = h->vf_grid.used_layout ? h->vf_grid.lay_nb_max : 0;
-            for (uint32_t b = 0; b + 1 < bs.size(); ++b) if (bs[b + 1] >= bs[b]) held_max = std::max(held_max, bs[b + 1] - bs[b]);
-            fprintf(stderr, "voxel filter: n %zu used_hint %d used_layout %d tshift %d stale %d overflow %d | next layout: %u bins over %u tiles, widest room %u, deepest cut %u | this build's fullest bin %u (nb_max %u)\n",
-                    n, (int)h->vf_grid.used_hint, (int)h->vf_grid.used_layout, h->vf_grid.tiled_shift, (int)ret.stale, (int)ret.overflow, nb, nt, room_max, kmax, held_max, nb_used);
-        }
-        if (ret.stale) {      // the box (or a bin's room) taken over from the previous call does not hold this cloud
-            ++h->vf_stale;
-            if (dev_env("PCR_VF_DEBUG")) fprintf(stderr, "voxel filter: n %zu leaf %g stale %d (1 box, 2 room, 3 layout)\n", n, leaf, (int)ret.stale);
-            // (the cell count the tile size goes by is kept once the box has its margin: a build without it takes the dense path -- 23 us instead of 11 for a scan)
-            if (h->vf_grid.hint_margin == 0) { h->vf_grid.hint_margin = 16; h->vf_grid.hint_margin_z_pcl = 4; h->vf_grid.cells_hint = 0; }
-            h->vf_grid.lay_room_shift = 1; h->vf_grid.lay_room_add = 256;
-            continue;
-        }
-        if (!ret.overflow) {
-            settled = true; count = ret.count; too_fine = ret.too_fine;
-            h->vf_grid.note_cells(ret.n_cells);
-            if (!ret.empty && !ret.too_fine) h->vf_grid.confirm();
-        } else if (h->vf_grid.grow_cells(ret.n_cells, &h->err) != hipSuccess) return 1;
-    }
-    if (!settled) return fail(h, "voxel table could not be sized");
+    if (vf_begin(h, d_pts, n, sf, leaf, d_out, cap) || vf_settle(h, &count, &too_fine)) return 1;
     if (too_fine) {
         // pcl::VoxelGrid: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
         *n_out = n;

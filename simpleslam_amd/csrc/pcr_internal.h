@@ -432,3 +432,6 @@ uint32_t loam_grid_blocks(uint32_t n_src);
 // voxel filter it runs through a handle, on that handle's stream, so that one synchronisation serves both
 struct pcr_handle;
 hipStream_t pcr_internal_stream(const pcr_handle* h);
+// ... and the voxel filter in two halves, device memory into device memory (out_capacity >= n): queue it; synchronise and collect it (redone there if the index's hints did not hold)
+int pcr_internal_vf_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity);
+int pcr_internal_vf_end(pcr_handle* h, size_t* n_out);

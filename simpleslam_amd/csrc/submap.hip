@@ -20,8 +20,10 @@
 
 #include "../../include/pcr_hip.h"
 
-// (library-internal, defined in capi.hip) the stream a handle queues its work on
+// (library-internal, defined in capi.hip) the stream a handle queues its work on; the voxel filter in two halves (queue; synchronise and collect)
 hipStream_t pcr_internal_stream(const pcr_handle* h);
+int pcr_internal_vf_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity);
+int pcr_internal_vf_end(pcr_handle* h, size_t* n_out);
 
 namespace {
 
@@ -94,6 +96,7 @@ struct pcr_map {
     std::vector<Kf> kfs;
     std::vector<long long> selected;  // mSubmapIdx
     size_t n_submap = 0;
+    bool pending = false;             // an assembly is queued on the filter's stream and has not been collected (pcr_map_update_begin): n_submap is not known yet
     uint64_t id = 0, generation = 0;  // identity of this store and of the sub-map it currently holds (every update is a new generation)
     std::string err;
 };
@@ -101,6 +104,18 @@ struct pcr_map {
 static thread_local std::string g_map_err;
 static int mfail(pcr_map* m, const std::string& s) { if (m) m->err = s; else g_map_err = s; return 1; }
 #define M_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return mfail(m, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+// collect the queued assembly, if any: the one synchronisation of an update (and the filter's second try when the index's hints did not hold)
+static int finish_pending(pcr_map* m) {
+    if (!m->pending) return 0;
+    m->pending = false;
+    m->n_submap = 0;
+    M_TRY(hipSetDevice(m->device));
+    size_t n_out = 0;
+    if (pcr_internal_vf_end(m->filter, &n_out)) return mfail(m, std::string("voxel filter: ") + pcr_last_error(m->filter));
+    m->n_submap = n_out;
+    return 0;
+}
 
 extern "C" {
 
@@ -121,9 +136,9 @@ pcr_map* pcr_map_create(int device) {
 void pcr_map_destroy(pcr_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    pcr_destroy(m->filter);           // (first: it waits for whatever is still queued on its stream -- an assembly nobody collected reads the buffers below)
     m->store.release(); m->concat.release(); m->submap.release(); m->desc.release();
     if (m->desc_host) (void)hipHostFree(m->desc_host);
-    pcr_destroy(m->filter);
     delete m;
 }
 
@@ -138,6 +153,7 @@ int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_by
     if (m->stride == 0) m->stride = stride_bytes;
     else if (m->stride != stride_bytes) return mfail(m, "all key frames of a map must share one point layout");
     M_TRY(hipSetDevice(m->device));
+    if (finish_pending(m)) return 1;      // (a queued assembly reads the store, which may move below)
     const size_t nf = n * (stride_bytes / 4);
     M_TRY(m->store.reserve((m->store_floats + nf + 4) * sizeof(float)));
     if (nf && on_device) {      // on the filter's stream, waited for: the caller may reuse its buffer when this returns (the blocking copy on the null stream took 60 us for 1 MB, round 5)
@@ -160,7 +176,7 @@ int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes) {
 }
 
 // transform + concatenate the selected key frames (m->selected, ascending) and voxel-filter the result into m->submap
-static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap) {
+static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap, bool wait = true) {
     std::vector<KfDesc> desc;
     size_t total = 0;
     for (long long i : m->selected) {
@@ -200,20 +216,22 @@ static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap) {
                        static_cast<const KfDesc*>(m->desc.p), (int)desc.size(), (unsigned int)total, (unsigned int)sf, static_cast<float*>(m->concat.p));
     }
     M_TRY(hipGetLastError());
-    size_t n_out = 0;
-    if (pcr_voxel_filter(m->filter, m->concat.p, total, m->stride, 1, grid_size, m->submap.p, total, 1, &n_out))
+    if (pcr_internal_vf_begin(m->filter, m->concat.p, total, m->stride, grid_size, m->submap.p, total))
         return mfail(m, std::string("voxel filter: ") + pcr_last_error(m->filter));
-    m->n_submap = n_out;
-    if (n_submap) *n_submap = n_out;
+    m->pending = true;
+    if (!wait) return 0;
+    if (finish_pending(m)) return 1;
+    if (n_submap) *n_submap = m->n_submap;
     return 0;
 }
 
-int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap) {
+static int update_by_radius(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap, bool wait) {
     if (!m) return 1;
     m->err.clear();
     if (!position) return mfail(m, "NULL position");
     if (!(grid_size > 0)) return mfail(m, "grid_size must be positive");
     M_TRY(hipSetDevice(m->device));
+    (void)finish_pending(m); m->err.clear();      // (an assembly nobody collected: waited for -- its buffers are about to be written again -- and superseded, whatever became of it)
     m->selected.clear();
     m->n_submap = 0;
     m->generation += 1;           // whatever happens below, the previous sub-map is gone
@@ -226,7 +244,24 @@ int pcr_map_update(pcr_map* m, const double position[3], double radius, double g
         for (int c = 0; c < 3; ++c) { const double e = position[c] - m->kfs[i].pose[12 + c]; d += e * e; }
         if (d < r2) m->selected.push_back((long long)i);
     }
-    return assemble_selected(m, grid_size, n_submap);
+    return assemble_selected(m, grid_size, n_submap, wait);
+}
+
+int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap) {
+    return update_by_radius(m, position, radius, grid_size, n_submap, true);
+}
+
+int pcr_map_update_begin(pcr_map* m, const double position[3], double radius, double grid_size) {
+    return update_by_radius(m, position, radius, grid_size, nullptr, false);
+}
+
+int pcr_map_wait(pcr_map* m, size_t* n_submap) {
+    if (!m) return 1;
+    if (n_submap) *n_submap = 0;
+    if (m->pending) m->err.clear();
+    if (finish_pending(m)) return 1;
+    if (n_submap) *n_submap = m->n_submap;
+    return 0;
 }
 
 int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid_size, size_t* n_submap) {
@@ -235,6 +270,7 @@ int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid
     if (!(grid_size > 0)) return mfail(m, "grid_size must be positive");
     if (search_num < 0) return mfail(m, "search_num must not be negative");
     M_TRY(hipSetDevice(m->device));
+    (void)finish_pending(m); m->err.clear();
     m->selected.clear();
     m->n_submap = 0;
     m->generation += 1;           // whatever happens below, the previous sub-map is gone
@@ -249,6 +285,7 @@ int pcr_map_update_window(pcr_map* m, long long key, int search_num, double grid
 
 const void* pcr_map_submap(const pcr_map* m, size_t* n, size_t* stride_bytes) {
     if (!m) return nullptr;
+    if (m->pending && finish_pending(const_cast<pcr_map*>(m))) { if (n) *n = 0; if (stride_bytes) *stride_bytes = m->stride; return nullptr; }      // (the queued assembly is collected by whoever asks for the sub-map first; its error is pcr_map_last_error's)
     if (n) *n = m->n_submap;
     if (stride_bytes) *stride_bytes = m->stride;
     return m->n_submap ? m->submap.p : nullptr;

@@ -12,7 +12,9 @@ One pass of the reference's front end in "lo" mode, reduced to what touches the 
 `drive()` runs that loop over any front that offers the four steps -- `GpuFront` here (the C ABI: pcr_voxel_filter,
 pcr_scan2map_submap, pcr_map_*), the CPU oracle's in oracle/ (tests and bench.py only).  The reference notifies a map thread and goes on;
 here the assembly happens at the end of the step that asked for it, key frame of that step included: deterministic, and the same on
-both fronts."""
+both fronts.  `GpuFront` queues the assembly (pcr_map_update_begin) and collects it when the sub-map is next needed -- after the next scan's voxel
+filter, whose kernels the assembly's then run beside, as the reference's map thread works beside its front end; the registration that follows always
+sees the finished sub-map, so the poses do not depend on it."""
 import time
 
 import numpy as np
@@ -47,7 +49,9 @@ def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap
     for k, scan in enumerate(scans):
         ds = front.voxel(scan, grid)
         pose = pose @ cmds[k]
-        if front.submap_points() > 0:
+        n_sub = front.submap_points()          # (collects an assembly the previous step queued)
+        if k: sub_n.append(n_sub)              # sub-map after step k - 1 = the one scan k is registered against
+        if n_sub > 0:
             t1 = time.perf_counter()
             c, it = front.scan2map(ds, pose)          # refines `pose` in place
             t_s2m += time.perf_counter() - t1
@@ -64,7 +68,8 @@ def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap
             front.update_map(t, radius, grid)
             last_update = t.copy()
             updates += 1
-        poses.append(pose.copy()); sub_n.append(front.submap_points())
+        poses.append(pose.copy())
+    sub_n.append(front.submap_points())
     front.finish()
     return dict(poses=poses, converged=conv, iterations=iters, submap_points=sub_n, keyframes=n_kf, updates=updates,
                 seconds=time.perf_counter() - t0, scan2map_seconds=t_s2m)
@@ -97,11 +102,16 @@ class GpuFront:
         self.map.addKeyFrame(scan, pose)
 
     def update_map(self, position, radius, grid):
-        self._n = self.map.updateMap(position, radius, grid)
         if self.calls is not None:
+            self._n = self.map.updateMap(position, radius, grid)
             self._sub_host = self.map.download()
+        else:
+            self.map.updateMapBegin(position, radius, grid)      # queued: collected by submap_points() / scan2map of the next step
+            self._n = None
 
     def submap_points(self):
+        if self._n is None:
+            self._n = self.map.wait()
         return self._n
 
     def finish(self):

@@ -187,3 +187,40 @@ def test_target_structures_live_as_long_as_the_submap_generation(gpu, keyframes,
     assert sm2.generation()[1] == sm.generation()[1] and sm2.generation()[0] != sm.generation()[0]
     p2 = init.copy(); reg.scan2MapSubmap(ds, sm2, p2)
     assert builds() == 4
+
+
+def test_an_update_in_two_halves_is_the_update(gpu, keyframes):
+    """pcr_map_update_begin queues the assembly, pcr_map_wait -- or whoever needs the sub-map first -- collects it: same key frames, same sub-map bit
+    for bit, same generation count as pcr_map_update, whatever happens in between (a voxel filter on another handle, a key frame added, another
+    update that supersedes it)."""
+    world, kfs = keyframes
+    whole, halves = SubMap(), SubMap()
+    for c, T in kfs[:10]:
+        whole.addKeyFrame(c, T); halves.addKeyFrame(c, T)
+    reg = LoamRegister()
+    scan, _ = synth.make_scan(world, 3, seed=91, beams=32, azimuths=512)
+    for step, (center, radius) in enumerate(((kfs[3][1][:3, 3], 8.0), (kfs[8][1][:3, 3], 3.0), (kfs[0][1][:3, 3] + 100.0, 8.0), (kfs[5][1][:3, 3], 6.0))):
+        n = whole.updateMap(center, radius=radius, grid_size=0.4)
+        halves.updateMapBegin(center, radius=radius, grid_size=0.4)
+        reg.voxelDownSample(scan, 0.4)                                       # other work, on another handle's stream
+        if step % 2 == 0:
+            assert halves.wait() == n                                        # collected explicitly ...
+        np.testing.assert_array_equal(halves.submapIdx(), whole.submapIdx())
+        assert halves.pointer()[1] == n                                      # ... or by asking for the sub-map
+        assert halves.generation()[1] == whole.generation()[1]
+        if n:
+            np.testing.assert_array_equal(halves.download(), whole.download())
+        assert halves.wait() == n                                            # nothing queued any more: the same count again
+    # a key frame added, or another update begun, while an assembly is queued: the queued one is collected (or superseded) first
+    halves.updateMapBegin(kfs[3][1][:3, 3], radius=8.0, grid_size=0.4)
+    halves.addKeyFrame(*kfs[10]); whole.addKeyFrame(*kfs[10])
+    halves.updateMapBegin(kfs[9][1][:3, 3], radius=8.0, grid_size=0.4)
+    halves.updateMapBegin(kfs[10][1][:3, 3], radius=8.0, grid_size=0.4)
+    n = whole.updateMap(kfs[10][1][:3, 3], radius=8.0, grid_size=0.4)
+    pose_a, pose_b = kfs[10][1].copy(), kfs[10][1].copy()
+    ca = reg.scan2MapSubmap(scan, halves, pose_a)                            # the registration collects it
+    reg2 = LoamRegister()
+    cb = reg2.scan2MapSubmap(scan, whole, pose_b)
+    assert halves.wait() == n and ca == cb
+    np.testing.assert_array_equal(pose_a, pose_b)
+    np.testing.assert_array_equal(halves.download(), whole.download())
