@@ -131,6 +131,15 @@ public:
         if (pcr_map_update(m_, position, radius, grid_size, &n)) throw std::runtime_error(pcr_map_last_error(m_));
         return n;
     }
+    // ... in two halves (MapManager's own thread as a stream, MapManager.cpp:109-119): queue the assembly; wait() -- or the next registration against this map -- collects it
+    void updateMapBegin(const double position[3], double radius = 8.0, double grid_size = 0.4) {
+        if (pcr_map_update_begin(m_, position, radius, grid_size)) throw std::runtime_error(pcr_map_last_error(m_));
+    }
+    size_t wait() {
+        size_t n = 0;
+        if (pcr_map_wait(m_, &n)) throw std::runtime_error(pcr_map_last_error(m_));
+        return n;
+    }
     std::vector<int64_t> submapIdx() const {                                    // mSubmapIdx
         size_t n = 0;
         pcr_map_submap_indices(m_, nullptr, 0, &n);
