@@ -497,7 +497,23 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
         if (per_kernel) {
             while ((int)h->ev_kernel.size() < 2 * iters) { hipEvent_t e; H_TRY(hipEventCreate(&e)); h->ev_kernel.push_back(e); }
         }
+        // Early exit (the reference's default: LoamRegister.cpp:198-220 leaves the loop once a step is small): the device ends the loop in a launch's
+        // prologue and the launches behind it leave at once -- but each still costs ~5 us of the stream, and the caller's loop converges after two
+        // iterations of eight (extra.sequence).  So with early exit on, the host stays TWO launches ahead of the prologue's progress word (host-mapped)
+        // instead of queueing all of them: a loop that ends after launch 2 costs four launches, not eight.  Without early exit (BASELINE's ten fixed
+        // iterations), sharded, or timed per kernel: everything is queued at once, as before.
+        const bool paced = a.c.early_exit != 0 && !shard && !per_kernel && iters > 3;
+        volatile int32_t* const progress = &h->result_host->progress;
+        *progress = -1;
+        int launched = 0;
         for (int k = 0; k < iters; ++k) {
+            if (paced && k >= 3) {
+                const int32_t want = (int32_t)(k - 2) << 1;
+                int32_t v = *progress;
+                for (int spin = 0; spin < 400000 && v < want; ++spin) { __builtin_ia32_pause(); v = *progress; }      // (bounded: a stalled device gets the launch anyway)
+                if (v >= 0 && (v & 1)) break;
+            }
+            ++launched;
             if (per_kernel) H_TRY(loam_launch_iteration(a, k, h->stream, h->ev_kernel[2 * k], h->ev_kernel[2 * k + 1]));
             else H_TRY(loam_launch_iteration(a, k, h->stream, nullptr, nullptr, !shard));
             if (h->host_ar) {
@@ -515,7 +531,7 @@ int run_loam(pcr_handle* h, const float* d_src, size_t n_src, size_t stride_floa
                 if (rc != 0) return fail(h, "ncclAllReduce failed with code " + std::to_string(rc));
             }
         }
-        H_TRY(loam_launch_finalize(a, iters, h->stream));
+        H_TRY(loam_launch_finalize(a, launched, h->stream));
         if (h->profile >= 1) H_TRY(hipEventRecord(h->ev_end, h->stream));
         // The result arrives in host-mapped memory, its completion word written last with a system-scope release: a short
         // spin on that word returns a few microseconds before the stream's completion signal wakes a sleeping thread

@@ -933,7 +933,7 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
     // partial-sum loads below the branch, i.e. two dependent round trips instead of one)
     if (prev_done) {
         if (t == 0) sh->done = 1;
-        if (blockIdx.x == 0 && t == 0) { *cur = *prev; }
+        if (blockIdx.x == 0 && t == 0) { *cur = *prev; __hip_atomic_store(&a.result->progress, (k << 1) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         __syncthreads();
         return true;
     }
@@ -1027,6 +1027,8 @@ __device__ bool loam_prologue(const LoamArgs& a, int k, double* sh_sum /* 8*32 *
         if (blockIdx.x == 0) {
             for (int i = 0; i < 16; ++i) cur->pose[i] = pose[i];
             cur->done = done; cur->converged = conv; cur->fail = fail; cur->iters_run = k;
+            // (the host may be queueing launches only a few ahead of this word: run_loam)
+            __hip_atomic_store(&a.result->progress, (k << 1) | (done ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (a.trace) {
                 LoamTrace* tr = &a.trace[k - 1];
                 for (int i = 0; i < 36; ++i) tr->JtJ[i] = JtJ[i];
@@ -1193,7 +1195,7 @@ __global__ __launch_bounds__(256) void loam_finalize_kernel(const LoamArgs a, co
         for (int i = 0; i < 16; ++i) r->pose[i] = T[i];
         r->converged = cur->converged; r->iters_run = cur->iters_run; r->fail = cur->fail;
         r->grid_overflow = a.grid.hdr->overflow; r->grid_empty = a.grid.hdr->empty; r->grid_cells = a.grid.hdr->n_cells;
-        r->grid_stale = a.grid.hdr->stale; r->pad2 = 0;
+        r->grid_stale = a.grid.hdr->stale;
         // completion marker: the host polls this word of host-mapped memory, so everything above has to be visible first
         __threadfence_system();
         __hip_atomic_store(&r->pad, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

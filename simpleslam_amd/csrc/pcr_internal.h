@@ -108,7 +108,8 @@ struct LoamResult {          // written by the finalize launch into host-mapped 
     double pose[16];         // after T2SE3
     int32_t converged, iters_run, fail, grid_overflow, grid_empty, pad;
     uint64_t grid_cells;     // cells the target needs (to grow the table on overflow)
-    int32_t grid_stale, pad2;
+    int32_t grid_stale;
+    int32_t progress;        // (launch whose prologue has run) << 1 | the loop has ended: written by every launch's prologue, read by a host that queues launches a few ahead (run_loam, early exit)
 };
 
 struct LoamTrace {           // per consumed linearisation
