@@ -39,6 +39,15 @@ for m in ("vgicp", "ndt"):
             for r in rows:
                 o.write(",".join([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
 
+f = newest("stats_sequence/**/*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(dst, f"{tag}_sequence_kernel_stats.csv"), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 scripts/seq_breakdown.py loam   (two drives of 64 scans: the caller's loop of extra.sequence, LOAM)\n")
+        o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            o.write(",".join([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+
 
 def means(pattern):
     f = newest(pattern)

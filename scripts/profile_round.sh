@@ -24,4 +24,6 @@ for m in vgicp ndt; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$m -- python3 $MARGS > $OUT/pmc_write_$m.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_$m -- python3 $MARGS > $OUT/pmc_sq_$m.log 2>&1
 done
+# the caller's loop (extra.sequence): kernel statistics of one LOAM drive (voxel filter, sub-map assembly, target builds, iterations)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sequence -- python3 $R/scripts/seq_breakdown.py loam > $OUT/stats_sequence.log 2>&1
 echo done
