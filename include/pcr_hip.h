@@ -234,7 +234,8 @@ int pcr_map_update(pcr_map* m, const double position[3], double radius, double g
  * (frontend/src/MapManager.cpp:109-119 notifies it and LidarOdometry goes on with the next scan): pcr_map_update_begin selects the key frames, starts a
  * new generation and QUEUES the assembly on the map's stream; pcr_map_wait collects it (the update's one synchronisation; errors of the assembly are
  * reported here).  Every call that needs the sub-map (pcr_map_submap, pcr_scan2map_submap) or changes the store (pcr_map_add_keyframe, another update)
- * collects a queued assembly first, so the result never depends on when the wait happens: pcr_map_update = begin + wait. */
+ * collects a queued assembly first, so the result never depends on when the wait happens: pcr_map_update = begin + wait.
+ * (A pcr_map, like a pcr_handle, is used by one thread at a time: the overlap is between the device's streams, not between host threads.) */
 int pcr_map_update_begin(pcr_map* m, const double position[3], double radius, double grid_size);
 int pcr_map_wait(pcr_map* m, size_t* n_submap);
 /* LoopClosureManager::loopFindNearKeyframes (backend/src/LoopClosureManager.cpp:40-60): key frames key - search_num .. key + search_num
