@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void grid_bbox_header_kernel(const float* __re
     }
 }
 
-__device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key, bool* outside = nullptr) {
+// (cxyz: the cell's coordinates in the lattice as well, for a caller that looks the cell up in a region mask)
+__device__ inline bool point_key(const GridHeader& h, float x, float y, float z, uint32_t* key, bool* outside = nullptr, uint32_t* cxyz = nullptr) {
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) return false;
     if (h.pcl_mode) {
         // ijk = static_cast<int>(std::floor(p * inverse_leaf_size) - static_cast<float>(min_b))   (voxel_grid.hpp)
@@ -170,6 +171,7 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
             return false;
         }
         *key = ((uint32_t)iz * (uint32_t)h.dims[1] + (uint32_t)iy) * (uint32_t)h.dims[0] + (uint32_t)ix;
+        if (cxyz) { cxyz[0] = (uint32_t)ix; cxyz[1] = (uint32_t)iy; cxyz[2] = (uint32_t)iz; }
         return true;
     }
     // cell index = floor(x / cell) - org.  For a power-of-two cell (LOAM) x / cell is exact and this
@@ -194,6 +196,7 @@ __device__ inline bool point_key(const GridHeader& h, float x, float y, float z,
     }
     const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
     *key = (cz * (uint32_t)h.dims[1] + cy) * (uint32_t)h.dims[0] + cx;
+    if (cxyz) { cxyz[0] = cx; cxyz[1] = cy; cxyz[2] = cz; }
     return true;
 }
 
@@ -431,12 +434,16 @@ __device__ __forceinline__ void load_xyz(const float* __restrict__ pts, size_t i
 // checked against the room and the buffer), and the caller rebuilds without hints (the same protocol as the bounding-box hint that this path
 // requires anyway).  kSub: the layout may hold tiles that are cut (see BINS): a point's bin comes from its tile's word; without it bin = tile, the
 // kernel of round 4 (the words cost the 10 M-point map's bin pass its third block per CU, and clouds of that size are never cut).
-template <bool kVec, int kBinPer, bool kPlace, bool kSub>
-__global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
+// kPacked (region-only builds, see grid_keep_kernel below): `pts` is the list that pass left -- float4 (x, y, z, original index), *n_packed of them, all
+// inside the box and the region -- so this pass pays its chunk protocol (four barriers and a returning claim per 2 048 points) for the points that are
+// kept only.
+template <bool kVec, int kBinPer, bool kPlace, bool kSub, bool kPacked = false>
+__global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ pts, uint32_t n_in, uint32_t stride, GridHeader* __restrict__ hdr,
                                                        uint32_t* __restrict__ bin_count, uint32_t* __restrict__ slot, int shift, uint32_t max_tiles, uint32_t nb_max,
                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ bin_start,
                                                        const uint32_t* __restrict__ lay_cur, float4* __restrict__ tiled, uint32_t tiled_cap,
-                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift) {
+                                                       const uint8_t* __restrict__ keep_mask, int keep_mshift, uint32_t* __restrict__ n_packed = nullptr) {
+    static_assert(!kPacked || (kVec && kPlace), "a packed list is float4 and is placed by a layout");
     // keep_mask (kPlace only; pcr_internal.h: BuildFilter): points in cells whose macro cell is not marked are left out of the index, as
     // non-finite points are; the layout is handed on unchanged (its rooms are the full cloud's)
     static_assert(kPlace || !kSub, "tiles are cut by a layout only");
@@ -451,8 +458,10 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
     const uint32_t c_first = blockIdx.x * kBinChunk;
     uint32_t nb_lay = 0, nt_lay = 0;
     if (kPlace) { nb_lay = lay_cur[kLayMeta]; nt_lay = lay_cur[kLayMeta + 1]; }      // (requested beside the header)
+    uint32_t n = n_in;
+    if (kPacked) n = min(*n_packed, n_in);
     const GridHeader h = *hdr;
-    if (h.overflow || h.empty) return;
+    if (h.overflow || h.empty) { if (kPacked && blockIdx.x == 0 && threadIdx.x == 0) *n_packed = 0u; return; }      // (the counter is left at zero: the state the next build's keep pass expects)
     const uint32_t ntiles = (uint32_t)(h.n_cells >> shift) + 1u;
     const uint32_t nb = kPlace ? nb_lay : ntiles;
     if (kPlace) {
@@ -468,10 +477,12 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         uint32_t bin[kBinPer], loc[kBinPer];
         bool first[kBinPer];
         float px[kBinPer], py[kBinPer], pz[kBinPer];
+        uint32_t pw[kPacked ? kBinPer : 1];      // kPacked: the original index the point carries
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) {      // all loads of the chunk in flight
             const uint32_t i = c0 + u * 256 + threadIdx.x;
-            load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
+            if (kPacked) { const float4 v = reinterpret_cast<const float4*>(pts)[i < n ? i : c0]; px[u] = v.x; py[u] = v.y; pz[u] = v.z; pw[u] = __float_as_uint(v.w); }
+            else load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
         }
 #pragma unroll
         for (int u = 0; u < kBinPer; ++u) {
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
                 const uint32_t i = c0 + u * 256 + threadIdx.x;
                 if (i < n && bin[u] != 0xffffffffu) {
                     const uint32_t r = hist[bin[u]] + loc[u], lo = sh_lay[bin[u]], room = sh_lay[bin[u] + 1u] - lo;
-                    if (r < room && lo + r < tiled_cap) tiled[lo + r] = make_float4(px[u], py[u], pz[u], __uint_as_float(i));
+                    if (r < room && lo + r < tiled_cap) tiled[lo + r] = make_float4(px[u], py[u], pz[u], __uint_as_float(kPacked ? pw[u] : i));
                     else over = true;
                 }
             }
@@ -583,7 +594,60 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
         if (j < per && b0 + j < nb) { bin_start[b0 + j] = off; off += c[j]; }
     if (threadIdx.x == 255) bin_start[nb] = total;
     if (threadIdx.x == 0) *ticket = 0u;                        // ready for the next build
+    if (kPacked && threadIdx.x == 0) *n_packed = 0u;           // (every block has read it: they all took the ticket after their loops)
     DEV_STAMP(0, 6);
+}
+
+// ---- region-only builds: the points of the region, listed ----
+// A build that indexes a scan's region only (BuildFilter: NDT's 5 M-point map, VGICP's lattice) drops nine points in ten -- and the bin pass charged every
+// chunk of 2 048 points its whole protocol all the same: 60 us for the 5 M-point map, 80 MB read at 1.3 TB/s (chunk sizes of 1 024 and 4 096: slower).
+// This pass only streams: eight points per thread, cell, mask byte, a block scan of the kept counts, ONE global claim per block and chunk, the kept points
+// stored as (x, y, z, original index).  The bin pass then reads that list (grid_bin_kernel<.., kPacked>).  A point outside the reused box raises
+// header.stale here, as the bin pass did.  The order of the list is the order the claims arrive in -- as the order of a bin's points already was.
+template <bool kVec>
+__global__ __launch_bounds__(256) void grid_keep_kernel(const float* __restrict__ pts, uint32_t n, uint32_t stride, GridHeader* __restrict__ hdr,
+                                                        const uint8_t* __restrict__ mask, int mshift, float4* __restrict__ out, uint32_t out_cap,
+                                                        uint32_t* __restrict__ counter) {
+    __shared__ uint32_t sh4[4];
+    __shared__ uint32_t sh_base;
+    constexpr int kPer = 8;
+    const GridHeader h = *hdr;
+    if (h.overflow || h.empty) return;
+    for (uint32_t c0 = blockIdx.x * (256u * kPer); c0 < n; c0 += gridDim.x * (256u * kPer)) {
+        float px[kPer], py[kPer], pz[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            load_xyz<kVec>(pts, i < n ? i : c0, stride, px[u], py[u], pz[u]);
+        }
+        uint32_t mi[kPer];      // the mask byte of the point's cell, or none
+        bool outside = false;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t i = c0 + u * 256 + threadIdx.x;
+            uint32_t key, cc[3];
+            bool out_u = false;
+            mi[u] = 0xffffffffu;
+            if (i < n && point_key(h, px[u], py[u], pz[u], &key, &out_u, cc)) mi[u] = roi_macro(h, mshift, (int)cc[0], (int)cc[1], (int)cc[2]);
+            outside = outside || (i < n && out_u);
+        }
+        if (outside && !h.clamped) hdr->stale = 1;      // (only a box reused from the previous build can be too small)
+        uint8_t mb[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) mb[u] = mask[mi[u] != 0xffffffffu ? mi[u] : 0u];      // (unconditional loads: all in flight)
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) { mb[u] = (mi[u] != 0xffffffffu && mb[u] != 0) ? 1 : 0; mine += mb[u]; }
+        uint32_t total;
+        uint32_t off = block_exclusive_scan_256(mine, &total, sh4);
+        if (threadIdx.x == 0) sh_base = total ? atomicAdd(counter, total) : 0u;
+        __syncthreads();
+        off += sh_base;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u)
+            if (mb[u]) { if (off < out_cap) out[off] = make_float4(px[u], py[u], pz[u], __uint_as_float(c0 + u * 256 + threadIdx.x)); ++off; }
+        __syncthreads();      // sh_base and sh4 are written again in the next chunk
+    }
 }
 
 template <bool kVec>
@@ -1165,7 +1229,7 @@ void DeviceBuf::release() {
 void GridIndex::release() {
     sorted.release(); cell_count.release(); cell_start.release(); block_sums.release();
     bbox_partials.release(); header.release(); keys.release(); ranks.release(); ticket.release();
-    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); layout[0].release(); layout[1].release(); lay_ok = false;
+    tiled.release(); bin_count.release(); bin_start.release(); tile_sq.release(); kept.release(); layout[0].release(); layout[1].release(); lay_ok = false;
     cell_capacity = 0; valid = false; n_points = 0;
 }
 
@@ -1352,7 +1416,25 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
                                                     bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, nb_bin, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
                                                     lay_cur, tiled.as<float4>(), tiled_cap, keep_mask, keep_mshift)
 #define PCR_LAUNCH_BIN_P(VEC, PLACE, SUB) do { if (bin_per == 4) PCR_LAUNCH_BIN(VEC, 4, PLACE, SUB); else if (bin_per == 8) PCR_LAUNCH_BIN(VEC, 8, PLACE, SUB); else PCR_LAUNCH_BIN(VEC, 16, PLACE, SUB); } while (0)
-        if (use_layout && use_sub) { if (vec) PCR_LAUNCH_BIN_P(true, true, true); else PCR_LAUNCH_BIN_P(false, true, true); }
+        // region-only builds of large clouds: the region's points are listed first, the bin pass reads the list (grid_keep_kernel; PCR_NO_KEEP_PASS=1 in a
+        // development build: the bin pass tests the mask itself, as before)
+        const bool keep_pass = keep_mask != nullptr && n >= 2000000 && dev_env("PCR_NO_KEEP_PASS") == nullptr;      // (a 1 M-point lattice build -- VGICP's -- is 1.5 % SLOWER with the extra launch)
+        if (keep_pass) {
+            PCR_TRY(kept.reserve((n + 16) * sizeof(float4)));
+            uint32_t* const n_kept = ticket.as<uint32_t>() + 16;      // (zero between builds: the bin pass's last block puts it back)
+            const int keep_blocks = (int)std::min<size_t>(1024, (n + 2047) / 2048);
+            const uint32_t kept_cap = (uint32_t)std::min<size_t>(kept.cap / sizeof(float4), 0xfffffff0u);
+            if (vec) hipLaunchKernelGGL(grid_keep_kernel<true>, dim3(keep_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(), keep_mask, keep_mshift, kept.as<float4>(), kept_cap, n_kept);
+            else hipLaunchKernelGGL(grid_keep_kernel<false>, dim3(keep_blocks), dim3(256), 0, s, d_pts, n32, st, header.as<GridHeader>(), keep_mask, keep_mshift, kept.as<float4>(), kept_cap, n_kept);
+            const int packed_blocks = std::min(bin_blocks, dev_env("PCR_PACKED_BLOCKS") ? atoi(dev_env("PCR_PACKED_BLOCKS")) : 512);      // (a block takes chunk after chunk: the list's length is the device's to know)
+            const size_t lds8 = bin_lds;
+#define PCR_LAUNCH_BIN_PACKED(SUB) hipLaunchKernelGGL((grid_bin_kernel<true, 8, true, SUB, true>), dim3(packed_blocks), dim3(256), lds8, s, kept.as<float>(), n32, 4u, header.as<GridHeader>(), \
+                                                    bin_count.as<uint32_t>(), ranks.as<uint32_t>(), tshift, max_bins, nb_bin, ticket.as<uint32_t>() + 8, bin_start.as<uint32_t>(), \
+                                                    lay_cur, tiled.as<float4>(), tiled_cap, (const uint8_t*)nullptr, 0, n_kept)
+            if (use_sub) PCR_LAUNCH_BIN_PACKED(true); else PCR_LAUNCH_BIN_PACKED(false);
+#undef PCR_LAUNCH_BIN_PACKED
+        }
+        else if (use_layout && use_sub) { if (vec) PCR_LAUNCH_BIN_P(true, true, true); else PCR_LAUNCH_BIN_P(false, true, true); }
         else if (use_layout) { if (vec) PCR_LAUNCH_BIN_P(true, true, false); else PCR_LAUNCH_BIN_P(false, true, false); }
         else { if (vec) PCR_LAUNCH_BIN_P(true, false, false); else PCR_LAUNCH_BIN_P(false, false, false); }
 #undef PCR_LAUNCH_BIN_P

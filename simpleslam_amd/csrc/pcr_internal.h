@@ -193,6 +193,7 @@ struct BuildFilter {
 
 struct GridIndex {
     DeviceBuf sorted, cell_count, cell_start, block_sums, bbox_partials, header, keys, ranks, ticket;
+    DeviceBuf kept;                             // region-only builds: the points of the region as (x, y, z, original index), listed by grid_keep_kernel for the bin pass
     DeviceBuf tiled, bin_count, bin_start, tile_sq;      // tiled build path: points grouped by tile, points per tile, first point of every tile, sum of count^2 per tile
     int tiled_shift = -1;                       // log2(cells per tile) of the last build when it took the tiled path
     // Bounding-box hint: a build whose header the host has seen to be good (confirm()) lets the NEXT build of the same kind skip
