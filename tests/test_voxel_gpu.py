@@ -129,3 +129,42 @@ def test_other_point_layouts(gpu, clouds, stride):
     if stride > 3:
         np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=1e-5, atol=1e-3)
         assert np.all(got[:, 4:] == 0)
+
+
+def test_runs_that_span_many_waves_and_repeated_calls_on_one_handle(gpu):
+    """A voxel's points are summed by the waves that hold them (voxel_filter.hip: lead sums + a segmented scan): voxels of one point, of a few,
+    of 100 000 (1 563 waves), runs that start and end anywhere in a wave -- the centroid is the f64 mean to float rounding, whatever the run's
+    length.  The same handle then filters clouds of other sizes and places: the index's box and layout hints of the previous call are tried first
+    and must never change a result."""
+    rng = np.random.default_rng(7)
+    reg = LoamRegister()
+    sizes = [1, 2, 63, 64, 65, 100_000, 3, 4097, 129, 20_000]
+    chunks = []
+    for k, m in enumerate(sizes):
+        c = np.zeros((m, 4), np.float32)
+        c[:, :3] = np.array([3.0 * k, -2.0 * (k % 3), 1.0 * k], np.float32) + 0.2 + 0.5 * rng.random((m, 3), dtype=np.float32)      # all inside one 1 m voxel
+        c[:, 3] = rng.random(m, dtype=np.float32) * 100
+        chunks.append(c)
+    pts = np.concatenate(chunks)
+    pts = pts[rng.permutation(pts.shape[0])]
+    got = reg.voxelDownSample(pts, 1.0)
+    assert got.shape[0] == len(sizes)
+    key = np.floor(pts[:, :3].astype(np.float64)).astype(np.int64)
+    for row in got:
+        sel = np.all(key == np.floor(row[:3].astype(np.float64)).astype(np.int64), axis=1)
+        assert sel.sum() in sizes
+        np.testing.assert_allclose(row, pts[sel].astype(np.float64).mean(0), rtol=2e-7, atol=1e-6)
+    ref, _ = oracle.voxel_filter(pts, 1.0)
+    assert ref.shape == got.shape
+    # other clouds through the same handle: shifted (outside the previous box), smaller, larger, the first again
+    for shift, take in ((np.array([40.0, -25.0, 3.0], np.float32), 50_000), (np.zeros(3, np.float32), 500), (np.array([-300.0, 0.0, 0.0], np.float32), pts.shape[0]), (np.zeros(3, np.float32), pts.shape[0])):
+        q = pts[:take].copy(); q[:, :3] += shift
+        a = reg.voxelDownSample(q, 1.0)
+        b = LoamRegister().voxelDownSample(q, 1.0)          # a fresh handle: no hints
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=2e-7, atol=1e-6)   # (the order of a voxel's points in the index, hence of the f64 additions, may differ)
+        r, _ = oracle.voxel_filter(q, 1.0)
+        assert r.shape == a.shape                                 # same occupied voxels
+        # (centroids: the oracle adds in float as PCL does -- n * eps * |x| = 0.2 m for the 100 000-point voxel 290 m from the origin; the f64 means above are the check)
+        small = np.array([np.all(np.abs(x[:3] - y[:3]) < 0.5) for x, y in zip(a, r)])
+        assert small.all()
