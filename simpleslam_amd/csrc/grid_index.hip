@@ -1314,7 +1314,11 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     // (never more than 2^11 cells per tile unless the counter array forces it: a tile's block zeroes, scans and writes every cell of it,
     //  and a sparse fine grid -- 3.6 M cells for a 65 k-point scan -- is better served by many small tiles than by 440 blocks of 8 192 cells)
     int tshift;
-    if (cells_hint) { tshift = 2; while ((cells_hint >> tshift) > tiles_target && tshift < 11) ++tshift; }
+    // (the voxel filter's grids -- 65 536 points over 2.3 M cells of 0.5 m -- take tiles of 4 096 cells: half the bins for the bin pass's last block to read back,
+    //  7 % off a scan's filter; 8 192 cells: slower again.  Round 5, scripts/seq_breakdown.py, two rounds on one box.)
+    static const int vf_cap = dev_env("PCR_VF_TILE_SHIFT_MAX") ? atoi(dev_env("PCR_VF_TILE_SHIFT_MAX")) : 12;
+    const int tshift_cap = cut_sparse ? vf_cap : 11;
+    if (cells_hint) { tshift = 2; while ((cells_hint >> tshift) > tiles_target && tshift < tshift_cap) ++tshift; }
     else { tshift = 8; while (((uint64_t)cap_eff >> tshift) + 2 > 2048 && tshift < 11) ++tshift; }
     if (const char* e = dev_env("PCR_TILE_SHIFT")) tshift = std::max(2, atoi(e));      // (development: tile size sweep)
     while (((uint64_t)cap_eff >> tshift) + 2 > (uint64_t)kMaxBins) ++tshift;
