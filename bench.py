@@ -683,6 +683,7 @@ def sequence_leg(args, local_rank):
             drift = max(synth.pose_error(a, b)[0] for a, b in zip(r["poses"][:len(rc["poses"])], rc["poses"]))
             gt = [synth.pose_error(a, b)[0] for a, b in zip(r["poses"], truth)]
             line = {"value": n / r["seconds"], "ms_per_scan": 1e3 * r["seconds"] / n, "scan2map_ms_per_scan": 1e3 * r["scan2map_seconds"] / max(1, n - 1),
+                    "ms_per_scan_by_step": {k: round(1e3 * v / n, 4) for k, v in r["step_seconds"].items()},
                     "mean_iterations": float(np.mean(r["iterations"][1:])), "converged": int(sum(r["converged"])), "keyframes": r["keyframes"], "submap_assemblies": r["updates"],
                     "submap_points_last": int(r["submap_points"][-1]), "target_builds": int(st["target_builds"]),
                     "hints": {"index_builds": diag["builds"], "box_hint_held": diag["box_hint"], "tile_layout_held": diag["layout_hint"],

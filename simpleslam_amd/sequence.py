@@ -39,17 +39,21 @@ def make_drive(n_scans, seed, map_points=200_000, beams=64, azimuths=1024, step=
 
 
 def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap=MIN_KF_GAP):
-    """Run the loop; -> dict(poses, converged, iterations, submap_points, keyframes, updates, seconds, scan2map_seconds)."""
+    """Run the loop; -> dict(poses, converged, iterations, submap_points, keyframes, updates, seconds, scan2map_seconds, step_seconds).
+    step_seconds: host time per step of the loop, summed over the drive (every step but a queued assembly returns when its result is there, so no
+    synchronisation is added to measure them): voxel, wait (collecting a queued sub-map), scan2map, add_keyframe, update_map."""
     pose = np.array(start_pose, float)
     kf_pos, n_kf, last_update = np.zeros((len(scans), 3)), 0, None      # (one array: the nearest key frame by one numpy expression, not a Python loop over them)
     poses, conv, iters, sub_n = [], [], [], []
     updates = 0
     t_s2m = 0.0
+    ts = dict(voxel=0.0, wait=0.0, scan2map=0.0, add_keyframe=0.0, update_map=0.0)
+    clock = time.perf_counter
     t0 = time.perf_counter()
     for k, scan in enumerate(scans):
-        ds = front.voxel(scan, grid)
+        t1 = clock(); ds = front.voxel(scan, grid); ts["voxel"] += clock() - t1
         pose = pose @ cmds[k]
-        n_sub = front.submap_points()          # (collects an assembly the previous step queued)
+        t1 = clock(); n_sub = front.submap_points(); ts["wait"] += clock() - t1          # (collects an assembly the previous step queued)
         if k: sub_n.append(n_sub)              # sub-map after step k - 1 = the one scan k is registered against
         if n_sub > 0:
             t1 = time.perf_counter()
@@ -62,17 +66,18 @@ def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap
         need_update = last_update is None or float(np.linalg.norm(last_update - t)) > kf_gap       # setCurPose
         # putKeyFrame: nearestKSearch's squared distance against minKFGap (MapManager.cpp:141-143)
         if n_kf == 0 or float(np.min(np.sum((kf_pos[:n_kf] - t) ** 2, axis=1))) > kf_gap:
-            front.add_keyframe(scan, pose)
+            t1 = clock(); front.add_keyframe(scan, pose); ts["add_keyframe"] += clock() - t1
             kf_pos[n_kf] = t; n_kf += 1
         if need_update:
-            front.update_map(t, radius, grid)
+            t1 = clock(); front.update_map(t, radius, grid); ts["update_map"] += clock() - t1
             last_update = t.copy()
             updates += 1
         poses.append(pose.copy())
-    sub_n.append(front.submap_points())
+    t1 = clock(); sub_n.append(front.submap_points()); ts["wait"] += clock() - t1
     front.finish()
+    ts["scan2map"] = t_s2m
     return dict(poses=poses, converged=conv, iterations=iters, submap_points=sub_n, keyframes=n_kf, updates=updates,
-                seconds=time.perf_counter() - t0, scan2map_seconds=t_s2m)
+                seconds=time.perf_counter() - t0, scan2map_seconds=t_s2m, step_seconds=ts)
 
 
 class GpuFront:
