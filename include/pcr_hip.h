@@ -229,6 +229,8 @@ const char* pcr_map_last_error(const pcr_map* m);
 /* KeyFrame{pc, pose} (common/types/basic.hpp:33-40); pose = 16 doubles column-major.  Index of the new key frame = count - 1. */
 int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_bytes, int on_device, const double pose[16]);
 int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes);
+/* Forget every key frame and the sub-map (a new session: MapManager::reset), keep the device memory the store has grown to; starts a new generation. */
+int pcr_map_clear(pcr_map* m);
 int pcr_map_update(pcr_map* m, const double position[3], double radius, double grid_size, size_t* n_submap);
 /* The same in two halves, for a caller that has something else to do meanwhile -- the reference assembles its sub-map on a map thread of its own
  * (frontend/src/MapManager.cpp:109-119 notifies it and LidarOdometry goes on with the next scan): pcr_map_update_begin selects the key frames, starts a

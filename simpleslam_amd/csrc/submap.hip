@@ -169,6 +169,17 @@ int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_by
     return 0;
 }
 
+int pcr_map_clear(pcr_map* m) {
+    if (!m) return 1;
+    m->err.clear();
+    M_TRY(hipSetDevice(m->device));
+    (void)finish_pending(m); m->err.clear();
+    m->kfs.clear(); m->selected.clear();
+    m->store_floats = 0; m->n_submap = 0;
+    m->generation += 1;           // whatever was built from the previous sub-map is stale
+    return 0;
+}
+
 int pcr_map_keyframes(const pcr_map* m, size_t* n_keyframes) {
     if (!m || !n_keyframes) return 1;
     *n_keyframes = m->kfs.size();

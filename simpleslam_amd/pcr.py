@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
     "pcr_vgicp_covariances", "pcr_vgicp_neighbours", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info", "pcr_comm_peer_export", "pcr_comm_init_peer",
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
-    "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_update", "pcr_map_update_begin", "pcr_map_wait", "pcr_map_update_window", "pcr_map_submap",
+    "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_clear", "pcr_map_update", "pcr_map_update_begin", "pcr_map_wait", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices", "pcr_map_generation", "pcr_scan2map_submap",
     "pcr_ndt_opt_create", "pcr_ndt_opt_destroy", "pcr_ndt_opt_request", "pcr_ndt_opt_feed", "pcr_ndt_opt_result", "pcr_ndt_opt_counts",
     "pcr_vgicp_opt_create", "pcr_vgicp_opt_destroy", "pcr_vgicp_opt_request", "pcr_vgicp_opt_feed", "pcr_vgicp_opt_result",
@@ -162,6 +162,7 @@ def load_library():
     L.pcr_map_last_error.restype = C.c_char_p
     L.pcr_map_add_keyframe.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp]
     L.pcr_map_keyframes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.pcr_map_clear.argtypes = [vp]
     L.pcr_map_update.argtypes = [vp, dp, C.c_double, C.c_double, C.POINTER(C.c_size_t)]
     L.pcr_map_update_begin.argtypes = [vp, dp, C.c_double, C.c_double]
     L.pcr_map_wait.argtypes = [vp, C.POINTER(C.c_size_t)]
@@ -618,6 +619,10 @@ class SubMap:
         n = C.c_size_t(0)
         self._check(self._lib.pcr_map_update(self._m, pos.ctypes.data_as(C.POINTER(C.c_double)), float(radius), float(grid_size), C.byref(n)))
         return n.value
+
+    def clear(self):
+        """pcr_map_clear: forget the key frames and the sub-map, keep the device memory (a new session on a store that has grown)."""
+        self._check(self._lib.pcr_map_clear(self._m))
 
     def updateMapBegin(self, position, radius=8.0, grid_size=0.4):
         """pcr_map_update_begin: select + queue the assembly (the reference's map thread works beside the front end); wait() -- or whatever asks for

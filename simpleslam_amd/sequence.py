@@ -119,6 +119,11 @@ class GpuFront:
             self._n = self.map.wait()
         return self._n
 
+    def reset(self):
+        """A new session on the same handles: key frames and sub-map forgotten (pcr_map_clear), the device memory they grew to kept."""
+        self.map.clear()
+        self._n = 0
+
     def finish(self):
         import torch
         torch.cuda.synchronize()

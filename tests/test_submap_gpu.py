@@ -224,3 +224,23 @@ def test_an_update_in_two_halves_is_the_update(gpu, keyframes):
     assert halves.wait() == n and ca == cb
     np.testing.assert_array_equal(pose_a, pose_b)
     np.testing.assert_array_equal(halves.download(), whole.download())
+
+
+def test_a_cleared_map_is_a_new_map_on_the_old_memory(gpu, keyframes):
+    """pcr_map_clear: no key frame, no sub-map, a new generation -- and the same key frames added again give the sub-map a fresh store gives, bit for bit."""
+    world, kfs = keyframes
+    used, fresh = SubMap(), SubMap()
+    for c, T in kfs:
+        used.addKeyFrame(c, T)
+    used.updateMap(kfs[3][1][:3, 3], radius=8.0, grid_size=0.4)
+    g0 = used.generation()[1]
+    used.updateMapBegin(kfs[5][1][:3, 3], radius=8.0, grid_size=0.4)            # (a queued assembly is waited for and dropped)
+    used.clear()
+    assert used.keyframes() == 0 and used.generation()[1] > g0 + 1
+    assert used.updateMap(kfs[3][1][:3, 3], radius=8.0, grid_size=0.4) == 0 and used.pointer()[1] == 0 and len(used.submapIdx()) == 0
+    for c, T in kfs[2:9]:
+        used.addKeyFrame(c, T); fresh.addKeyFrame(c, T)
+    n = fresh.updateMap(kfs[4][1][:3, 3], radius=6.0, grid_size=0.4)
+    assert used.updateMap(kfs[4][1][:3, 3], radius=6.0, grid_size=0.4) == n > 0
+    np.testing.assert_array_equal(used.submapIdx(), fresh.submapIdx())
+    np.testing.assert_array_equal(used.download(), fresh.download())
