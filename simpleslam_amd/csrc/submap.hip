@@ -69,13 +69,15 @@ __global__ __launch_bounds__(256) void submap_transform_pack_kernel(const float*
 
 struct Buf {
     void* p = nullptr; size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
+    // keep: the contents move along (the key-frame store); the other buffers are written anew by every assembly
+    hipError_t reserve(size_t bytes, bool keep = true) {
         if (bytes <= cap) return hipSuccess;
         void* q = nullptr;
-        const size_t want = bytes + bytes / 2 + 4096;
+        const size_t want = 2 * bytes + 4096;      // (doubling: every growth is a device-wide stop -- allocation, copy, free -- and a session's first minutes are made of them)
         hipError_t e = hipMalloc(&q, want);
         if (e != hipSuccess) return e;
-        if (p) { e = hipMemcpy(q, p, cap, hipMemcpyDeviceToDevice); (void)hipFree(p); if (e != hipSuccess) { (void)hipFree(q); p = nullptr; cap = 0; return e; } }
+        if (p && !keep) (void)hipFree(p);
+        else if (p) { e = hipMemcpy(q, p, cap, hipMemcpyDeviceToDevice); (void)hipFree(p); if (e != hipSuccess) { (void)hipFree(q); p = nullptr; cap = 0; return e; } }
         p = q; cap = want;
         return hipSuccess;
     }
@@ -202,9 +204,9 @@ static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap, boo
     }
     if (total == 0) return 0;
     const size_t sf = m->stride / 4;
-    M_TRY(m->concat.reserve(total * m->stride));
-    M_TRY(m->submap.reserve(total * m->stride));
-    M_TRY(m->desc.reserve(desc.size() * sizeof(KfDesc)));
+    M_TRY(m->concat.reserve(total * m->stride, false));
+    M_TRY(m->submap.reserve(total * m->stride, false));
+    M_TRY(m->desc.reserve(desc.size() * sizeof(KfDesc), false));
     // the descriptors and the transform pass go onto the FILTER's stream, in front of the filter's own launches: one synchronisation -- the filter's,
     // for its voxel count -- serves the whole assembly (round 4: a blocking copy, the pass on the null stream, a device-wide synchronisation, then the
     // filter with two more: 0.49 ms for a 500 k-point concatenation of which a third was waiting; round 5, scripts/seq_breakdown.py)
