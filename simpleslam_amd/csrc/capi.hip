@@ -1960,7 +1960,13 @@ int pcr_scan2map_submap(pcr_handle* h, const void* src, size_t n_src, int src_on
     double need = current ? 0.0 : 1.0;
     if (sharded(h) && ranks_allreduce(h, &need, 1, 1)) return 1;
     if (need != 0.0) {
-        if (prepare_target_from(h, static_cast<const float*>(d_dst), n_dst, stride_bytes)) return 1;
+        // VGICP, a scan that is in HBM already: its side goes onto the side stream FIRST and runs beside the new sub-map's preparation (clouds of a few ten
+        // thousand points: the device is mostly idle behind either)
+        if (h->method == kVgicp && !sharded(h) && src_on_device && n_src > 0 && src && vgicp_source_enqueue(h, static_cast<const float*>(src), n_src, stride_bytes / 4)) return 1;
+        if (prepare_target_from(h, static_cast<const float*>(d_dst), n_dst, stride_bytes)) {
+            if (h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }      // (nothing of this call stays in flight)
+            return 1;
+        }
         h->map_id = id; h->map_gen = gen;
         h->target_builds += 1;
     }
@@ -1980,7 +1986,16 @@ int pcr_align(pcr_handle* h, const void* src, size_t n_src, size_t stride_bytes,
     const float* d_src = (const float*)src;
     if (!on_device && stage_host(h, &h->src_stage, src, n_src, stride_bytes, &d_src)) return 1;
     if (h->method == kNdt) return run_ndt(h, d_src, n_src, stride_bytes / 4, pose_inout, converged);
-    if (h->method == kVgicp) return vgicp_align_recut(h, d_src, n_src, stride_bytes / 4, pose_inout, converged) ? 1 : 0;
+    if (h->method == kVgicp) {
+        // the scan's own side (two index levels, the 20-neighbour search, the covariances) queued on the side stream with its headers mirrored to the host, as
+        // pcr_scan2map queues it -- unless pcr_scan2map_submap has queued it already, ahead of the target's preparation.  Settled the checked way (a header
+        // read back after every level: two host round trips with an idle device in between, ~55 us of a 0.3 ms call against a kept sub-map) only if that fails.
+        if (!sharded(h) && n_src > 0 && !(h->side_pending && h->side_src == d_src && h->side_n == n_src && h->side_stride == stride_bytes / 4) &&
+            vgicp_source_enqueue(h, d_src, n_src, stride_bytes / 4)) return 1;
+        const int rc = vgicp_align_recut(h, d_src, n_src, stride_bytes / 4, pose_inout, converged) ? 1 : 0;
+        if (h->side_pending) { (void)hipEventSynchronize(h->ev_side_done); h->side_pending = false; }      // (an alignment that failed before it collected the scan's side: nothing stays in flight behind the caller's back)
+        return rc;
+    }
     return run_loam(h, d_src, n_src, stride_bytes / 4, pose_inout, converged, false);
 }
 
