@@ -214,6 +214,13 @@ int pcr_vgicp_linearize(pcr_handle* h, const void* src, size_t n_src, size_t str
 int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_bytes, int on_device, double leaf, void* out,
                      size_t out_capacity, int out_on_device, size_t* n_out);
 
+/* The same in two halves, device memory in and out: _begin queues the filter on the handle's stream and returns, _end waits for it and returns the voxel
+ * count (the filter's one synchronisation).  For a caller that has the NEXT scan while this one is being registered -- replaying a recording, or a
+ * front end that lags its sensor: filter it on a second handle (a stream of its own) meanwhile.  out_capacity >= n; input and output stay untouched until _end.
+ * One filter per handle at a time (pcr_voxel_filter on that handle in between is refused). */
+int pcr_voxel_filter_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity);
+int pcr_voxel_filter_end(pcr_handle* h, size_t* n_out);
+
 /* ---- the producer of `dst`: MapManager's key-frame store and sub-map assembly, on the device ----
  * MapManager::updateMap (frontend/src/MapManager.cpp:151-201): key frames whose position lies within `radius`
  * (mSurroundingKeyframeSearchRadius = 8 m, MapManager.hpp:68; squared L2 in double, strict '<' like

@@ -129,6 +129,7 @@ struct pcr_handle {
     double* out48_dev = nullptr;
     DeviceBuf nd_ctl;                    // NdtCtl: the device-resident optimiser's state
     struct VfJob { const float* d_pts; size_t n, sf; double leaf; float* d_out; size_t cap; } vf_job = {};      // the filter that is queued (vf_enqueue / vf_settle)
+    bool vf_inflight = false; size_t vf_inflight_n = 0;      // pcr_voxel_filter_begin has queued a filter that pcr_voxel_filter_end has not collected
     unsigned long long vf_builds = 0, vf_stale = 0;      // index builds of the voxel filter, and how many found the reused box / layout too small
     char* vf_ret = nullptr;              // page-locked: what the voxel filter's last block reports (VfResult: the voxel count + the index header's verdict)
     DeviceBuf vg_reduced;                // sharded VGICP over the peer exchange: a pass's 32 sums folded over the rows and the ranks
@@ -2109,6 +2110,7 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
     if (!(leaf > 0)) return fail(h, "leaf size must be positive");
     if (n > 0xfffffff0ull) return fail(h, "cloud too large");
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    if (h->vf_inflight) return fail(h, "a voxel filter is queued on this handle (pcr_voxel_filter_begin): collect it with pcr_voxel_filter_end first");
     if (n == 0) return 0;
     const size_t sf = stride_bytes / 4;
     const float* d_pts = static_cast<const float*>(pts);
@@ -2136,6 +2138,32 @@ int pcr_voxel_filter(pcr_handle* h, const void* pts, size_t n, size_t stride_byt
     if (count > out_capacity) return fail(h, "output capacity too small: " + std::to_string(count) + " voxels are occupied");
     if (!out_on_device && count) H_TRY(hipMemcpy(out, d_out, (size_t)count * stride_bytes, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int pcr_voxel_filter_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity) {
+    if (!h) return 1;
+    h->err.clear();
+    if (h->vf_inflight) return fail(h, "a voxel filter is already queued on this handle: collect it with pcr_voxel_filter_end first");
+    if (n && (!d_pts || !d_out)) return fail(h, "NULL cloud or output with nonzero size");
+    if (out_capacity < n) return fail(h, "pcr_voxel_filter_begin needs room for n points (a leaf too small for the data returns the input unfiltered)");
+    if (!(leaf > 0)) return fail(h, "leaf size must be positive");
+    if (n > 0xfffffff0ull) return fail(h, "cloud too large");
+    if (check_stride(h, stride_bytes) || set_device(h)) return 1;
+    h->vf_inflight_n = n;
+    if (n && pcr_internal_vf_begin(h, d_pts, n, stride_bytes, leaf, d_out, out_capacity)) return 1;
+    h->vf_inflight = true;
+    return 0;
+}
+
+int pcr_voxel_filter_end(pcr_handle* h, size_t* n_out) {
+    if (!h) return 1;
+    if (!n_out) return fail(h, "n_out is NULL");
+    *n_out = 0;
+    if (!h->vf_inflight) return fail(h, "no voxel filter is queued on this handle");
+    h->vf_inflight = false;
+    h->err.clear();
+    if (h->vf_inflight_n == 0) return 0;
+    return pcr_internal_vf_end(h, n_out);
 }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ class PcrStats(C.Structure):
 ABI_SYMBOLS = [
     "pcr_default_params", "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_scan2map", "pcr_scan2map_device", "pcr_host_pin", "pcr_host_unpin",
     "pcr_set_target", "pcr_align", "pcr_invalidate_target", "pcr_fitness", "pcr_loam_linearize", "pcr_get_trace", "pcr_get_trace_counts",
-    "pcr_vgicp_covariances", "pcr_vgicp_neighbours", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info", "pcr_comm_peer_export", "pcr_comm_init_peer",
+    "pcr_vgicp_covariances", "pcr_vgicp_neighbours", "pcr_vgicp_linearize", "pcr_voxel_filter", "pcr_voxel_filter_begin", "pcr_voxel_filter_end", "pcr_get_timeline", "pcr_ndt_derivatives", "pcr_get_stats", "pcr_set_profile", "pcr_set_stream", "pcr_set_query_tile", "pcr_comm_unique_id", "pcr_comm_init", "pcr_comm_info", "pcr_comm_peer_export", "pcr_comm_init_peer",
     "pcr_comm_init_host", "pcr_set_shard", "pcr_set_params", "pcr_get_params", "pcr_fitness_gated",
     "pcr_map_create", "pcr_map_destroy", "pcr_map_last_error", "pcr_map_add_keyframe", "pcr_map_keyframes", "pcr_map_clear", "pcr_map_update", "pcr_map_update_begin", "pcr_map_wait", "pcr_map_update_window", "pcr_map_submap",
     "pcr_map_submap_indices", "pcr_map_generation", "pcr_scan2map_submap",
@@ -123,6 +123,8 @@ def load_library():
     L.pcr_ndt_derivatives.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, dp, dp]
     L.pcr_get_timeline.argtypes = [vp, vp, C.c_size_t, ip, ip]
     L.pcr_voxel_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, vp, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    L.pcr_voxel_filter_begin.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_double, vp, C.c_size_t]
+    L.pcr_voxel_filter_end.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.pcr_get_stats.argtypes = [vp, C.POINTER(PcrStats)]
     L.pcr_scan2map_submap.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, dp, ip]
     L.pcr_ndt_opt_create.restype = vp
@@ -345,6 +347,21 @@ class PointCloudRegister:
         out = np.zeros((max(n, 1), s // 4), np.float32)
         self._check(self._lib.pcr_voxel_filter(self._h, p, n, s, 0, float(grid_size), out.ctypes.data_as(C.c_void_p), n, 0, C.byref(cnt)))
         return out[:cnt.value].copy()
+
+    def voxelDownSampleBegin(self, cloud, grid_size):
+        """pcr_voxel_filter_begin for a CUDA tensor: queue the filter, return a token for voxelDownSampleEnd (the input must stay alive until then)."""
+        import torch
+        p, n, s, dev, keep = _cloud(cloud)
+        if not dev:
+            raise PcrError("voxelDownSampleBegin takes a CUDA tensor")
+        out = torch.empty((max(n, 1), s // 4), dtype=torch.float32, device=keep.device)
+        self._check(self._lib.pcr_voxel_filter_begin(self._h, p, n, s, float(grid_size), C.c_void_p(out.data_ptr()), n))
+        return (out, keep)
+
+    def voxelDownSampleEnd(self, token):
+        cnt = C.c_size_t(0)
+        self._check(self._lib.pcr_voxel_filter_end(self._h, C.byref(cnt)))
+        return token[0][:cnt.value]
 
     # -- introspection ---------------------------------------------------------
     def stats(self):

@@ -38,10 +38,12 @@ def make_drive(n_scans, seed, map_points=200_000, beams=64, azimuths=1024, step=
     return scans, truth, cmds
 
 
-def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap=MIN_KF_GAP):
+def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap=MIN_KF_GAP, prefetch=False):
     """Run the loop; -> dict(poses, converged, iterations, submap_points, keyframes, updates, seconds, scan2map_seconds, step_seconds).
     step_seconds: host time per step of the loop, summed over the drive (every step but a queued assembly returns when its result is there, so no
-    synchronisation is added to measure them): voxel, wait (collecting a queued sub-map), scan2map, add_keyframe, update_map."""
+    synchronisation is added to measure them): voxel, wait (collecting a queued sub-map), scan2map, add_keyframe, update_map.
+    prefetch: the NEXT scan's voxel filter is queued (front.prefetch) before this scan is registered -- a caller that has the next scan already (a
+    recording replayed, a front end that lags its sensor); a front without prefetch() filters in place, so the results are the same either way."""
     pose = np.array(start_pose, float)
     kf_pos, n_kf, last_update = np.zeros((len(scans), 3)), 0, None      # (one array: the nearest key frame by one numpy expression, not a Python loop over them)
     poses, conv, iters, sub_n = [], [], [], []
@@ -51,7 +53,9 @@ def drive(front, scans, cmds, start_pose, grid=0.5, radius=SEARCH_RADIUS, kf_gap
     clock = time.perf_counter
     t0 = time.perf_counter()
     for k, scan in enumerate(scans):
-        t1 = clock(); ds = front.voxel(scan, grid); ts["voxel"] += clock() - t1
+        t1 = clock(); ds = front.voxel(scan, grid); ts["voxel"] += clock() - t1          # (collects the prefetched filter of this scan, if one was queued)
+        if prefetch and k + 1 < len(scans) and hasattr(front, "prefetch"):
+            t1 = clock(); front.prefetch(scans[k + 1], grid); ts["voxel"] += clock() - t1
         pose = pose @ cmds[k]
         t1 = clock(); n_sub = front.submap_points(); ts["wait"] += clock() - t1          # (collects an assembly the previous step queued)
         if k: sub_n.append(n_sub)              # sub-map after step k - 1 = the one scan k is registered against
@@ -92,9 +96,22 @@ class GpuFront:
         self._n = 0
         self.calls = [] if record else None
         self._sub_host = None
+        self._filt, self._pre = None, None      # prefetch(): the filter's own handle, the filter in flight (scan, grid, token)
 
     def voxel(self, scan, grid):
+        if self._pre is not None and self._pre[0] is scan and self._pre[1] == grid:      # queued by prefetch(): collect it
+            tok, self._pre = self._pre[2], None
+            return self._filt.voxelDownSampleEnd(tok)
         return self.reg.voxelDownSample(scan, grid)
+
+    def prefetch(self, scan, grid):
+        """Queue the voxel filter of a scan that is registered LATER, on a handle (a stream) of its own: pcr_voxel_filter_begin."""
+        if self._filt is None:
+            from .pcr import make_register
+            self._filt = make_register("loam")      # (any method: the filter is the handle's, not the registrar's)
+        if self._pre is not None:
+            self._filt.voxelDownSampleEnd(self._pre[2])
+        self._pre = (scan, grid, self._filt.voxelDownSampleBegin(scan, grid))
 
     def scan2map(self, ds, pose):
         init = pose.copy() if self.calls is not None else None
@@ -123,6 +140,8 @@ class GpuFront:
         """A new session on the same handles: key frames and sub-map forgotten (pcr_map_clear), the device memory they grew to kept."""
         self.map.clear()
         self._n = 0
+        if self._pre is not None:
+            self._filt.voxelDownSampleEnd(self._pre[2]); self._pre = None
 
     def finish(self):
         import torch

@@ -68,3 +68,24 @@ def test_hint_statistics_are_reported(drive_inputs):
     st = reg.stats()
     assert st["index_box_hint"] in (0, 1) and st["index_layout_hint"] in (0, 1)
     assert st["index_layout_hint"] <= st["index_box_hint"]       # a layout is only ever used together with the reused header
+
+
+@pytest.mark.parametrize("method", ["loam", "ndt", "vgicp"])
+def test_a_second_session_and_a_filter_queued_ahead_change_nothing(drive_inputs, method):
+    """The drive again on the same handles after pcr_map_clear (what bench.py times), and once more with the next scan's voxel filter queued on a
+    second handle before the current scan is registered (pcr_voxel_filter_begin / _end): the poses of all three are the same, bit for bit."""
+    import torch
+    from simpleslam_amd import make_register, sequence
+    scans, truth, cmds = drive_inputs
+    d_scans = [torch.from_numpy(s).cuda() for s in scans]
+    front = sequence.GpuFront(make_register(method))
+    first = sequence.drive(front, d_scans, cmds, truth[0])
+    front.reset()
+    again = sequence.drive(front, d_scans, cmds, truth[0])
+    front.reset()
+    ahead = sequence.drive(front, d_scans, cmds, truth[0], prefetch=True)
+    for r in (again, ahead):
+        assert r["keyframes"] == first["keyframes"] and r["updates"] == first["updates"] and r["submap_points"] == first["submap_points"]
+        assert r["converged"] == first["converged"] and r["iterations"] == first["iterations"]
+        for a, b in zip(r["poses"], first["poses"]):
+            np.testing.assert_array_equal(a, b)

@@ -168,3 +168,33 @@ def test_runs_that_span_many_waves_and_repeated_calls_on_one_handle(gpu):
         # (centroids: the oracle adds in float as PCL does -- n * eps * |x| = 0.2 m for the 100 000-point voxel 290 m from the origin; the f64 means above are the check)
         small = np.array([np.all(np.abs(x[:3] - y[:3]) < 0.5) for x, y in zip(a, r)])
         assert small.all()
+
+
+def test_filter_in_two_halves_on_a_second_handle(gpu, clouds):
+    """pcr_voxel_filter_begin / _end: the filter queued on one handle while another registers; same voxels, bit for bit, as the call in one piece on a
+    handle in the same state; misuse is refused."""
+    import torch
+    from simpleslam_amd import pcr
+    a, b = LoamRegister(), LoamRegister()
+    other = LoamRegister()
+    scan = torch.from_numpy(np.ascontiguousarray(clouds["scan"])).cuda()
+    m = torch.from_numpy(np.ascontiguousarray(clouds["map"][:200_000])).cuda()
+    for rep in range(3):                                                  # (repeated: the hints of the previous call are in play on both handles alike)
+        q = scan + float(rep)
+        tok = a.voxelDownSampleBegin(q, 0.4)
+        pose = np.eye(4)
+        other.scan2Map(scan, m, pose)                                     # another handle works meanwhile
+        got = a.voxelDownSampleEnd(tok)
+        ref = b.voxelDownSample(q, 0.4)
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    tok = a.voxelDownSampleBegin(scan, 0.4)
+    with pytest.raises(pcr.PcrError):
+        a.voxelDownSampleBegin(scan, 0.4)                                 # one at a time
+    with pytest.raises(pcr.PcrError):
+        a.voxelDownSample(scan, 0.4)
+    assert a.voxelDownSampleEnd(tok).shape[0] > 0
+    with pytest.raises(pcr.PcrError):
+        a.voxelDownSampleEnd(tok)                                         # nothing queued
+    empty = torch.zeros((0, 4), dtype=torch.float32, device="cuda")
+    assert a.voxelDownSampleEnd(a.voxelDownSampleBegin(empty, 0.4)).shape[0] == 0
