@@ -2027,9 +2027,10 @@ int vf_begin(pcr_handle* h, const float* d_pts, size_t n, size_t sf, double leaf
     // The index reuses the previous call's box and tile layout when the cloud still fits (GridIndex::hint_ok): the order of the voxels -- idx sorts by
     // (z, y, x) -- does not depend on where the box starts, so the output is the same either way; a cloud that does not fit comes back `stale` and is
     // built afresh, from then on with room around the box (a sub-map's box moves with the vehicle) and half as much again per bin.
-    H_TRY(h->vf_head.reserve((n + 4096) * sizeof(uint32_t)));
-    H_TRY(h->vf_sums.reserve((n / 2048 + 2) * sizeof(uint32_t)));
-    H_TRY(h->vf_count.reserve(voxel_filter_wave_bytes(n)));
+    const size_t nr = std::max(n, h->vf_grid.reserve_points);
+    H_TRY(h->vf_head.reserve((nr + 4096) * sizeof(uint32_t)));
+    H_TRY(h->vf_sums.reserve((nr / 2048 + 2) * sizeof(uint32_t)));
+    H_TRY(h->vf_count.reserve(voxel_filter_wave_bytes(nr)));
     if (!h->vf_ret) H_TRY(hipHostMalloc((void**)&h->vf_ret, sizeof(VfResult) + 64, hipHostMallocDefault));
     h->vf_grid.no_hints = h->prm.index_no_hints != 0;
     h->vf_grid.cut_sparse = true; h->vf_grid.coherent_input = true;
@@ -2080,6 +2081,7 @@ int pcr_internal_vf_begin(pcr_handle* h, const void* d_pts, size_t n, size_t str
     if (check_stride(h, stride_bytes) || set_device(h)) return 1;
     return vf_begin(h, static_cast<const float*>(d_pts), n, stride_bytes / 4, leaf, static_cast<float*>(d_out), out_capacity);
 }
+void pcr_internal_vf_reserve(pcr_handle* h, size_t points) { if (h && points <= 0xfffffff0ull) h->vf_grid.reserve_points = std::max(h->vf_grid.reserve_points, points); }
 int pcr_internal_vf_end(pcr_handle* h, size_t* n_out) {
     if (!h || !n_out) return 1;
     *n_out = 0;

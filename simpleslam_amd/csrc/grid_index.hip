@@ -1290,10 +1290,11 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     if (filter) { filter->applied = false; filter->tail_applied = false; }
     const bool force_atomic_path = dev_env("PCR_INDEX_ATOMIC") != nullptr;      // A/B switch for profiling the two build paths
     if (n > 0xfffffff0ull) { if (err) *err = "target cloud too large (>= 2^32 points)"; return hipErrorInvalidValue; }
-    PCR_TRY(sorted.reserve((n + 16) * sizeof(float4)));   // padded: the search reads whole chunks
+    const size_t n_res = std::max(n, reserve_points);      // (reserve_points: the caller knows its clouds will grow to that -- the sub-map assembly's concatenations)
+    PCR_TRY(sorted.reserve((n_res + 16) * sizeof(float4)));   // padded: the search reads whole chunks
     PCR_TRY(bbox_partials.reserve(kBBoxBlocks * 6 * sizeof(float)));
-    PCR_TRY(keys.reserve((n + 1) * sizeof(uint32_t)));
-    PCR_TRY(ranks.reserve((n + 1) * sizeof(uint32_t)));
+    PCR_TRY(keys.reserve((n_res + 1) * sizeof(uint32_t)));
+    PCR_TRY(ranks.reserve((n_res + 1) * sizeof(uint32_t)));
     if (!ticket.p) {
         PCR_TRY(ticket.reserve(256));
         PCR_TRY(hipMemsetAsync(ticket.p, 0, 256, s));
@@ -1352,7 +1353,7 @@ hipError_t GridIndex::build(const float* d_pts, size_t n, size_t stride_floats, 
     // thousand points -- never more than kMaxBins.
     if (tiled_path) {
         const uint32_t max_bins = (uint32_t)(((uint64_t)cap_eff >> tshift) + 2);      // tiles the (bounded) cell table can make
-        PCR_TRY(tiled.reserve((n + 16) * sizeof(float4)));
+        PCR_TRY(tiled.reserve((n_res + 16) * sizeof(float4)));
         PCR_TRY(bin_start.reserve((kMaxBins + 8) * sizeof(uint32_t)));
         PCR_TRY(tile_sq.reserve((kMaxBins + 8) * sizeof(unsigned long long)));
         tiled_shift = tshift;

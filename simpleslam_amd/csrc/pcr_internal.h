@@ -237,6 +237,7 @@ struct GridIndex {
     uint64_t cells_hint = 0;    // cells of the last header of this index the host has seen (0: none): bounds the next build's cell count and sets its tile size
     void note_cells(uint64_t n_cells) { if (n_cells) cells_hint = n_cells; }
     size_t n_points = 0;
+    size_t reserve_points = 0;  // build() sizes its point-sized buffers for at least that many points (a caller whose clouds grow: every growth is an allocation and a free, device-wide stops)
     bool valid = false;
     GridView view() const {
         return GridView{header.as<GridHeader>(), sorted.as<float4>(), cell_start.as<uint32_t>()};
@@ -437,3 +438,5 @@ hipStream_t pcr_internal_stream(const pcr_handle* h);
 // ... and the voxel filter in two halves, device memory into device memory (out_capacity >= n): queue it; synchronise and collect it (redone there if the index's hints did not hold)
 int pcr_internal_vf_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity);
 int pcr_internal_vf_end(pcr_handle* h, size_t* n_out);
+// ... and a hint: clouds of up to `points` points will come (the filter's and its index's buffers are sized for that at the next call)
+void pcr_internal_vf_reserve(pcr_handle* h, size_t points);

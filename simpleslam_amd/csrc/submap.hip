@@ -24,6 +24,7 @@
 hipStream_t pcr_internal_stream(const pcr_handle* h);
 int pcr_internal_vf_begin(pcr_handle* h, const void* d_pts, size_t n, size_t stride_bytes, double leaf, void* d_out, size_t out_capacity);
 int pcr_internal_vf_end(pcr_handle* h, size_t* n_out);
+void pcr_internal_vf_reserve(pcr_handle* h, size_t points);
 
 namespace {
 
@@ -86,6 +87,8 @@ struct Buf {
 
 }  // namespace
 
+static constexpr int kWindow = 16;      // key frames a sub-map is expected to hold (8 m radius, a key frame per metre: MapManager.hpp:67-68)
+
 struct pcr_map {
     int device = 0;
     pcr_handle* filter = nullptr;     // device context of the voxel filter
@@ -98,6 +101,7 @@ struct pcr_map {
     std::vector<Kf> kfs;
     std::vector<long long> selected;  // mSubmapIdx
     size_t n_submap = 0;
+    size_t max_kf_points = 0;         // the largest key frame so far: buffers are sized for a window of kWindow such key frames from the start
     bool pending = false;             // an assembly is queued on the filter's stream and has not been collected (pcr_map_update_begin): n_submap is not known yet
     uint64_t id = 0, generation = 0;  // identity of this store and of the sub-map it currently holds (every update is a new generation)
     std::string err;
@@ -157,7 +161,9 @@ int pcr_map_add_keyframe(pcr_map* m, const void* pts, size_t n, size_t stride_by
     M_TRY(hipSetDevice(m->device));
     if (finish_pending(m)) return 1;      // (a queued assembly reads the store, which may move below)
     const size_t nf = n * (stride_bytes / 4);
-    M_TRY(m->store.reserve((m->store_floats + nf + 4) * sizeof(float)));
+    m->max_kf_points = std::max(m->max_kf_points, n);
+    // (room for a window of key frames from the first one on: a store that grows is copied, and every growth is a device-wide stop)
+    M_TRY(m->store.reserve((std::max(m->store_floats + nf, (size_t)kWindow * nf) + 4) * sizeof(float)));
     if (nf && on_device) {      // on the filter's stream, waited for: the caller may reuse its buffer when this returns (the blocking copy on the null stream took 60 us for 1 MB, round 5)
         hipStream_t fs = pcr_internal_stream(m->filter);
         M_TRY(hipMemcpyAsync(static_cast<float*>(m->store.p) + m->store_floats, pts, nf * sizeof(float), hipMemcpyDeviceToDevice, fs));
@@ -204,8 +210,10 @@ static int assemble_selected(pcr_map* m, double grid_size, size_t* n_submap, boo
     }
     if (total == 0) return 0;
     const size_t sf = m->stride / 4;
-    M_TRY(m->concat.reserve(total * m->stride, false));
-    M_TRY(m->submap.reserve(total * m->stride, false));
+    const size_t room = std::max(total, (size_t)kWindow * m->max_kf_points);      // (the concatenation of a window of key frames: the buffers, the filter's and its index's, start at that size)
+    M_TRY(m->concat.reserve(room * m->stride, false));
+    M_TRY(m->submap.reserve(room * m->stride, false));
+    pcr_internal_vf_reserve(m->filter, room);
     M_TRY(m->desc.reserve(desc.size() * sizeof(KfDesc), false));
     // the descriptors and the transform pass go onto the FILTER's stream, in front of the filter's own launches: one synchronisation -- the filter's,
     // for its voxel count -- serves the whole assembly (round 4: a blocking copy, the pass on the null stream, a device-wide synchronisation, then the
