@@ -2034,6 +2034,8 @@ int vf_begin(pcr_handle* h, const float* d_pts, size_t n, size_t sf, double leaf
     if (!h->vf_ret) H_TRY(hipHostMalloc((void**)&h->vf_ret, sizeof(VfResult) + 64, hipHostMallocDefault));
     h->vf_grid.no_hints = h->prm.index_no_hints != 0;
     h->vf_grid.cut_sparse = true; h->vf_grid.coherent_input = true;
+    // (room around the box and in the bins from the first build on: a handle's second cloud never fits the first one's tight box, and that build was made twice)
+    if (h->vf_grid.hint_margin == 0) { h->vf_grid.hint_margin = 16; h->vf_grid.hint_margin_z_pcl = 4; h->vf_grid.lay_room_shift = 1; h->vf_grid.lay_room_add = 256; }
     h->vf_job = pcr_handle::VfJob{d_pts, n, sf, leaf, d_out, cap};
     return vf_enqueue(h);
 }
